@@ -1,0 +1,106 @@
+"""Generate tests/golden/* from the reference's committed data.  RUN IN THE BUILD
+CONTAINER ONLY (it reads /root/reference, which does not exist on the GPU box).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.
+
+What is written (all plain numpy arrays; pickles are never shipped because
+``pickle.load`` executes code):
+  weights_<case>.npz   the reference's trained weights (W0..Wn, b0..bn, layers)
+                       converted from the committed pickles
+                       (INF:159-186 ``save_NN``/``load_NN`` format [W_list, b_list]).
+  golden_<case>.npz    on a fixed seeded 1024-point set inside the case's domain:
+                       Y [N,7], dY [3,N,7], residuals f [N,7] (net_f_sig, INF:221-265),
+                       sumsq [7], flat gradient of sum_i sumsq_i/N (float64 oracle).
+  fem_<case>.npz       <=600 FEM nodes x 5 frames sub-sampled from the reference's
+                       FEM_result/ProbeData-k.mat (fields x,y,u,v,s11,s22,s12) --
+                       physics-sanity bands only (SURVEY Appx C), plus the oracle's
+                       prediction on them.
+Usage:  python -m oracle.make_golden
+"""
+from __future__ import annotations
+
+import os
+import pickle
+
+import numpy as np
+import scipy.io
+
+from . import pinn_oracle as po
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# case -> (pickle, lb, ub, normalize, FEM dir, FEM coordinate shift, frames per second, source disc)
+CASES = {
+    # INF:641-650 domain/source; INF:191 normalised inputs; INF:455-456 FEM shift +30
+    "inf20s": dict(pkl="ElasticWaveInfinite/uv_NN_20s.pickle", lb=[0, 0, 0], ub=[30, 30, 20.0],
+                   normalize=True, fem="ElasticWaveInfinite/FEM_result", shift=30.0, fps=4.0,
+                   src=(15.0, 15.0, 2.0), frames=(10, 20, 30, 40, 60), case="infinite"),
+    "inf10s": dict(pkl="ElasticWaveInfinite/uv_NN_10s.pickle", lb=[0, 0, 0], ub=[30, 30, 10.0],
+                   normalize=True, fem=None, shift=30.0, fps=4.0, src=(15.0, 15.0, 2.0), frames=(),
+                   case="infinite"),
+    # SEMI:675-676 domain [-15,15]^2 x [0,16], raw inputs SEMI:198, FEM shift +45 (SEMI:475-476),
+    # source disc r=2 at (0,0) (SEMI:682-684)
+    "semi16s": dict(pkl="ElasticWaveSemiInfinite/uv_NN#16s.pickle", lb=[-15, -15, 0], ub=[15, 15, 16.0],
+                    normalize=False, fem="ElasticWaveSemiInfinite/FEM_result", shift=45.0, fps=4.0,
+                    src=(0.0, 0.0, 2.0), frames=(12, 24, 32, 48, 64), case="semi_infinite"),
+    # CONF:887-888 domain, raw inputs CONF:235, FEM shift +15 (CONF:605-606), source CONF:896-898
+    "conf14s": dict(pkl="ElasticWaveConfined/uv_NN_14s_float64_new.pickle", lb=[-15, -15, 0], ub=[15, 15, 14.0],
+                    normalize=False, fem="ElasticWaveConfined/FEM_result/30x30_gauss_fine", shift=15.0, fps=4.0,
+                    src=(0.0, 0.0, 2.0), frames=(8, 16, 28, 40, 56), case="confined"),
+}
+
+
+def load_pickle(path):
+    with open(path, "rb") as f:
+        W, b = pickle.load(f, encoding="latin1")
+    return [np.asarray(w) for w in W], [np.asarray(x).reshape(-1) for x in b]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(1111)
+    for name, c in CASES.items():
+        W, b = load_pickle(os.path.join(REF, c["pkl"]))
+        layers = [W[0].shape[0]] + [w.shape[1] for w in W]
+        np.savez_compressed(os.path.join(OUT, f"weights_{name}.npz"), layers=np.array(layers),
+                            **{f"W{i}": w for i, w in enumerate(W)}, **{f"b{i}": x for i, x in enumerate(b)})
+        flat = po.pack_params(W, b)
+        lb, ub = np.array(c["lb"], float), np.array(c["ub"], float)
+        N = 1024
+        X = lb + (ub - lb) * rng.random((4 * N, 3))
+        xc, yc, r = c["src"]
+        X = X[(X[:, 0] - xc) ** 2 + (X[:, 1] - yc) ** 2 > r * r][:N]      # DelSrcPT, INF:619-622
+        out = po.wave2d_fields(flat, layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, c["normalize"])
+        tw = np.ones(7) / N
+        ss, g, f = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, c["normalize"],
+                                       term_weights=tw)
+        np.savez_compressed(os.path.join(OUT, f"golden_{name}.npz"), X=X, lb=lb, ub=ub,
+                            normalize=np.array(c["normalize"]), Y=out["Y"], dY=np.stack(out["dY"]),
+                            f=f, sumsq=ss, grad=g.astype(np.float32), case=np.array(c["case"]))
+        print(name, layers, "loss_f_uv", ss[:4].sum() / N, "loss_f_s", ss[4:].sum() / N)
+        if c["fem"]:
+            rows = []
+            for k in c["frames"]:
+                d = scipy.io.loadmat(os.path.join(REF, c["fem"], f"ProbeData-{k}.mat"))
+                fx, fy = d["x"].reshape(-1) - c["shift"], d["y"].reshape(-1) - c["shift"]
+                ok = ((fx >= lb[0]) & (fx <= ub[0]) & (fy >= lb[1]) & (fy <= ub[1])
+                      & ((fx - xc) ** 2 + (fy - yc) ** 2 > (r + 0.25) ** 2))
+                idx = rng.choice(np.nonzero(ok)[0], size=600, replace=False)
+                rows.append(np.stack([fx[idx], fy[idx], np.full(600, k / c["fps"])]
+                                     + [d[q].reshape(-1)[idx] for q in ("u", "v", "s11", "s22", "s12")], 1))
+            fem = np.concatenate(rows, 0)            # columns x,y,t (PINN coordinates), u,v,s11,s22,s12
+            pred = po.wave2d_fields(flat, layers, fem[:, 0], fem[:, 1], fem[:, 2], lb, ub, c["normalize"])
+            rel = {q: [] for q in ("u", "v", "s11", "s22", "s12")}
+            for i in range(len(c["frames"])):
+                sl = slice(600 * i, 600 * (i + 1))
+                for j, q in enumerate(("u", "v", "s11", "s22", "s12")):
+                    rel[q].append(np.linalg.norm(pred[q][sl] - fem[sl, 3 + j]) / np.linalg.norm(fem[sl, 3 + j]))
+            np.savez_compressed(os.path.join(OUT, f"fem_{name}.npz"), fem=fem.astype(np.float32),
+                                frames=np.array(c["frames"]),
+                                rel_l2=np.array([rel[q] for q in ("u", "v", "s11", "s22", "s12")]))
+            print("  FEM rel-L2 per frame  u:", np.round(rel["u"], 3), " s11:", np.round(rel["s11"], 3))
+
+
+if __name__ == "__main__":
+    main()
