@@ -1,0 +1,112 @@
+/* C-ABI of the MI355X-native PINN-elastodynamics hot path (libpinn_hip.so).
+ *
+ * The reference (Raocp/PINN-elastodynamics) has no FFI: its "operator interface" for this path is
+ * the method surface of the TF1 model class.  Each entry point below names the reference graph
+ * piece it replaces (file:line relative to the reference repository, INF =
+ * ElasticWaveInfinite/ElasticWave.py).  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ *
+ * Conventions
+ *   - every pointer except `layers`, `lb`, `ub`, `term_weights`, `out_weights` is a DEVICE pointer
+ *     owned by the caller; the library allocates nothing and keeps no state between calls;
+ *   - all work is enqueued on `stream` (a hipStream_t passed as void*); calls return immediately;
+ *   - return value: 0 on success, a negative PINN_ERR_* code for bad arguments, a positive
+ *     hipError_t value if a launch failed.  Nothing throws.
+ *   - flat parameter vector: W0, b0, W1, b1, ... with each W row-major [in, out] and each b of
+ *     length out -- the arrays of the reference checkpoint [W_list, b_list] (INF:159-165)
+ *     concatenated layer by layer;
+ *   - `layers` = {3, H, ..., H, n_out} exactly like the reference's uv_layers (INF:645).
+ */
+#ifndef PINN_HIP_H
+#define PINN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* precision_mode: operand type of the matrix pipe (accumulation is always fp32) */
+enum {
+    PINN_PREC_BF16 = 0,   /* bf16 operands, one MFMA per product (BASELINE config "bf16-MFMA/fp32-accum") */
+    PINN_PREC_F16X3 = 1,  /* fp16 hi + scaled-lo split, three MFMAs per product: fp32-class accuracy */
+    PINN_PREC_F16 = 2,    /* fp16 operands, one MFMA per product */
+    PINN_PREC_BF16X3 = 3  /* bf16 hi/lo split, three MFMAs per product (16-bit significand) */
+};
+
+enum {
+    PINN_OK = 0,
+    PINN_ERR_NULL = -1,        /* a required pointer is NULL */
+    PINN_ERR_LAYERS = -2,      /* unsupported layer list (see pinn_supported_width) */
+    PINN_ERR_PRECISION = -3,   /* unknown precision_mode */
+    PINN_ERR_WORKSPACE = -4,   /* workspace smaller than pinn_min_workspace_bytes() or misaligned */
+    PINN_ERR_SIZE = -5         /* n <= 0 */
+};
+
+/* Padded hidden width the kernels use for a real hidden width h (0 if unsupported). */
+int pinn_supported_width(int h);
+
+/* Workspace sizing.  `recommended` holds all tiles of an n-point call in one pass; anything
+ * >= `min` works (the call then walks the points in several chunks).  n_streams: 4 for the
+ * residual path, 1 for the value-only data terms. */
+size_t pinn_workspace_bytes(const int* layers, int n_layers, int64_t n, int precision_mode);
+size_t pinn_min_workspace_bytes(const int* layers, int n_layers, int precision_mode);
+
+/* Replaces net_f_sig + the seven mean-squares + their gradient: INF:221-265 (SEMI:228-272,
+ * CONF:304-348), INF:104-110, and d/d(W,b) as built by optimizer_Adam.minimize INF:131-133.
+ *   loss_terms_out[i] = sum_n f_i(n)^2, i in (f_u,f_v,f_ut,f_vt,f_s11,f_s22,f_s12)   (INF:265 order)
+ *   grad_flat_out (+)= d/dparams sum_i term_weights[i] * loss_terms[i]
+ * The caller folds the loss layout (INF:119 / SEMI:127 / CONF:156) and reduce_mean's 1/N into
+ * term_weights.  normalize != 0 applies INF:191's input map with lb/ub. */
+int pinn_wave2d_loss_grad(const float* params_flat, const int* layers, int n_layers,
+                          const float* x, const float* y, const float* t, int64_t n,
+                          const double lb[3], const double ub[3], int normalize,
+                          double E, double mu, double rho, int plane_strain,
+                          const float term_weights[7],
+                          float* loss_terms_out, float* grad_flat_out, int accumulate,
+                          int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
+/* Same call, but brackets every kernel with HIP events on `stream` and returns, in the HOST array
+ * kernel_ms, the summed durations of {weight repack, chain kernel (forward + reverse chain),
+ * weight-gradient kernel, small reductions}.  Synchronous; used by bench.py's roofline leg only. */
+int pinn_wave2d_loss_grad_profile(const float* params_flat, const int* layers, int n_layers,
+                                  const float* x, const float* y, const float* t, int64_t n,
+                                  const double lb[3], const double ub[3], int normalize,
+                                  double E, double mu, double rho, int plane_strain,
+                                  const float term_weights[7],
+                                  float* loss_terms_out, float* grad_flat_out, int accumulate,
+                                  int precision_mode, void* workspace, size_t ws_bytes, void* stream,
+                                  float kernel_ms[4]);
+
+/* Replaces the value-only terms on the small side sets and their gradient: loss_IC INF:111-114,
+ * loss_SRC INF:115-116, loss_NB INF:117-118 (SEMI:125-126), loss_FIX CONF:145-146.
+ *   loss_terms_out[o] = sum_n (Y_o(n) - targets[o][n])^2      (targets == NULL means 0)
+ *   grad_flat_out (+)= d/dparams sum_o out_weights[o] * loss_terms[o]
+ * targets is SoA [n_out][n]. */
+int pinn_data_loss_grad(const float* params_flat, const int* layers, int n_layers,
+                        const float* x, const float* y, const float* t, int64_t n,
+                        const double lb[3], const double ub[3], int normalize,
+                        const float* targets, const float* out_weights,
+                        float* loss_terms_out, float* grad_flat_out, int accumulate,
+                        int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
+/* Replaces net_uv + the Jacobian pieces net_e needs (INF:201-219), i.e. what predict/probe
+ * evaluate (INF:337-359):  fields_out is SoA [4*n_out][n] = Y, dY/dx, dY/dy, dY/dt. */
+int pinn_wave2d_fields(const float* params_flat, const int* layers, int n_layers,
+                       const float* x, const float* y, const float* t, int64_t n,
+                       const double lb[3], const double ub[3], int normalize,
+                       float* fields_out, int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
+/* Replaces tf.train.AdamOptimizer's update (INF:131-133; TF1 rule: epsilon outside the bias
+ * correction).  step is 1-based.  All arrays are length n_params, updated in place. */
+int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_flat, int64_t n_params,
+                   double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+
+const char* pinn_error_string(int code);
+int pinn_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PINN_HIP_H */

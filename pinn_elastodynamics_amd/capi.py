@@ -1,0 +1,120 @@
+"""ctypes binding of the C-ABI declared in include/pinn_hip.h (libpinn_hip.so).
+
+Pointer arguments are passed as plain integers (``tensor.data_ptr()`` for device memory), so the
+binding itself has no torch dependency; PyTorch is only the owner of device buffers and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PREC = {"bf16": 0, "f16x3": 1, "f16": 2, "bf16x3": 3}
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "lib", "libpinn_hip.so")
+
+
+class PinnLibError(RuntimeError):
+    pass
+
+
+class PinnLib:
+    """Thin, checked wrapper over the shared library's entry points."""
+
+    def __init__(self, path: str = DEFAULT_LIB):
+        if not os.path.exists(path):
+            raise PinnLibError(
+                f"{path} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C pinn_elastodynamics_amd/csrc hip`). There is no CPU fallback.")
+        self.path = path
+        self.lib = C.CDLL(path)
+        L = self.lib
+        vp, i32, i64, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_size_t
+        pi32, pf64, pf32 = C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_float)
+        L.pinn_abi_version.restype = i32
+        L.pinn_supported_width.argtypes = [i32]
+        L.pinn_supported_width.restype = i32
+        L.pinn_error_string.argtypes = [i32]
+        L.pinn_error_string.restype = C.c_char_p
+        L.pinn_workspace_bytes.argtypes = [pi32, i32, i64, i32]
+        L.pinn_workspace_bytes.restype = sz
+        L.pinn_min_workspace_bytes.argtypes = [pi32, i32, i32]
+        L.pinn_min_workspace_bytes.restype = sz
+        L.pinn_wave2d_loss_grad.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, f64, f64, f64, i32, pf32,
+                                            vp, vp, i32, i32, vp, sz, vp]
+        L.pinn_wave2d_loss_grad.restype = i32
+        L.pinn_wave2d_loss_grad_profile.argtypes = L.pinn_wave2d_loss_grad.argtypes + [pf32]
+        L.pinn_wave2d_loss_grad_profile.restype = i32
+        L.pinn_data_loss_grad.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, pf32, vp, vp, i32, i32, vp, sz, vp]
+        L.pinn_data_loss_grad.restype = i32
+        L.pinn_wave2d_fields.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, i32, vp, sz, vp]
+        L.pinn_wave2d_fields.restype = i32
+        L.pinn_adam_step.argtypes = [vp, vp, vp, vp, i64, f64, f64, f64, f64, i64, vp]
+        L.pinn_adam_step.restype = i32
+
+    # -- helpers -------------------------------------------------------------------------------
+    @staticmethod
+    def _ints(v):
+        return (C.c_int * len(v))(*[int(x) for x in v])
+
+    @staticmethod
+    def _d3(v):
+        return (C.c_double * 3)(*[float(x) for x in v])
+
+    @staticmethod
+    def _floats(v, n):
+        v = list(v) + [0.0] * (n - len(v))
+        return (C.c_float * n)(*[float(x) for x in v])
+
+    def check(self, rc: int, what: str):
+        if rc != 0:
+            raise PinnLibError(f"{what} failed: {self.lib.pinn_error_string(rc).decode()} (code {rc})")
+
+    # -- entry points --------------------------------------------------------------------------
+    def abi_version(self) -> int:
+        return self.lib.pinn_abi_version()
+
+    def supported_width(self, h: int) -> int:
+        return self.lib.pinn_supported_width(int(h))
+
+    def workspace_bytes(self, layers, n, prec) -> int:
+        return int(self.lib.pinn_workspace_bytes(self._ints(layers), len(layers), int(n), PREC[prec]))
+
+    def min_workspace_bytes(self, layers, prec) -> int:
+        return int(self.lib.pinn_min_workspace_bytes(self._ints(layers), len(layers), PREC[prec]))
+
+    def wave2d_loss_grad(self, params, layers, x, y, t, n, lb, ub, normalize, E, mu, rho, plane_strain, term_weights,
+                         loss_out, grad_out, accumulate, prec, ws, ws_bytes, stream=0):
+        rc = self.lib.pinn_wave2d_loss_grad(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
+                                            int(bool(normalize)), float(E), float(mu), float(rho), int(bool(plane_strain)),
+                                            self._floats(term_weights, 7), loss_out, grad_out, int(bool(accumulate)), PREC[prec],
+                                            ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_wave2d_loss_grad")
+
+    def wave2d_loss_grad_profile(self, params, layers, x, y, t, n, lb, ub, normalize, E, mu, rho, plane_strain, term_weights,
+                                 loss_out, grad_out, accumulate, prec, ws, ws_bytes, stream=0):
+        """Synchronous; returns [repack, chain, wgrad, reductions] kernel milliseconds (HIP events)."""
+        ms = (C.c_float * 4)()
+        rc = self.lib.pinn_wave2d_loss_grad_profile(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb),
+                                                    self._d3(ub), int(bool(normalize)), float(E), float(mu), float(rho),
+                                                    int(bool(plane_strain)), self._floats(term_weights, 7), loss_out, grad_out,
+                                                    int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream, ms)
+        self.check(rc, "pinn_wave2d_loss_grad_profile")
+        return [float(v) for v in ms]
+
+    def data_loss_grad(self, params, layers, x, y, t, n, lb, ub, normalize, targets, out_weights, loss_out, grad_out,
+                       accumulate, prec, ws, ws_bytes, stream=0):
+        rc = self.lib.pinn_data_loss_grad(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
+                                          int(bool(normalize)), targets, self._floats(out_weights, 8), loss_out, grad_out,
+                                          int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_data_loss_grad")
+
+    def wave2d_fields(self, params, layers, x, y, t, n, lb, ub, normalize, fields_out, prec, ws, ws_bytes, stream=0):
+        rc = self.lib.pinn_wave2d_fields(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
+                                         int(bool(normalize)), fields_out, PREC[prec], ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_wave2d_fields")
+
+    def adam_step(self, params, m, v, grad, n_params, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, stream=0):
+        rc = self.lib.pinn_adam_step(params, m, v, grad, int(n_params), float(lr), float(beta1), float(beta2), float(eps),
+                                     int(step), stream)
+        self.check(rc, "pinn_adam_step")

@@ -1,0 +1,229 @@
+// extern "C" entry points of libpinn_hip.so (declared in include/pinn_hip.h): argument checking,
+// decoding into pinn::Call, and dispatch to the kernel family for (precision_mode, hidden width).
+#include "pinn_host.hpp"
+
+namespace pinn {
+#define PINN_VARIANT(op, split, width) const Impl* impl_##op##_##split##_##width();
+#include "pinn_variants.def"
+#undef PINN_VARIANT
+
+static const Impl* find_impl(int precision_mode, int width) {
+    const char* op;
+    int split;
+    switch (precision_mode) {
+        case PINN_PREC_BF16: op = "BF16"; split = 1; break;
+        case PINN_PREC_F16X3: op = "F16"; split = 3; break;
+        case PINN_PREC_F16: op = "F16"; split = 1; break;
+        case PINN_PREC_BF16X3: op = "BF16"; split = 3; break;
+        default: return nullptr;
+    }
+    auto same = [](const char* a, const char* b) { while (*a && *a == *b) { ++a; ++b; } return *a == *b; };
+#define PINN_VARIANT(o, s, w) if (same(op, #o) && split == s && width == w) return impl_##o##_##s##_##w();
+#include "pinn_variants.def"
+#undef PINN_VARIANT
+    return nullptr;
+}
+
+static int decode_net(const int* layers, int n_layers, NetDesc& net, int& width) {
+    if (!layers) return PINN_ERR_NULL;
+    if (n_layers < 3 || n_layers - 1 > MAX_WLAYERS) return PINN_ERR_LAYERS;
+    if (layers[0] != 3) return PINN_ERR_LAYERS;
+    const int h = layers[1], nout = layers[n_layers - 1];
+    for (int i = 1; i < n_layers - 1; ++i) if (layers[i] != h) return PINN_ERR_LAYERS;
+    if (nout < 1 || nout > 8) return PINN_ERR_LAYERS;
+    width = pinn_supported_width(h);
+    if (!width) return PINN_ERR_LAYERS;
+    net.nl = n_layers - 2;
+    net.h = h;
+    net.nout = nout;
+    int o = 0;
+    for (int l = 0; l <= net.nl; ++l) {
+        const int n_in = layers[l], n_out = layers[l + 1];
+        net.w_off[l] = o;
+        o += n_in * n_out;
+        net.b_off[l] = o;
+        o += n_out;
+    }
+    for (int l = net.nl + 1; l < MAX_WLAYERS; ++l) net.w_off[l] = net.b_off[l] = 0;
+    net.nparams = o;
+    return PINN_OK;
+}
+
+static void input_map(const double lb[3], const double ub[3], int normalize, Call& c) {
+    for (int k = 0; k < 3; ++k) {
+        if (normalize) {   // INF:191  H = 2 (X - lb)/(ub - lb) - 1
+            const double s = 2.0 / (ub[k] - lb[k]);
+            c.sx[k] = (float)s;
+            c.ox[k] = (float)(-lb[k] * s - 1.0);
+        } else {
+            c.sx[k] = 1.0f;
+            c.ox[k] = 0.0f;
+        }
+    }
+}
+}  // namespace pinn
+
+using namespace pinn;
+
+extern "C" {
+
+int pinn_abi_version(void) { return 1; }
+
+int pinn_supported_width(int h) {
+    if (h < 1) return 0;
+    static const int widths[] = {32, 64, 96, 128, 160};
+    for (int w : widths) if (h <= w) return w;
+    return 0;
+}
+
+const char* pinn_error_string(int code) {
+    switch (code) {
+        case PINN_OK: return "ok";
+        case PINN_ERR_NULL: return "required pointer is NULL";
+        case PINN_ERR_LAYERS: return "unsupported layer list (need {3, H x k, n_out<=8}, H<=160, <=16 weight layers, and a compiled variant)";
+        case PINN_ERR_PRECISION: return "unknown precision_mode";
+        case PINN_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
+        case PINN_ERR_SIZE: return "n must be positive";
+        default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
+    }
+}
+
+static int prepare(const float* params, const int* layers, int n_layers, const float* x, const float* y, const float* t, int64_t n,
+                   const double lb[3], const double ub[3], int normalize, int precision_mode, void* ws, size_t ws_bytes, void* stream,
+                   Call& c, const Impl*& impl) {
+    if (!params || !x || !y || !t || !ws) return PINN_ERR_NULL;
+    if (normalize && (!lb || !ub)) return PINN_ERR_NULL;
+    if (n <= 0) return PINN_ERR_SIZE;
+    if (precision_mode < 0 || precision_mode > 3) return PINN_ERR_PRECISION;
+    int width = 0;
+    const int rc = decode_net(layers, n_layers, c.net, width);
+    if (rc) return rc;
+    impl = find_impl(precision_mode, width);
+    if (!impl) return PINN_ERR_LAYERS;
+    c.params = params;
+    c.x = x;
+    c.y = y;
+    c.t = t;
+    c.n = (long)n;
+    input_map(lb, ub, normalize, c);
+    c.ws = ws;
+    c.ws_bytes = ws_bytes;
+    c.stream = (hipStream_t)stream;
+    c.loss_out = nullptr;
+    c.grad_out = nullptr;
+    c.accumulate = 0;
+    c.c1 = c.c2 = c.G = c.rho = 0.0f;
+    for (int i = 0; i < 8; ++i) c.tw[i] = 0.0f;
+    c.targets = nullptr;
+    c.fields_out = nullptr;
+    c.prof_ms = nullptr;
+    return PINN_OK;
+}
+
+size_t pinn_workspace_bytes(const int* layers, int n_layers, int64_t n, int precision_mode) {
+    NetDesc net;
+    int width = 0;
+    if (n <= 0 || decode_net(layers, n_layers, net, width)) return 0;
+    const Impl* impl = find_impl(precision_mode, width);
+    return impl ? impl->ws_bytes(net, (long)n, 0) : 0;
+}
+
+size_t pinn_min_workspace_bytes(const int* layers, int n_layers, int precision_mode) {
+    NetDesc net;
+    int width = 0;
+    if (decode_net(layers, n_layers, net, width)) return 0;
+    const Impl* impl = find_impl(precision_mode, width);
+    return impl ? impl->ws_bytes(net, 1L << 40, 1) : 0;
+}
+
+static int wave2d_loss_grad_impl(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
+                          int64_t n, const double lb[3], const double ub[3], int normalize, double E, double mu, double rho,
+                          int plane_strain, const float term_weights[7], float* loss_terms_out, float* grad_flat_out, int accumulate,
+                          int precision_mode, void* workspace, size_t ws_bytes, void* stream, float* prof_ms) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+    if (rc) return rc;
+    if (!term_weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
+    if (c.net.nout != 7) return PINN_ERR_LAYERS;
+    // Hooke coefficients: plane strain INF:238-241, plane stress PLATE:416-418
+    double c1, c2;
+    if (plane_strain) {
+        const double coef = E / ((1.0 + mu) * (1.0 - 2.0 * mu));
+        c1 = coef * (1.0 - mu);
+        c2 = coef * mu;
+    } else {
+        c1 = E / (1.0 - mu * mu);
+        c2 = E * mu / (1.0 - mu * mu);
+    }
+    c.c1 = (float)c1;
+    c.c2 = (float)c2;
+    c.G = (float)(E / (2.0 * (1.0 + mu)));
+    c.rho = (float)rho;
+    for (int i = 0; i < 7; ++i) c.tw[i] = term_weights[i];
+    c.loss_out = loss_terms_out;
+    c.grad_out = grad_flat_out;
+    c.accumulate = accumulate;
+    c.prof_ms = prof_ms;
+    return impl->wave_loss_grad(c);
+}
+
+int pinn_wave2d_loss_grad(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
+                          int64_t n, const double lb[3], const double ub[3], int normalize, double E, double mu, double rho,
+                          int plane_strain, const float term_weights[7], float* loss_terms_out, float* grad_flat_out, int accumulate,
+                          int precision_mode, void* workspace, size_t ws_bytes, void* stream) {
+    return wave2d_loss_grad_impl(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, E, mu, rho, plane_strain, term_weights,
+                                 loss_terms_out, grad_flat_out, accumulate, precision_mode, workspace, ws_bytes, stream, nullptr);
+}
+
+int pinn_wave2d_loss_grad_profile(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
+                                  int64_t n, const double lb[3], const double ub[3], int normalize, double E, double mu, double rho,
+                                  int plane_strain, const float term_weights[7], float* loss_terms_out, float* grad_flat_out,
+                                  int accumulate, int precision_mode, void* workspace, size_t ws_bytes, void* stream, float kernel_ms[4]) {
+    if (!kernel_ms) return PINN_ERR_NULL;
+    return wave2d_loss_grad_impl(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, E, mu, rho, plane_strain, term_weights,
+                                 loss_terms_out, grad_flat_out, accumulate, precision_mode, workspace, ws_bytes, stream, kernel_ms);
+}
+
+int pinn_data_loss_grad(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
+                        int64_t n, const double lb[3], const double ub[3], int normalize, const float* targets,
+                        const float* out_weights, float* loss_terms_out, float* grad_flat_out, int accumulate, int precision_mode,
+                        void* workspace, size_t ws_bytes, void* stream) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+    if (rc) return rc;
+    if (!out_weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
+    for (int i = 0; i < c.net.nout; ++i) c.tw[i] = out_weights[i];
+    c.targets = targets;
+    c.loss_out = loss_terms_out;
+    c.grad_out = grad_flat_out;
+    c.accumulate = accumulate;
+    return impl->data_loss_grad(c);
+}
+
+int pinn_wave2d_fields(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
+                       int64_t n, const double lb[3], const double ub[3], int normalize, float* fields_out, int precision_mode,
+                       void* workspace, size_t ws_bytes, void* stream) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+    if (rc) return rc;
+    if (!fields_out) return PINN_ERR_NULL;
+    c.fields_out = fields_out;
+    return impl->fields(c);
+}
+
+int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_flat, int64_t n_params, double lr, double beta1,
+                   double beta2, double eps, int64_t step, void* stream) {
+    if (!params_flat || !m || !v || !grad_flat) return PINN_ERR_NULL;
+    if (n_params <= 0 || step < 1) return PINN_ERR_SIZE;
+    // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t)   (TF1 AdamOptimizer)
+    const double b1t = __builtin_pow(beta1, (double)step), b2t = __builtin_pow(beta2, (double)step);
+    const double lr_t = lr * __builtin_sqrt(1.0 - b2t) / (1.0 - b1t);
+    hipLaunchKernelGGL((adam_tf1_kernel<0>), dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params_flat, m, v,
+                       grad_flat, (long)n_params, (float)lr_t, (float)beta1, (float)beta2, (float)eps);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,760 @@
+// Device code of the PINN-elastodynamics hot path for gfx950 (CDNA4, wave64, MFMA 16x16x32).
+//
+// What the kernels compute (reference: ElasticWaveInfinite/ElasticWave.py, "INF"):
+//   neural_net INF:188-199, net_uv INF:201-211, net_e INF:213-219, net_f_sig INF:221-265,
+//   the mean-square terms INF:104-118 and d(loss)/d(W,b) (what AdamOptimizer.minimize
+//   differentiates, INF:131-133).
+// How: the twelve tf.gradients reverse passes of the reference are replaced by three input
+// tangents (d/dx, d/dy, d/dt) carried forward next to the value ("4 streams"), followed by one
+// reverse pass over that computation.  See DESIGN.md for the derivation and the layouts.
+//
+// Lane maps used throughout (MFMA 16x16x32, lane l: c = l & 15, q = l >> 4):
+//   A operand: row m = c, k-slot 8q+j (j = 0..7);  B operand: col n = c, k-slot 8q+j;
+//   C/D: row 4q+r (r = 0..3), col c.
+// "Swapped chain": every layer computes D'[feature, point] = W^T[feature, k] . H^T[k, point], so a
+// lane ends up holding 4 consecutive output features (16 mb + 4q + r) of ITS point c, which is
+// exactly what it must supply as B-operand k-slots of the next layer once the weight fragments
+// are stored with the matching k permutation  kmap(kk,q,j) = 32kk + 16(j>>2) + 4q + (j&3).
+// No LDS round trip or cross-lane traffic is needed between layers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pinn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int MAX_WLAYERS = 16;   // weight matrices per net (hidden layers + 1)
+constexpr int NOUT_PAD = 16;      // network outputs are padded to one 16-row MFMA block
+
+// ------------------------------------------------------------------------------------------
+// 16-bit operand types of the matrix pipe
+// ------------------------------------------------------------------------------------------
+struct OpF16 {
+    typedef _Float16 T;
+    typedef f16x8 V8;
+    typedef f16x2 V2;
+    // low part of the hi/lo split is stored scaled by 2^11 so that it keeps fp16's normal range
+    static constexpr float LO_SCALE = 2048.0f;
+    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(V8, a), __builtin_bit_cast(V8, b), c, 0, 0, 0);
+    }
+};
+struct OpBF16 {
+    typedef __bf16 T;
+    typedef bf16x8 V8;
+    typedef bf16x2 V2;
+    static constexpr float LO_SCALE = 256.0f;
+    static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(V8, a), __builtin_bit_cast(V8, b), c, 0, 0, 0);
+    }
+};
+
+template <class Op>
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typename Op::V2 v;
+    v[0] = (typename Op::T)a;
+    v[1] = (typename Op::T)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <class Op>
+__device__ __forceinline__ float cvt16(uint16_t bits) {
+    return (float)__builtin_bit_cast(typename Op::T, bits);
+}
+template <class Op>
+__device__ __forceinline__ float round16(float a) {
+    return (float)(typename Op::T)a;
+}
+
+// ------------------------------------------------------------------------------------------
+// kernel arguments (plain structs passed by value)
+// ------------------------------------------------------------------------------------------
+struct NetDesc {
+    int nl;                    // hidden layers; weight matrices = nl + 1
+    int h;                     // real hidden width (<= WIDTH template parameter)
+    int nout;                  // real number of outputs (7 for the wave scripts, INF:204-210)
+    int w_off[MAX_WLAYERS];    // offset of W_l in the flat parameter vector (W row-major [in,out])
+    int b_off[MAX_WLAYERS];    // offset of b_l
+    int nparams;
+};
+
+struct PackedWeights {         // produced by repack_kernel, consumed by chain_kernel
+    const float* w0p;          // [WIDTH][4]  (W0[0][f], W0[1][f], W0[2][f], b0[f])
+    const float* bias_mid;     // [nl-1][WIDTH] biases of weight layers 1..nl-1
+    const float* bias_last;    // [16]
+    const u32x4* frags;        // fragment store, see frag_index()
+};
+
+enum { HEAD_WAVE = 0, HEAD_DATA = 1, HEAD_FIELDS = 2 };
+
+struct ChainArgs {
+    NetDesc net;
+    PackedWeights pw;
+    const float* x;            // SoA point coordinates
+    const float* y;
+    const float* t;
+    long n;                    // total points of this call
+    long tile0;                // first tile of this workspace chunk
+    long ntiles;               // tiles in this chunk
+    float sx[3], ox[3];        // input map x' = x*sx + ox  (INF:191 when normalising, identity otherwise)
+    float c1, c2, G, rho;      // Hooke coefficients (INF:238-241 / PLATE:416-418) and density
+    float tw[8];               // per-residual (HEAD_WAVE) or per-output (HEAD_DATA) weights, max-normalised
+    const float* targets;      // HEAD_DATA: [nout][n] SoA targets or nullptr (= 0)
+    uint16_t* S;               // forward-state panels of this chunk
+    uint16_t* Z;               // adjoint panels of this chunk
+    long S_tile_stride;        // in 16-bit elements
+    long Z_tile_stride;
+    float* loss_part;          // [total waves][8] per-wave partial sums of squares
+    float* fields_out;         // HEAD_FIELDS: [4*nout][n]  (Y, dY/dx, dY/dy, dY/dt)
+};
+
+struct WgradArgs {
+    NetDesc net;
+    const uint16_t* S;
+    const uint16_t* Z;
+    long S_tile_stride, Z_tile_stride;
+    long ntiles;               // tiles in this chunk (even when NB == 1)
+    float* partial;            // [gridDim.x][nparams]
+    int first_pass;            // 1: overwrite partials, 0: add to them
+};
+
+struct RepackArgs {
+    NetDesc net;
+    const float* params;
+    float* w0p;
+    float* bias_mid;
+    float* bias_last;
+    u32x4* frags;
+};
+
+// k-slot -> feature permutation shared by every A/B fragment pair of the chain
+__host__ __device__ __forceinline__ int kmap(int kk, int q, int j) { return 32 * kk + 16 * (j >> 2) + 4 * q + (j & 3); }
+
+// Fragment store layout: [frag][part][lane] of u32x4 with
+//   fwd_mid (l,mb,kk), l = 1..nl-1 : ((l-1)*WB + mb)*KS + kk
+//   fwd_last(kk)                   : FM + kk                      (FM = (nl-1)*WB*KS)
+//   bwd_mid (l,mb,kk)              : FM + KS + ((l-1)*WB + mb)*KS + kk
+//   bwd_last(mb)                   : 2*FM + KS + mb
+template <int WIDTH>
+struct FragIndex {
+    static constexpr int WB = WIDTH / 16, KS = WIDTH / 32;
+    __host__ __device__ static int fm(int nl) { return (nl - 1) * WB * KS; }
+    __host__ __device__ static int fwd_mid(int l, int mb, int kk) { return ((l - 1) * WB + mb) * KS + kk; }
+    __host__ __device__ static int fwd_last(int nl, int kk) { return fm(nl) + kk; }
+    __host__ __device__ static int bwd_mid(int nl, int l, int mb, int kk) { return fm(nl) + KS + ((l - 1) * WB + mb) * KS + kk; }
+    __host__ __device__ static int bwd_last(int nl, int mb) { return 2 * fm(nl) + KS + mb; }
+    __host__ __device__ static int total(int nl) { return 2 * fm(nl) + KS + WB; }
+};
+
+// Panel geometry inside one tile record (units: 16-bit elements).  TP = points per tile.
+//   S panels: layer 0 has 16 rows (the inputs), layers 1..nl have WIDTH rows (hidden states h_l)
+//   Z panels: layers 0..nl-1 have WIDTH rows (adjoints of the pre-activations), layer nl has 16 rows
+template <int WIDTH, int NB, int NS, int NP>
+struct PanelGeom {
+    static constexpr int TP = 16 * NB;
+    __host__ __device__ static long s_off(int l) { return l == 0 ? 0 : (long)NS * NP * 16 * TP + (long)(l - 1) * NS * NP * WIDTH * TP; }
+    __host__ __device__ static long z_off(int l) { return (long)l * NS * NP * WIDTH * TP; }
+    __host__ __device__ static long s_tile(int nl) { return s_off(nl + 1); }
+    __host__ __device__ static long z_tile(int nl) { return z_off(nl) + (long)NS * NP * 16 * TP; }
+};
+
+// ------------------------------------------------------------------------------------------
+// repack: flat fp32 parameters -> MFMA A-operand fragments (hi [+ scaled lo]) + fp32 side tables
+// ------------------------------------------------------------------------------------------
+template <class Op, int SPLIT, int WIDTH>
+__global__ __launch_bounds__(256) void repack_kernel(const RepackArgs a) {
+    typedef FragIndex<WIDTH> FI;
+    constexpr int NP = SPLIT == 3 ? 2 : 1;
+    const int nl = a.net.nl, H = a.net.h, NO = a.net.nout;
+    const int FM = FI::fm(nl), NF = FI::total(nl);
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nthreads = (long)gridDim.x * blockDim.x;
+    for (long i = gid; i < (long)NF * 64; i += nthreads) {
+        const int frag = (int)(i >> 6), lane = (int)(i & 63), c = lane & 15, q = lane >> 4;
+        // decode the fragment kind
+        int kind, l = 0, mb = 0, kk = 0, rem = frag;
+        if (rem < FM) { kind = 0; l = 1 + rem / (FI::WB * FI::KS); mb = (rem / FI::KS) % FI::WB; kk = rem % FI::KS; }
+        else if ((rem -= FM) < FI::KS) { kind = 1; kk = rem; }
+        else if ((rem -= FI::KS) < FM) { kind = 2; l = 1 + rem / (FI::WB * FI::KS); mb = (rem / FI::KS) % FI::WB; kk = rem % FI::KS; }
+        else { kind = 3; mb = rem - FM; }
+        uint32_t hi[4], lo[4];
+        for (int d = 0; d < 4; ++d) {
+            float w2[2];
+            for (int e = 0; e < 2; ++e) {
+                const int j = 2 * d + e;
+                int in, out, n_in, n_out, wl;
+                if (kind == 0) { wl = l; in = kmap(kk, q, j); out = 16 * mb + c; n_in = H; n_out = H; }
+                else if (kind == 1) { wl = nl; in = kmap(kk, q, j); out = c; n_in = H; n_out = NO; }
+                else if (kind == 2) { wl = l; in = 16 * mb + c; out = kmap(kk, q, j); n_in = H; n_out = H; }
+                else { wl = nl; in = 16 * mb + c; out = kmap(0, q, j); n_in = H; n_out = NO; }
+                w2[e] = (in < n_in && out < n_out) ? a.params[a.net.w_off[wl] + in * n_out + out] : 0.0f;
+            }
+            hi[d] = pack2<Op>(w2[0], w2[1]);
+            lo[d] = pack2<Op>((w2[0] - round16<Op>(w2[0])) * Op::LO_SCALE, (w2[1] - round16<Op>(w2[1])) * Op::LO_SCALE);
+        }
+        u32x4 vh = {hi[0], hi[1], hi[2], hi[3]};
+        a.frags[((long)frag * NP + 0) * 64 + lane] = vh;
+        if (NP == 2) {
+            u32x4 vl = {lo[0], lo[1], lo[2], lo[3]};
+            a.frags[((long)frag * NP + 1) * 64 + lane] = vl;
+        }
+    }
+    // fp32 side tables
+    for (long i = gid; i < WIDTH; i += nthreads) {
+        const int f = (int)i;
+        const bool ok = f < H;
+        a.w0p[4 * f + 0] = ok ? a.params[a.net.w_off[0] + 0 * H + f] : 0.0f;
+        a.w0p[4 * f + 1] = ok ? a.params[a.net.w_off[0] + 1 * H + f] : 0.0f;
+        a.w0p[4 * f + 2] = ok ? a.params[a.net.w_off[0] + 2 * H + f] : 0.0f;
+        a.w0p[4 * f + 3] = ok ? a.params[a.net.b_off[0] + f] : 0.0f;
+    }
+    for (long i = gid; i < (long)(nl - 1) * WIDTH; i += nthreads) {
+        const int l = 1 + (int)(i / WIDTH), f = (int)(i % WIDTH);
+        a.bias_mid[i] = f < H ? a.params[a.net.b_off[l] + f] : 0.0f;
+    }
+    for (long i = gid; i < NOUT_PAD; i += nthreads) a.bias_last[i] = i < NO ? a.params[a.net.b_off[nl] + i] : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------
+// chain kernel: forward (value + tangents), residual/loss head, reverse chain; spills the
+// per-layer states S and adjoints Z as [feature][point] panels for the weight-gradient kernel.
+// One wave owns a tile of TP = 16*NB points; no LDS, no barriers.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tanh_act(float z, float& h, float& sd) {
+    // tanh(z) = 1 - 2/(1 + e^{2z});  exp2/rcp are the hardware transcendental ops
+    const float e = __builtin_amdgcn_exp2f(z * 2.8853900817779268f);
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    h = 1.0f - 2.0f * r;
+    sd = 1.0f - h * h;
+}
+
+template <class Op, int SPLIT, int WIDTH, int NB, int NS, int HEAD>
+struct Chain {
+    static constexpr int WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1, TP = 16 * NB;
+    static constexpr float INV_LS = 1.0f / Op::LO_SCALE;
+    typedef PanelGeom<WIDTH, NB, NS, NP> PG;
+    typedef FragIndex<WIDTH> FI;
+
+    // Take one 16-feature block of per-point values (vals[s][nb][r], feature 16*mb+4q+r), turn it
+    // into k-slots of the next GEMM's B fragments (hi [+lo]) and, if `panel` is given, store it
+    // into the [feature][point] panel of this tile.  KSN = k-steps of the destination fragments.
+    template <int KSN, int MB>
+    static __device__ __forceinline__ void emit(u32x4 (&Bn)[NS][NB][KSN][NP], const float (&vals)[NS][NB][4],
+                                                uint16_t* panel, int rows, int c, int q) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float* v = vals[s][nb];
+                const uint32_t h0 = pack2<Op>(v[0], v[1]), h1 = pack2<Op>(v[2], v[3]);
+                Bn[s][nb][MB >> 1][0][(MB & 1) * 2 + 0] = h0;
+                Bn[s][nb][MB >> 1][0][(MB & 1) * 2 + 1] = h1;
+                uint32_t l0 = 0, l1 = 0;
+                if (NP == 2) {
+                    l0 = pack2<Op>((v[0] - round16<Op>(v[0])) * Op::LO_SCALE, (v[1] - round16<Op>(v[1])) * Op::LO_SCALE);
+                    l1 = pack2<Op>((v[2] - round16<Op>(v[2])) * Op::LO_SCALE, (v[3] - round16<Op>(v[3])) * Op::LO_SCALE);
+                    Bn[s][nb][MB >> 1][1][(MB & 1) * 2 + 0] = l0;
+                    Bn[s][nb][MB >> 1][1][(MB & 1) * 2 + 1] = l1;
+                }
+                if (panel) {
+                    uint16_t* p = panel + ((long)(s * NP) * rows + 16 * MB + 4 * q) * TP + 16 * nb + c;
+                    p[0 * TP] = (uint16_t)(h0 & 0xffffu);
+                    p[1 * TP] = (uint16_t)(h0 >> 16);
+                    p[2 * TP] = (uint16_t)(h1 & 0xffffu);
+                    p[3 * TP] = (uint16_t)(h1 >> 16);
+                    if (NP == 2) {
+                        uint16_t* pl = p + (long)rows * TP;
+                        pl[0 * TP] = (uint16_t)(l0 & 0xffffu);
+                        pl[1 * TP] = (uint16_t)(l0 >> 16);
+                        pl[2 * TP] = (uint16_t)(l1 & 0xffffu);
+                        pl[3 * TP] = (uint16_t)(l1 >> 16);
+                    }
+                }
+            }
+        }
+    }
+
+    // acc[s][nb] (+ corr) = A(mb) . B over KSB k-steps
+    template <int KSB>
+    static __device__ __forceinline__ void gemm_block(const u32x4* Afr, int lane, const u32x4 (&B)[NS][NB][KSB][NP],
+                                                      f32x4 (&acc)[NS][NB], f32x4 (&accc)[NS][NB]) {
+        u32x4 A[KSB][NP];
+#pragma unroll
+        for (int kk = 0; kk < KSB; ++kk)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) A[kk][p] = Afr[((long)kk * NP + p) * 64 + lane];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                f32x4 m = {0.f, 0.f, 0.f, 0.f}, cc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kk = 0; kk < KSB; ++kk) {
+                    m = Op::mfma(A[kk][0], B[s][nb][kk][0], m);
+                    if (NP == 2) {
+                        cc = Op::mfma(A[kk][0], B[s][nb][kk][1], cc);
+                        cc = Op::mfma(A[kk][1], B[s][nb][kk][0], cc);
+                    }
+                }
+                acc[s][nb] = m;
+                accc[s][nb] = cc;
+            }
+    }
+
+    static __device__ __forceinline__ float comb(const f32x4& m, const f32x4& cc, int r) {
+        return NP == 2 ? m[r] + cc[r] * INV_LS : m[r];
+    }
+
+    // load the stored state (h, hdot_k) of one feature block from the S panel of layer l
+    template <int MB>
+    static __device__ __forceinline__ void load_state(const uint16_t* panel, int c, int q, float (&st)[NS][NB][4]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const uint16_t* p = panel + ((long)(s * NP) * WIDTH + 16 * MB + 4 * q) * TP + 16 * nb + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = cvt16<Op>(p[r * TP]);
+                    if (NP == 2) v += cvt16<Op>(p[(long)WIDTH * TP + r * TP]) * INV_LS;
+                    st[s][nb][r] = v;
+                }
+            }
+    }
+
+    // reverse of (h = tanh z, hdot_k = (1-h^2) zdot_k):   INF:131-133 (gradient of TanhGrad)
+    static __device__ __forceinline__ void act_bwd(const float (&st)[NS][NB][4], const f32x4 (&acc)[NS][NB],
+                                                   const f32x4 (&accc)[NS][NB], float (&vals)[NS][NB][4]) {
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float h = st[0][nb][r];
+                const float sd = 1.0f - h * h;
+                const float hb = comb(acc[0][nb], accc[0][nb], r);
+                float dot = 0.0f;
+#pragma unroll
+                for (int s = 1; s < NS; ++s) {
+                    const float hdb = comb(acc[s][nb], accc[s][nb], r);
+                    dot += hdb * st[s][nb][r];
+                    vals[s][nb][r] = sd * hdb;
+                }
+                vals[0][nb][r] = sd * hb - 2.0f * h * dot;
+            }
+    }
+
+    template <int MB>
+    struct MbLoop {
+        // forward first layer (K = 3, plain VALU): INF:191-195 with the tangent seeds e_k * sx_k
+        static __device__ __forceinline__ void first(const ChainArgs& a, const float (&xin)[NB][3], u32x4 (&Bn)[NS][NB][KS][NP],
+                                                     uint16_t* panel, int c, int q) {
+            float vals[NS][NB][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const f32x4 w = *reinterpret_cast<const f32x4*>(a.pw.w0p + 4 * (16 * MB + 4 * q + r));
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float z = w[3] + w[0] * xin[nb][0] + w[1] * xin[nb][1] + w[2] * xin[nb][2];
+                    float h, sd;
+                    tanh_act(z, h, sd);
+                    vals[0][nb][r] = h;
+#pragma unroll
+                    for (int s = 1; s < NS; ++s) vals[s][nb][r] = sd * (a.sx[s - 1] * w[s - 1]);
+                }
+            }
+            emit<KS, MB>(Bn, vals, panel, WIDTH, c, q);
+            if constexpr (MB + 1 < WB) MbLoop<MB + 1>::first(a, xin, Bn, panel, c, q);
+        }
+        // forward hidden layer: z = W^T h + b, h' = tanh z, hdot' = (1-h'^2) W^T hdot     INF:192-195
+        static __device__ __forceinline__ void fwd(const u32x4* Al, const float* bl, int lane, const u32x4 (&B)[NS][NB][KS][NP],
+                                                   u32x4 (&Bn)[NS][NB][KS][NP], uint16_t* panel, int c, int q) {
+            f32x4 acc[NS][NB], accc[NS][NB];
+            gemm_block<KS>(Al + (long)MB * KS * NP * 64, lane, B, acc, accc);
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * MB + 4 * q);
+            float vals[NS][NB][4];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float h, sd;
+                    tanh_act(comb(acc[0][nb], accc[0][nb], r) + bias[r], h, sd);
+                    vals[0][nb][r] = h;
+#pragma unroll
+                    for (int s = 1; s < NS; ++s) vals[s][nb][r] = sd * comb(acc[s][nb], accc[s][nb], r);
+                }
+            emit<KS, MB>(Bn, vals, panel, WIDTH, c, q);
+            if constexpr (MB + 1 < WB) MbLoop<MB + 1>::fwd(Al, bl, lane, B, Bn, panel, c, q);
+        }
+        // reverse through one weight layer (KSB k-steps of its outputs) and the activation below it
+        template <int KSB>
+        static __device__ __forceinline__ void bwd(const u32x4* Al, int lane, const u32x4 (&Zf)[NS][NB][KSB][NP],
+                                                   const uint16_t* spanel, u32x4 (&Zn)[NS][NB][KS][NP], uint16_t* zpanel, int c, int q) {
+            f32x4 acc[NS][NB], accc[NS][NB];
+            gemm_block<KSB>(Al + (long)MB * KSB * NP * 64, lane, Zf, acc, accc);
+            float st[NS][NB][4], vals[NS][NB][4];
+            load_state<MB>(spanel, c, q, st);
+            act_bwd(st, acc, accc, vals);
+            emit<KS, MB>(Zn, vals, zpanel, WIDTH, c, q);
+            if constexpr (MB + 1 < WB) MbLoop<MB + 1>::template bwd<KSB>(Al, lane, Zf, spanel, Zn, zpanel, c, q);
+        }
+    };
+
+    static __device__ void run(const ChainArgs& a) {
+        const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+        const int wpb = blockDim.x >> 6;
+        const long gwave = (long)blockIdx.x * wpb + (threadIdx.x >> 6), nwaves = (long)gridDim.x * wpb;
+        const int nl = a.net.nl;
+        constexpr bool SPILL = HEAD != HEAD_FIELDS;
+        float lsum[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lsum[i] = 0.0f;
+
+        for (long tile = gwave; tile < a.ntiles; tile += nwaves) {
+            uint16_t* St = SPILL ? a.S + tile * a.S_tile_stride : nullptr;
+            uint16_t* Zt = SPILL ? a.Z + tile * a.Z_tile_stride : nullptr;
+            float xin[NB][3];
+            bool valid[NB];
+            long pidx[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const long p = (a.tile0 + tile) * TP + 16 * nb + c;
+                valid[nb] = p < a.n;
+                pidx[nb] = valid[nb] ? p : a.n - 1;
+                xin[nb][0] = a.x[pidx[nb]] * a.sx[0] + a.ox[0];
+                xin[nb][1] = a.y[pidx[nb]] * a.sx[1] + a.ox[1];
+                xin[nb][2] = a.t[pidx[nb]] * a.sx[2] + a.ox[2];
+            }
+            // ---- S_0: the inputs as a 16-row panel (rows 0..2 = x'; tangent stream k has sx_k in row k)
+            if (SPILL) {
+                float v0[NS][NB][4];
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float v = 0.0f;
+                            if (q == 0 && r < 3) v = (s == 0) ? xin[nb][r] : (r == s - 1 ? a.sx[r] : 0.0f);
+                            v0[s][nb][r] = v;
+                        }
+                u32x4 dummy[NS][NB][1][NP];
+                emit<1, 0>(dummy, v0, St + PG::s_off(0), 16, c, q);
+            }
+            // ---- forward
+            u32x4 B[NS][NB][KS][NP];
+            MbLoop<0>::first(a, xin, B, SPILL ? St + PG::s_off(1) : nullptr, c, q);
+            for (int l = 1; l < nl; ++l) {
+                u32x4 Bn[NS][NB][KS][NP];
+                MbLoop<0>::fwd(a.pw.frags + (long)FI::fwd_mid(l, 0, 0) * NP * 64, a.pw.bias_mid + (long)(l - 1) * WIDTH, lane, B, Bn,
+                               SPILL ? St + PG::s_off(l + 1) : nullptr, c, q);
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) B[s][nb][kk][p] = Bn[s][nb][kk][p];
+            }
+            // ---- output layer  Y = h W_L + b_L  (INF:196-198): lane holds outputs 4q+r of its point
+            f32x4 yacc[NS][NB], yaccc[NS][NB];
+            gemm_block<KS>(a.pw.frags + (long)FI::fwd_last(nl, 0) * NP * 64, lane, B, yacc, yaccc);
+            const f32x4 bl = *reinterpret_cast<const f32x4*>(a.pw.bias_last + 4 * q);
+            // Every lane gathers all 8 (padded) outputs of its point: own block + the q^1 partner's
+            float Y[NS][NB][8];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float own = comb(yacc[s][nb], yaccc[s][nb], r) + (s == 0 ? bl[r] : 0.0f);
+                        const float oth = __shfl_xor(own, 16);
+                        Y[s][nb][r] = (q & 1) ? oth : own;
+                        Y[s][nb][4 + r] = (q & 1) ? own : oth;
+                    }
+            // ---- head
+            float adj[NS][NB][8];     // dL/dY (s=0) and dL/d(dY/dx_k) (s=k+1) for the 8 padded outputs
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const float vm = valid[nb] ? 1.0f : 0.0f;
+                if constexpr (HEAD == HEAD_WAVE) {
+                    // net_f_sig INF:221-265; outputs (u,v,ut,vt,s11,s22,s12); streams (value, d/dx, d/dy, d/dt)
+                    const float(&V)[8] = Y[0][nb];
+                    const float(&X)[8] = Y[1][nb];
+                    const float(&Yy)[8] = Y[2][nb];
+                    const float(&T)[8] = Y[3][nb];
+                    const float e11 = X[0], e22 = Yy[1], e12 = Yy[0] + X[1];          // INF:216-218
+                    float f[7];
+                    f[0] = X[4] + Yy[6] - a.rho * T[2];                               // f_u   INF:262
+                    f[1] = Yy[5] + X[6] - a.rho * T[3];                               // f_v   INF:263
+                    f[2] = T[0] - V[2];                                               // f_ut  INF:248
+                    f[3] = T[1] - V[3];                                               // f_vt  INF:249
+                    f[4] = V[4] - (a.c1 * e11 + a.c2 * e22);                          // f_s11 INF:244
+                    f[5] = V[5] - (a.c2 * e11 + a.c1 * e22);                          // f_s22 INF:246
+                    f[6] = V[6] - a.G * e12;                                          // f_s12 INF:245
+                    float g[7];
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) {
+                        if (q == 0) lsum[i] += vm * f[i] * f[i];
+                        g[i] = 2.0f * a.tw[i] * f[i] * vm;
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int o = 0; o < 8; ++o) adj[s][nb][o] = 0.0f;
+                    adj[0][nb][2] = -g[2];
+                    adj[0][nb][3] = -g[3];
+                    adj[0][nb][4] = g[4];
+                    adj[0][nb][5] = g[5];
+                    adj[0][nb][6] = g[6];
+                    adj[1][nb][0] = -a.c1 * g[4] - a.c2 * g[5];
+                    adj[1][nb][1] = -a.G * g[6];
+                    adj[1][nb][4] = g[0];
+                    adj[1][nb][6] = g[1];
+                    adj[2][nb][0] = -a.G * g[6];
+                    adj[2][nb][1] = -a.c2 * g[4] - a.c1 * g[5];
+                    adj[2][nb][5] = g[1];
+                    adj[2][nb][6] = g[0];
+                    adj[3][nb][0] = g[2];
+                    adj[3][nb][1] = g[3];
+                    adj[3][nb][2] = -a.rho * g[0];
+                    adj[3][nb][3] = -a.rho * g[1];
+                } else if constexpr (HEAD == HEAD_DATA) {
+                    // loss_IC / loss_SRC / loss_NB / loss_FIX (INF:111-118, CONF:145-146): sum_o w_o (Y_o - target_o)^2
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) {
+                        float d = 0.0f;
+                        if (o < a.net.nout) d = Y[0][nb][o] - (a.targets ? a.targets[(long)o * a.n + pidx[nb]] : 0.0f);
+                        if (q == 0) lsum[o] += vm * d * d;
+                        adj[0][nb][o] = 2.0f * a.tw[o] * d * vm;
+                    }
+                } else {
+                    // predict (INF:337-347): write Y and the three tangents, [4*nout][n]
+                    if (q == 0 && valid[nb]) {
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+#pragma unroll
+                            for (int o = 0; o < 8; ++o)
+                                if (o < a.net.nout) a.fields_out[((long)s * a.net.nout + o) * a.n + pidx[nb]] = Y[s][nb][o];
+                    }
+                }
+            }
+            if constexpr (HEAD != HEAD_FIELDS) {
+                // ---- Z_nl: adjoint of the outputs, lane keeps outputs 4(q&1)+r for q<2, zeros otherwise
+                u32x4 ZL[NS][NB][1][NP];
+                {
+                    float vals[NS][NB][4];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) vals[s][nb][r] = q < 2 ? ((q & 1) ? adj[s][nb][4 + r] : adj[s][nb][r]) : 0.0f;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int p = 0; p < NP; ++p) ZL[s][nb][0][p] = u32x4{0u, 0u, 0u, 0u};
+                    emit<1, 0>(ZL, vals, Zt + PG::z_off(nl), 16, c, q);
+                }
+                // ---- reverse chain
+                u32x4 Zc[NS][NB][KS][NP];
+                MbLoop<0>::template bwd<1>(a.pw.frags + (long)FI::bwd_last(nl, 0) * NP * 64, lane, ZL, St + PG::s_off(nl), Zc,
+                                           Zt + PG::z_off(nl - 1), c, q);
+                for (int l = nl - 1; l >= 1; --l) {
+                    u32x4 Zn[NS][NB][KS][NP];
+                    MbLoop<0>::template bwd<KS>(a.pw.frags + (long)FI::bwd_mid(nl, l, 0, 0) * NP * 64, lane, Zc, St + PG::s_off(l), Zn,
+                                                Zt + PG::z_off(l - 1), c, q);
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                                for (int p = 0; p < NP; ++p) Zc[s][nb][kk][p] = Zn[s][nb][kk][p];
+                }
+            }
+        }
+        if constexpr (HEAD != HEAD_FIELDS) {
+            // per-wave partial sums of squares (only q == 0 lanes hold data): reduce over the 16 points
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = lsum[i];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                if (lane == 0) a.loss_part[gwave * 8 + i] = v;
+            }
+        }
+    }
+};
+
+template <class Op, int SPLIT, int WIDTH, int NB, int NS, int HEAD>
+__global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
+    Chain<Op, SPLIT, WIDTH, NB, NS, HEAD>::run(a);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight-gradient kernel:  Wbar_l[in,out] = sum_tiles sum_streams S_l[in, pts] . Z_l[out, pts]^T
+// grid = (chunks, nl+1); wave w of a block owns in-blocks w, w+4, ...; contraction over points
+// (32 per MFMA k-step) read straight from the [feature][point] panels -- no LDS.
+// ------------------------------------------------------------------------------------------
+template <class Op, int SPLIT, int WIDTH, int NB, int NS>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    constexpr int WB = WIDTH / 16, NP = SPLIT == 3 ? 2 : 1, TP = 16 * NB, IBW = (WB + 3) / 4;
+    constexpr float INV_LS = 1.0f / Op::LO_SCALE;
+    typedef PanelGeom<WIDTH, NB, NS, NP> PG;
+    const int l = blockIdx.y, nl = a.net.nl;
+    const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
+    const int IB = l == 0 ? 1 : WB, OB = l == nl ? 1 : WB;
+    const int rowsS = l == 0 ? 16 : WIDTH, rowsZ = l == nl ? 16 : WIDTH;
+    const int real_in = l == 0 ? 3 : a.net.h, real_out = l == nl ? a.net.nout : a.net.h;
+
+    f32x4 acc[IBW][WB], accc[IBW][WB], bacc[WB], baccc[WB];
+#pragma unroll
+    for (int ob = 0; ob < WB; ++ob) {
+        bacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        baccc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < IBW; ++i) {
+            acc[i][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+            accc[i][ob] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const uint32_t one2 = pack2<Op>(1.0f, 1.0f);
+    const u32x4 ones = {one2, one2, one2, one2};
+
+    const long nksteps = a.ntiles * TP / 32;
+    for (long ks = blockIdx.x; ks < nksteps; ks += gridDim.x) {
+        const long tile = NB == 2 ? ks : 2 * ks + (q >> 1);
+        const int col0 = NB == 2 ? 8 * q : 8 * (q & 1);
+        for (int s = 0; s < NS; ++s) {
+            const uint16_t* Sp = a.S + tile * a.S_tile_stride + PG::s_off(l) + (long)(s * NP) * rowsS * TP + col0;
+            const uint16_t* Zp = a.Z + tile * a.Z_tile_stride + PG::z_off(l) + (long)(s * NP) * rowsZ * TP + col0;
+            u32x4 Zh[WB], Zl[WB];
+#pragma unroll
+            for (int ob = 0; ob < WB; ++ob)
+                if (ob < OB) {
+                    Zh[ob] = *reinterpret_cast<const u32x4*>(Zp + (long)(16 * ob + c) * TP);
+                    if (NP == 2) Zl[ob] = *reinterpret_cast<const u32x4*>(Zp + (long)rowsZ * TP + (long)(16 * ob + c) * TP);
+                }
+#pragma unroll
+            for (int i = 0; i < IBW; ++i) {
+                const int ib = wave + 4 * i;
+                if (ib < IB) {
+                    const u32x4 Ah = *reinterpret_cast<const u32x4*>(Sp + (long)(16 * ib + c) * TP);
+                    u32x4 Al = {0u, 0u, 0u, 0u};
+                    if (NP == 2) Al = *reinterpret_cast<const u32x4*>(Sp + (long)rowsS * TP + (long)(16 * ib + c) * TP);
+#pragma unroll
+                    for (int ob = 0; ob < WB; ++ob)
+                        if (ob < OB) {
+                            acc[i][ob] = Op::mfma(Ah, Zh[ob], acc[i][ob]);
+                            if (NP == 2) {
+                                accc[i][ob] = Op::mfma(Ah, Zl[ob], accc[i][ob]);
+                                accc[i][ob] = Op::mfma(Al, Zh[ob], accc[i][ob]);
+                            }
+                        }
+                }
+            }
+            if (s == 0 && wave == 0) {   // bias gradient: ones^T . Z (value stream)
+#pragma unroll
+                for (int ob = 0; ob < WB; ++ob)
+                    if (ob < OB) {
+                        bacc[ob] = Op::mfma(ones, Zh[ob], bacc[ob]);
+                        if (NP == 2) baccc[ob] = Op::mfma(ones, Zl[ob], baccc[ob]);
+                    }
+            }
+        }
+    }
+    float* part = a.partial + (long)blockIdx.x * a.net.nparams;
+#pragma unroll
+    for (int i = 0; i < IBW; ++i) {
+        const int ib = wave + 4 * i;
+        if (ib < IB) {
+#pragma unroll
+            for (int ob = 0; ob < WB; ++ob)
+                if (ob < OB) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int in = 16 * ib + 4 * q + r, out = 16 * ob + c;
+                        if (in < real_in && out < real_out) {
+                            const float v = NP == 2 ? acc[i][ob][r] + accc[i][ob][r] * INV_LS : acc[i][ob][r];
+                            float* dst = part + a.net.w_off[l] + in * real_out + out;
+                            *dst = a.first_pass ? v : *dst + v;
+                        }
+                    }
+                }
+        }
+    }
+    if (wave == 0 && q == 0) {
+#pragma unroll
+        for (int ob = 0; ob < WB; ++ob)
+            if (ob < OB) {
+                const int out = 16 * ob + c;
+                if (out < real_out) {
+                    const float v = NP == 2 ? bacc[ob][0] + baccc[ob][0] * INV_LS : bacc[ob][0];
+                    float* dst = part + a.net.b_off[l] + out;
+                    *dst = a.first_pass ? v : *dst + v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small reductions / optimizer
+// ------------------------------------------------------------------------------------------
+// grad[p] = (accumulate ? grad[p] : 0) + scale * sum_c partial[c][p]
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void reduce_grad_kernel(const float* partial, int nchunks, int nparams, float scale,
+                                                          float* grad, int accumulate) {
+    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nparams) return;
+    float s = 0.0f;
+    for (int cidx = 0; cidx < nchunks; ++cidx) s += partial[(long)cidx * nparams + p];
+    grad[p] = (accumulate ? grad[p] : 0.0f) + scale * s;
+}
+
+// loss_terms[i] (+)= sum over waves of loss_part[w][i]   (single block of 64 threads; nterms <= 8)
+template <int UNUSED = 0>
+__global__ __launch_bounds__(64) void reduce_loss_kernel(const float* loss_part, long nwaves, int nterms, float* loss_terms,
+                                                         int accumulate) {
+    const int lane = threadIdx.x;
+    for (int i = 0; i < nterms; ++i) {
+        double s = 0.0;
+        for (long w = lane; w < nwaves; w += 64) s += (double)loss_part[w * 8 + i];
+        float v = (float)s;
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        if (lane == 0) loss_terms[i] = (accumulate ? loss_terms[i] : 0.0f) + v;
+    }
+}
+
+// tf.train.AdamOptimizer (TF1 rule; INF:131-133): epsilon added to the UNCORRECTED sqrt(v); the bias
+// correction lives in lr_t = lr * sqrt(1-beta2^t)/(1-beta1^t), computed by the caller in double.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void adam_tf1_kernel(float* theta, float* m, float* v, const float* g, long n, float lr_t,
+                                                       float beta1, float beta2, float eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float gi = g[i];
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    theta[i] -= lr_t * mi / (__builtin_amdgcn_sqrtf(vi) + eps);
+}
+
+}  // namespace pinn

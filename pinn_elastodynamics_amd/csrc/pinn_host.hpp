@@ -1,0 +1,261 @@
+// Host-side launch logic of libpinn_hip.so, templated on the matrix-pipe operand type, the
+// split factor and the padded hidden width.  One instantiation per line of pinn_variants.def
+// (compiled as its own object by the build, see __graft_entry__.build()).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/pinn_hip.h"
+#include "pinn_device.hpp"
+
+namespace pinn {
+
+struct Call {
+    NetDesc net;
+    const float* params;
+    const float* x;
+    const float* y;
+    const float* t;
+    long n;
+    float sx[3], ox[3];
+    void* ws;
+    size_t ws_bytes;
+    hipStream_t stream;
+    float* loss_out;
+    float* grad_out;
+    int accumulate;
+    // wave residual head
+    float c1, c2, G, rho;
+    float tw[8];
+    // data head
+    const float* targets;
+    // fields head
+    float* fields_out;
+    // optional per-kernel timing (host pointer, 4 floats: repack, chain, wgrad, reductions) -- makes the call synchronous
+    float* prof_ms;
+};
+
+struct Impl {
+    int (*wave_loss_grad)(const Call&);
+    int (*data_loss_grad)(const Call&);
+    int (*fields)(const Call&);
+    size_t (*ws_bytes)(const NetDesc&, long n, int minimum);
+};
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+template <class Op, int SPLIT, int WIDTH>
+struct Host {
+    static constexpr int NB = WIDTH <= 64 ? 2 : 1;
+    static constexpr int NP = SPLIT == 3 ? 2 : 1;
+    static constexpr int TP = 16 * NB;
+    static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
+    static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
+    static constexpr long MIN_TILES = 64;
+    typedef FragIndex<WIDTH> FI;
+
+    struct Plan {
+        size_t w0p, bias_mid, bias_last, frags, loss_part, partial, panels, fixed_end;
+        long s_tile, z_tile;     // 16-bit elements per tile
+        long ntiles;             // total tiles of the call (even)
+        long chunk_tiles;        // tiles per workspace pass (even)
+    };
+
+    template <int NS>
+    static void plan_fixed(const NetDesc& net, long n, Plan& p) {
+        typedef PanelGeom<WIDTH, NB, NS, NP> PG;
+        size_t o = 0;
+        p.w0p = o;
+        o = align_up(o + (size_t)WIDTH * 4 * sizeof(float), 256);
+        p.bias_mid = o;
+        o = align_up(o + (size_t)(net.nl > 1 ? net.nl - 1 : 1) * WIDTH * sizeof(float), 256);
+        p.bias_last = o;
+        o = align_up(o + NOUT_PAD * sizeof(float), 256);
+        p.frags = o;
+        o = align_up(o + (size_t)FI::total(net.nl) * NP * 64 * sizeof(u32x4), 256);
+        p.loss_part = o;
+        o = align_up(o + (size_t)MAX_BLOCKS * 4 * 8 * sizeof(float), 256);
+        p.partial = o;
+        o = align_up(o + (size_t)NCHUNK * net.nparams * sizeof(float), 256);
+        p.panels = o;
+        p.fixed_end = o;
+        p.s_tile = PG::s_tile(net.nl);
+        p.z_tile = PG::z_tile(net.nl);
+        long nt = (n + TP - 1) / TP;
+        p.ntiles = (nt + 1) & ~1L;
+    }
+
+    static size_t ws_bytes(const NetDesc& net, long n, int minimum) {
+        Plan p;
+        plan_fixed<4>(net, n, p);
+        const long tiles = minimum ? (p.ntiles < MIN_TILES ? p.ntiles : MIN_TILES) : p.ntiles;
+        return p.fixed_end + (size_t)tiles * (size_t)(p.s_tile + p.z_tile) * 2;
+    }
+
+    template <int NS>
+    static int make_plan(const Call& c, Plan& p, bool panels) {
+        if (((uintptr_t)c.ws & 255) != 0) return PINN_ERR_WORKSPACE;
+        plan_fixed<NS>(c.net, c.n, p);
+        if (c.ws_bytes < p.fixed_end) return PINN_ERR_WORKSPACE;
+        if (!panels) { p.chunk_tiles = p.ntiles; return PINN_OK; }
+        const size_t per_tile = (size_t)(p.s_tile + p.z_tile) * 2;
+        long fit = (long)((c.ws_bytes - p.fixed_end) / per_tile) & ~1L;
+        if (fit > p.ntiles) fit = p.ntiles;
+        if (fit < 2) return PINN_ERR_WORKSPACE;
+        p.chunk_tiles = fit;
+        return PINN_OK;
+    }
+
+    static PackedWeights packed(const Call& c, const Plan& p) {
+        char* b = static_cast<char*>(c.ws);
+        PackedWeights pw;
+        pw.w0p = reinterpret_cast<const float*>(b + p.w0p);
+        pw.bias_mid = reinterpret_cast<const float*>(b + p.bias_mid);
+        pw.bias_last = reinterpret_cast<const float*>(b + p.bias_last);
+        pw.frags = reinterpret_cast<const u32x4*>(b + p.frags);
+        return pw;
+    }
+
+    static int repack(const Call& c, const Plan& p) {
+        char* b = static_cast<char*>(c.ws);
+        RepackArgs ra;
+        ra.net = c.net;
+        ra.params = c.params;
+        ra.w0p = reinterpret_cast<float*>(b + p.w0p);
+        ra.bias_mid = reinterpret_cast<float*>(b + p.bias_mid);
+        ra.bias_last = reinterpret_cast<float*>(b + p.bias_last);
+        ra.frags = reinterpret_cast<u32x4*>(b + p.frags);
+        const long items = (long)FI::total(c.net.nl) * 64;
+        const int blocks = (int)((items + 255) / 256);
+        hipLaunchKernelGGL((repack_kernel<Op, SPLIT, WIDTH>), dim3(blocks), dim3(256), 0, c.stream, ra);
+        return (int)hipGetLastError();
+    }
+
+    static void fill_common(const Call& c, const Plan& p, ChainArgs& a) {
+        a.net = c.net;
+        a.pw = packed(c, p);
+        a.x = c.x;
+        a.y = c.y;
+        a.t = c.t;
+        a.n = c.n;
+        for (int k = 0; k < 3; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
+        a.c1 = c.c1;
+        a.c2 = c.c2;
+        a.G = c.G;
+        a.rho = c.rho;
+        a.targets = c.targets;
+        a.fields_out = c.fields_out;
+        a.S = nullptr;
+        a.Z = nullptr;
+        a.S_tile_stride = p.s_tile;
+        a.Z_tile_stride = p.z_tile;
+        a.loss_part = reinterpret_cast<float*>(static_cast<char*>(c.ws) + p.loss_part);
+    }
+
+    static int chain_blocks(long ntiles) {
+        long b = (ntiles + 3) / 4;
+        if (b > MAX_BLOCKS) b = MAX_BLOCKS;
+        if (b < 1) b = 1;
+        return (int)b;
+    }
+
+    // forward + reverse chain + weight gradient for one head (NS streams)
+    template <int NS, int HEAD>
+    static int loss_grad(const Call& c, int nterms) {
+        Plan p;
+        int rc = make_plan<NS>(c, p, true);
+        if (rc) return rc;
+        // optional HIP-event timing of each kernel class (bench.py's roofline leg)
+        hipEvent_t ev[2] = {nullptr, nullptr};
+        float acc_ms[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool prof = c.prof_ms != nullptr;
+        if (prof) { hipEventCreate(&ev[0]); hipEventCreate(&ev[1]); }
+        auto tic = [&]() { if (prof) hipEventRecord(ev[0], c.stream); };
+        auto toc = [&](int slot) {
+            if (!prof) return;
+            hipEventRecord(ev[1], c.stream);
+            hipEventSynchronize(ev[1]);
+            float ms = 0.f;
+            hipEventElapsedTime(&ms, ev[0], ev[1]);
+            acc_ms[slot] += ms;
+        };
+        tic();
+        rc = repack(c, p);
+        if (rc) return rc;
+        toc(0);
+        float twmax = 0.0f;
+        for (int i = 0; i < 8; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
+        ChainArgs a;
+        fill_common(c, p, a);
+        for (int i = 0; i < 8; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
+        char* b = static_cast<char*>(c.ws);
+        a.S = reinterpret_cast<uint16_t*>(b + p.panels);
+        a.Z = a.S + p.chunk_tiles * p.s_tile;
+        WgradArgs w;
+        w.net = c.net;
+        w.S = a.S;
+        w.Z = a.Z;
+        w.S_tile_stride = p.s_tile;
+        w.Z_tile_stride = p.z_tile;
+        w.partial = reinterpret_cast<float*>(b + p.partial);
+        int pass = 0;
+        for (long t0 = 0; t0 < p.ntiles; t0 += p.chunk_tiles, ++pass) {
+            const long nt = (p.ntiles - t0) < p.chunk_tiles ? (p.ntiles - t0) : p.chunk_tiles;
+            a.tile0 = t0;
+            a.ntiles = nt;
+            const int blocks = chain_blocks(nt);
+            tic();
+            hipLaunchKernelGGL((chain_kernel<Op, SPLIT, WIDTH, NB, NS, HEAD>), dim3(blocks), dim3(256), 0, c.stream, a);
+            if ((rc = (int)hipGetLastError())) return rc;
+            toc(1);
+            tic();
+            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(64), 0, c.stream, (const float*)a.loss_part, (long)blocks * 4, nterms,
+                               c.loss_out, pass > 0 ? 1 : 0);
+            if ((rc = (int)hipGetLastError())) return rc;
+            toc(3);
+            w.ntiles = nt;
+            w.first_pass = pass == 0 ? 1 : 0;
+            tic();
+            hipLaunchKernelGGL((wgrad_kernel<Op, SPLIT, WIDTH, NB, NS>), dim3(NCHUNK, c.net.nl + 1), dim3(256), 0, c.stream, w);
+            if ((rc = (int)hipGetLastError())) return rc;
+            toc(2);
+        }
+        tic();
+        hipLaunchKernelGGL((reduce_grad_kernel<0>), dim3((c.net.nparams + 255) / 256), dim3(256), 0, c.stream, (const float*)w.partial,
+                           (int)NCHUNK, c.net.nparams, twmax, c.grad_out, c.accumulate);
+        rc = (int)hipGetLastError();
+        toc(3);
+        if (prof) {
+            for (int i = 0; i < 4; ++i) c.prof_ms[i] = acc_ms[i];
+            hipEventDestroy(ev[0]);
+            hipEventDestroy(ev[1]);
+        }
+        return rc;
+    }
+
+    static int wave_loss_grad(const Call& c) { return loss_grad<4, HEAD_WAVE>(c, 7); }
+    static int data_loss_grad(const Call& c) { return loss_grad<1, HEAD_DATA>(c, c.net.nout); }
+
+    static int fields(const Call& c) {
+        Plan p;
+        int rc = make_plan<4>(c, p, false);
+        if (rc) return rc;
+        rc = repack(c, p);
+        if (rc) return rc;
+        ChainArgs a;
+        fill_common(c, p, a);
+        for (int i = 0; i < 8; ++i) a.tw[i] = 0.0f;
+        a.tile0 = 0;
+        a.ntiles = p.ntiles;
+        hipLaunchKernelGGL((chain_kernel<Op, SPLIT, WIDTH, NB, 4, HEAD_FIELDS>), dim3(chain_blocks(p.ntiles)), dim3(256), 0, c.stream, a);
+        return (int)hipGetLastError();
+    }
+
+    static const Impl* impl() {
+        static const Impl I = {&wave_loss_grad, &data_loss_grad, &fields, &ws_bytes};
+        return &I;
+    }
+};
+
+}  // namespace pinn

@@ -1,0 +1,403 @@
+"""Host-side mirror of the reference's model class for the three elastic-wave cases.
+
+Same names, argument order and column-tensor convention as ``class DeepHPM`` in
+  INF  = ElasticWaveInfinite/ElasticWave.py      (float32, inputs normalised, INF:191)
+  SEMI = ElasticWaveSemiInfinite/ElasticWave.py  (raw inputs, loss layout SEMI:127)
+  CONF = ElasticWaveConfined/ElasticWave.py      (raw inputs, FIXED edges, CONF:156)
+but nothing of TF1's runtime: weights live in one flat fp32 device vector, point sets are device
+resident (no per-step feed, cf. INF:297-305), the loss + gradient of every term comes from the
+HIP kernels behind ``include/pinn_hip.h`` and Adam runs on the device.
+
+Data-parallel training (one process per GPU, torch.distributed): every point set is sharded into
+contiguous row ranges (the reference's own batching precedent, INF:292-297); each rank's kernels
+weight their partial sums with the GLOBAL 1/N, one all-reduce(sum) of [flat gradient | loss sums]
+follows, and the identical fused Adam step runs on every rank, so the weights stay bit-identical.
+"""
+from __future__ import annotations
+
+import pickle
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+# multipliers of (loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss_NB, loss_FIX) in the total loss
+LOSS_LAYOUT = {
+    "infinite": dict(f_uv=1.0, f_s=1.0, IC=1.0, SRC=1.0, NB=0.0, FIX=0.0),        # INF:119 (loss_NB excluded)
+    "semi_infinite": dict(f_uv=5.0, f_s=5.0, IC=2.0, SRC=2.0, NB=2.0, FIX=0.0),   # SEMI:127
+    "confined": dict(f_uv=5.0, f_s=5.0, IC=1.0, SRC=1.0, NB=0.0, FIX=1.0),        # CONF:156
+}
+# scipy L-BFGS-B options of tf.contrib.opt.ScipyOptimizerInterface (INF:122-129, SEMI:130-137, CONF:159-166)
+_EPS = float(np.finfo(float).eps)
+BFGS_OPTIONS = {
+    "infinite": dict(maxiter=10000, maxfun=10000, maxcor=50, maxls=50, ftol=0.001 * _EPS),
+    "semi_infinite": dict(maxiter=1000, maxfun=1000, maxcor=50, maxls=50, ftol=0.001 * _EPS),
+    "confined": dict(maxiter=100000, maxfun=100000, maxcor=50, maxls=50, ftol=1.0 * _EPS),
+}
+_SLOTS = ("collo", "IC", "SRC", "NB", "FIX")   # 8 floats each in the loss-sum buffer
+
+
+def _col(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+
+
+def xavier_init(layers: Sequence[int], rng: np.random.Generator):
+    """initialize_NN / xavier_init (INF:141-156): truncated normal (|z| <= 2) times
+    sqrt(2/(in+out)), zero biases of shape [1, out].  The build's own seeded stream (TF1's is
+    not reproducible)."""
+    Ws, bs = [], []
+    for i in range(len(layers) - 1):
+        n_in, n_out = layers[i], layers[i + 1]
+        W = rng.standard_normal((n_in, n_out))
+        bad = np.abs(W) > 2.0
+        while bad.any():
+            W[bad] = rng.standard_normal(int(bad.sum()))
+            bad = np.abs(W) > 2.0
+        Ws.append((W * np.sqrt(2.0 / (n_in + n_out))).astype(np.float32))
+        bs.append(np.zeros((1, n_out), dtype=np.float32))
+    return Ws, bs
+
+
+def pack_params(weights, biases) -> np.ndarray:
+    """[W_list, b_list] -> flat fp32 vector W0,b0,W1,b1,... (the C-ABI layout)."""
+    parts = []
+    for W, b in zip(weights, biases):
+        parts += [np.asarray(W, dtype=np.float32).reshape(-1), np.asarray(b, dtype=np.float32).reshape(-1)]
+    return np.concatenate(parts)
+
+
+def unpack_params(flat, layers):
+    Ws, bs, o = [], [], 0
+    flat = np.asarray(flat)
+    for i in range(len(layers) - 1):
+        n_in, n_out = layers[i], layers[i + 1]
+        Ws.append(flat[o:o + n_in * n_out].reshape(n_in, n_out).copy())
+        o += n_in * n_out
+        bs.append(flat[o:o + n_out].reshape(1, n_out).copy())
+        o += n_out
+    assert o == flat.size
+    return Ws, bs
+
+
+class DeepHPM:
+    """Drop-in for the reference's model class on the wave cases (INF:21-376)."""
+
+    def __init__(self, Collo, SRC, IC, UP, uv_layers, lb, ub, ExistModel=0, modelDir='', *, case="infinite",
+                 FIX=None, precision="f16x3", engine=None, seed=1111, process_group=None, verbose=True,
+                 E=2.5, mu=0.25, rho=1.0):
+        self.count = 0                      # callback counter (INF:26)
+        self.loss_rec = []                  # SEMI:39
+        self.case = case
+        self.layout = LOSS_LAYOUT[case]
+        self.normalize = case == "infinite"            # INF:191 vs SEMI:198 / CONF:235
+        self.lb = np.asarray(lb, dtype=np.float64).reshape(-1)
+        self.ub = np.asarray(ub, dtype=np.float64).reshape(-1)
+        self.E, self.mu, self.rho = E, mu, rho         # INF:33-35
+        self.uv_layers = [int(v) for v in uv_layers]
+        self.verbose = verbose
+
+        # ---- data parallel topology
+        self.pg = process_group
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.rank = torch.distributed.get_rank(self.pg)
+            self.world = torch.distributed.get_world_size(self.pg)
+        else:
+            self.rank, self.world = 0, 1
+
+        # ---- engine (GPU kernels); tests may inject a stand-in with the same methods
+        if engine is None:
+            from .hip_engine import HipEngine
+            n_max = max(int(np.asarray(Collo).shape[0]) // self.world + 1, 1 << 14)
+            engine = HipEngine(self.uv_layers, precision=precision, max_points=n_max)
+        self.engine = engine
+        self.device = engine.device
+
+        # ---- weights (INF:64-68)
+        if ExistModel == 0:
+            W, b = xavier_init(self.uv_layers, np.random.default_rng(seed))
+        else:
+            W, b = self.load_NN(modelDir, self.uv_layers)
+        self.n_params = sum(w.size for w in W) + sum(x.size for x in b)
+        self.theta = torch.from_numpy(pack_params(W, b)).to(self.device)
+        self.adam_m = torch.zeros_like(self.theta)
+        self.adam_v = torch.zeros_like(self.theta)
+        self.adam_t = 0
+
+        # ---- point sets, column split like INF:40-59, stored SoA on the device
+        def dev(a):
+            return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
+
+        Collo = np.asarray(Collo, dtype=np.float64)
+        self.x_c, self.y_c, self.t_c = Collo[:, 0:1], Collo[:, 1:2], Collo[:, 2:3]
+        self._collo = tuple(dev(_col(Collo[:, k])) for k in range(3))
+        self._sides = {}      # name -> (x, y, t, targets[7,n] or None, out columns)
+
+        def side(name, A, cols, target_cols=None):
+            if A is None:
+                return
+            A = np.asarray(A, dtype=np.float64)
+            if A.shape[0] == 0:
+                return
+            n_glob = A.shape[0]
+            s, e = self._shard(0, n_glob)            # this rank's contiguous rows
+            A = A[s:e]
+            tg = None
+            if target_cols is not None and e > s:
+                T = np.zeros((7, A.shape[0]), dtype=np.float32)
+                for o, cidx in zip(cols, target_cols):
+                    T[o] = A[:, cidx]
+                tg = dev(T)
+            self._sides[name] = (dev(_col(A[:, 0])), dev(_col(A[:, 1])), dev(_col(A[:, 2])), tg, tuple(cols), n_glob)
+
+        side("IC", IC, (0, 1, 2, 3))                     # u,v,ut,vt = 0 at t=0          INF:111-114
+        side("SRC", SRC, (0, 1), (3, 4))                 # u,v = source displacement     INF:115-116
+        side("NB", UP, (5, 6))                           # s22,s12 = 0 on the free edge  INF:117-118
+        side("FIX", FIX, (0, 1))                         # u,v = 0 on the fixed edges    CONF:145-146
+        self.SRC, self.IC, self.UP, self.FIX = SRC, IC, UP, FIX
+
+        P = self.n_params
+        self._buf = torch.zeros(P + 8 * len(_SLOTS), dtype=torch.float32, device=self.device)
+
+    # ------------------------------------------------------------------------------------------
+    # checkpoints: the reference's [W_list, b_list] pickle (INF:159-186); .npz is accepted too
+    # ------------------------------------------------------------------------------------------
+    def save_NN(self, fileDir, TYPE=''):
+        W, b = unpack_params(self.theta.detach().cpu().numpy(), self.uv_layers)
+        if str(fileDir).endswith(".npz"):
+            np.savez(fileDir, layers=np.array(self.uv_layers), **{f"W{i}": w for i, w in enumerate(W)},
+                     **{f"b{i}": x for i, x in enumerate(b)})
+        else:
+            with open(fileDir, 'wb') as f:
+                pickle.dump([W, b], f)
+        if self.verbose:
+            print("Save NN parameters successfully...")
+
+    def load_NN(self, fileDir, layers):
+        num_layers = len(layers)
+        if str(fileDir).endswith(".npz"):
+            z = np.load(fileDir)
+            n = sum(1 for k in z.files if k.startswith("W"))
+            uv_weights = [z[f"W{i}"] for i in range(n)]
+            uv_biases = [z[f"b{i}"] for i in range(n)]
+        else:
+            with open(fileDir, 'rb') as f:
+                uv_weights, uv_biases = pickle.load(f, encoding="latin1")
+        # Stored model must have the same number of layers (INF:178)
+        assert num_layers == (len(uv_weights) + 1)
+        weights = [np.asarray(w, dtype=np.float32) for w in uv_weights]
+        biases = [np.asarray(b, dtype=np.float32).reshape(1, -1) for b in uv_biases]
+        for i, w in enumerate(weights):
+            assert w.shape == (layers[i], layers[i + 1]), "stored weight shape does not match uv_layers"
+        if self.verbose:
+            print("Load NN parameters successfully...")
+        return weights, biases
+
+    def set_weights(self, weights, biases):
+        self.theta.copy_(torch.from_numpy(pack_params(weights, biases)).to(self.device))
+
+    # ------------------------------------------------------------------------------------------
+    # graph pieces as callables on column arrays [N,1] (INF:188-276)
+    # ------------------------------------------------------------------------------------------
+    def _fields(self, x, y, t):
+        xs = [torch.from_numpy(np.ascontiguousarray(_col(a), dtype=np.float32)).to(self.device) for a in (x, y, t)]
+        return self.engine.fields(self.theta, xs[0], xs[1], xs[2], self.lb, self.ub, self.normalize)   # [4,7,N]
+
+    @staticmethod
+    def _cols(T):
+        return tuple(T[i].detach().cpu().numpy().reshape(-1, 1) for i in range(T.shape[0]))
+
+    def neural_net(self, X, weights=None, biases=None):
+        """INF:188-199 on X [N,3] -> Y [N,n_out] with the model's current weights."""
+        X = np.asarray(X)
+        F = self._fields(X[:, 0], X[:, 1], X[:, 2])
+        return F[0].T.detach().cpu().numpy()
+
+    def net_uv(self, x, y, t):                       # INF:201-211
+        return self._cols(self._fields(x, y, t)[0])
+
+    def net_e(self, x, y, t):                        # INF:213-219
+        F = self._fields(x, y, t)
+        e11, e22, e12 = F[1, 0], F[2, 1], F[2, 0] + F[1, 1]
+        return self._cols(torch.stack([e11, e22, e12]))
+
+    def net_f_sig(self, x, y, t):                    # INF:221-265
+        F = self._fields(x, y, t)
+        return self._cols(self._residuals(F))
+
+    def _residuals(self, F):
+        E, mu, rho = self.E, self.mu, self.rho
+        V, X, Y, T = F[0], F[1], F[2], F[3]
+        e11, e22, e12 = X[0], Y[1], Y[0] + X[1]
+        coef = E / ((1 + mu) * (1 - 2 * mu))                         # plane strain, INF:238
+        sp11 = coef * (1 - mu) * e11 + coef * mu * e22
+        sp22 = coef * mu * e11 + coef * (1 - mu) * e22
+        sp12 = E / (2 * (1 + mu)) * e12
+        f_u = X[4] + Y[6] - rho * T[2]
+        f_v = Y[5] + X[6] - rho * T[3]
+        return torch.stack([f_u, f_v, T[0] - V[2], T[1] - V[3], V[4] - sp11, V[5] - sp22, V[6] - sp12])
+
+    def net_surf_var(self, x, y, t, nx, ny):         # INF:267-276
+        u, v, ut, vt, s11, s22, s12 = self.net_uv(x, y, t)
+        return s11 * nx + s12 * ny, s12 * nx + s22 * ny
+
+    def callback(self, loss):                        # INF:278-280, SEMI:285-288
+        self.count = self.count + 1
+        self.loss_rec.append(loss)
+        if self.verbose and self.rank == 0:
+            print('{} th iterations, Loss: {}'.format(self.count, loss))
+
+    # ------------------------------------------------------------------------------------------
+    # one evaluation of loss terms + total gradient on one collocation block
+    # ------------------------------------------------------------------------------------------
+    def _shard(self, lo, hi):
+        n = hi - lo
+        return lo + n * self.rank // self.world, lo + n * (self.rank + 1) // self.world
+
+    def _loss_and_grad(self, idx_start, idx_end):
+        """Fills self._buf = [grad (P) | 8 floats per slot] with this rank's partial sums, then
+        all-reduces.  Returns nothing; everything stays on the device."""
+        P, lay, eng, buf = self.n_params, self.layout, self.engine, self._buf
+        buf[P:].zero_()
+        grad = buf[:P]
+        n_blk = idx_end - idx_start
+        s, e = self._shard(idx_start, idx_end)
+        tw = [lay["f_uv"] / n_blk] * 4 + [lay["f_s"] / n_blk] * 3
+        wrote = False
+        if e > s:
+            x, y, t = (a[s:e] for a in self._collo)
+            eng.wave_loss_grad(self.theta, x, y, t, self.lb, self.ub, self.normalize, tw, self.E, self.mu, self.rho, True,
+                               grad_out=grad, accumulate=False, loss_out=buf[P:P + 8])
+            wrote = True
+        for k, name in enumerate(_SLOTS[1:], start=1):
+            if name not in self._sides or lay[name] == 0.0:
+                continue
+            x, y, t, tg, cols, n = self._sides[name]
+            if x.numel() == 0:
+                continue
+            ow = [0.0] * 7
+            for o in cols:
+                ow[o] = lay[name] / n
+            eng.data_loss_grad(self.theta, x, y, t, self.lb, self.ub, self.normalize, tg, ow,
+                               grad_out=grad, accumulate=wrote, loss_out=buf[P + 8 * k:P + 8 * k + 8])
+            wrote = True
+        if not wrote:
+            grad.zero_()
+        if self.world > 1:
+            torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+
+    def _terms_from_sums(self, sums, n_blk):
+        """sums: [len(_SLOTS), 8] numpy array of sums of squares -> the reference's loss terms."""
+        lay = self.layout
+        out = {"loss_f_uv": float(sums[0, :4].sum() / n_blk), "loss_f_s": float(sums[0, 4:7].sum() / n_blk)}
+        for k, name in enumerate(_SLOTS[1:], start=1):
+            if name in self._sides:
+                n = self._sides[name][5]
+                cols = list(self._sides[name][4])
+                out["loss_" + name] = float(sums[k, cols].sum() / n)
+            else:
+                out["loss_" + name] = 0.0
+        out["loss"] = (lay["f_uv"] * out["loss_f_uv"] + lay["f_s"] * out["loss_f_s"] + lay["IC"] * out["loss_IC"]
+                       + lay["SRC"] * out["loss_SRC"] + lay["NB"] * out["loss_NB"] + lay["FIX"] * out["loss_FIX"])
+        return out
+
+    # ------------------------------------------------------------------------------------------
+    # training drivers
+    # ------------------------------------------------------------------------------------------
+    def train(self, iter, learning_rate, batch_num):
+        """Adam loop of INF:282-319: contiguous collocation blocks, ``iter`` steps per block, all
+        side sets fed whole to every block.  Returns the per-step lists
+        (loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss).  Deviation: each recorded value is the loss
+        the step's gradient was taken at (the reference re-evaluates every term after the update
+        with four to six extra sess.run calls per step, INF:308-317)."""
+        loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss = [], [], [], [], []
+        P = self.n_params
+        col_num = self._collo[0].numel()
+        for i in range(batch_num):
+            idx_start = int(i * col_num / batch_num)
+            idx_end = int((i + 1) * col_num / batch_num)
+            rec = torch.empty((iter, 8 * len(_SLOTS)), dtype=torch.float32, device=self.device)
+            for it in range(iter):
+                self._loss_and_grad(idx_start, idx_end)
+                rec[it].copy_(self._buf[P:])
+                self.adam_t += 1
+                self.engine.adam_step(self.theta, self.adam_m, self.adam_v, self._buf[:P], learning_rate, self.adam_t)
+                if self.verbose and it % 10 == 0 and self.rank == 0:
+                    tm = self._terms_from_sums(rec[it].detach().cpu().numpy().reshape(len(_SLOTS), 8), idx_end - idx_start)
+                    print('It: %d, Loss: %.3e' % (it, tm["loss"]))
+            sums = rec.detach().cpu().numpy().reshape(iter, len(_SLOTS), 8)
+            for it in range(iter):
+                tm = self._terms_from_sums(sums[it], idx_end - idx_start)
+                loss_f_uv.append(tm["loss_f_uv"])
+                loss_f_s.append(tm["loss_f_s"])
+                loss_IC.append(tm["loss_IC"])
+                loss_SRC.append(tm["loss_SRC"])
+                loss.append(tm["loss"])
+        return loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss
+
+    def train_bfgs(self, batch_num, options: Optional[dict] = None):
+        """L-BFGS-B stage of INF:321-335: scipy on the host over a float64 copy of the flat
+        parameter vector, loss and gradient from the device kernels; ``callback`` fires once per
+        function evaluation like ScipyOptimizerInterface's loss_callback."""
+        import scipy.optimize
+        P = self.n_params
+        opts = dict(BFGS_OPTIONS[self.case])
+        if options:
+            opts.update(options)
+        col_num = self._collo[0].numel()
+        result = None
+        for i in range(batch_num):
+            idx_start = int(i * col_num / batch_num)
+            idx_end = int((i + 1) * col_num / batch_num)
+
+            def fun(theta64):
+                self.theta.copy_(torch.from_numpy(theta64.astype(np.float32)).to(self.device))
+                self._loss_and_grad(idx_start, idx_end)
+                host = self._buf.detach().cpu().numpy()
+                tm = self._terms_from_sums(host[P:].reshape(len(_SLOTS), 8), idx_end - idx_start)
+                self.callback(tm["loss"])
+                return tm["loss"], host[:P].astype(np.float64)
+
+            x0 = self.theta.detach().cpu().numpy().astype(np.float64)
+            result = scipy.optimize.minimize(fun, x0, jac=True, method='L-BFGS-B', options=opts)
+            self.theta.copy_(torch.from_numpy(result.x.astype(np.float32)).to(self.device))
+        return result
+
+    # ------------------------------------------------------------------------------------------
+    # inference / diagnostics
+    # ------------------------------------------------------------------------------------------
+    def predict(self, x_star, y_star, t_star):
+        """INF:337-347: (u, v, s11, s22, s12, e11, e22, e12), each numpy [M,1]."""
+        F = self._fields(x_star, y_star, t_star)
+        out = torch.stack([F[0, 0], F[0, 1], F[0, 4], F[0, 5], F[0, 6], F[1, 0], F[2, 1], F[2, 0] + F[1, 1]])
+        return self._cols(out)
+
+    probe = predict                                  # INF:349-359 is a verbatim copy of predict
+
+    def getloss(self):
+        """INF:361-376: (loss, loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss_NB) on the full sets."""
+        n = self._collo[0].numel()
+        self._loss_and_grad(0, n)
+        host = self._buf[self.n_params:].detach().cpu().numpy().reshape(len(_SLOTS), 8)
+        tm = self._terms_from_sums(host, n)
+        if self.layout["NB"] == 0.0 and "NB" in self._sides:
+            # loss_NB is reported by getloss even where it is excluded from the total (INF:117-119,374)
+            lay = dict(self.layout)
+            self.layout = dict(lay, NB=1.0)
+            try:
+                self._loss_and_grad(0, n)
+                h2 = self._buf[self.n_params:].detach().cpu().numpy().reshape(len(_SLOTS), 8)
+                tm["loss_NB"] = self._terms_from_sums(h2, n)["loss_NB"]
+            finally:
+                self.layout = lay
+        return tm["loss"], tm["loss_f_uv"], tm["loss_f_s"], tm["loss_IC"], tm["loss_SRC"], tm["loss_NB"]
+
+
+class DeepHPMConfined(DeepHPM):
+    """Signature of the confined-domain script (CONF:23): its distance/particular networks are
+    created but never enter the graph there (CONF:282-294 ignores them), so they are accepted and
+    ignored here too."""
+
+    def __init__(self, Collo, SRC, IC, FIXED, DIST, uv_layers, dist_layers, part_layers, lb, ub,
+                 uvDir='', partDir='', distDir='', **kw):
+        super().__init__(Collo, SRC, IC, None, uv_layers, lb, ub, ExistModel=1 if uvDir else 0, modelDir=uvDir,
+                         case="confined", FIX=FIXED, **kw)

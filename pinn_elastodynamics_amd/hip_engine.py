@@ -1,0 +1,120 @@
+"""Device engine: PyTorch owns HBM buffers and streams, libpinn_hip.so does the work.
+
+This is the only place the product touches the GPU kernels.  There is NO CPU fallback: without a
+GPU or without the built shared library, construction raises.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from .capi import DEFAULT_LIB, PinnLib, PinnLibError
+
+
+def param_count(layers: Sequence[int]) -> int:
+    return sum(layers[i] * layers[i + 1] + layers[i + 1] for i in range(len(layers) - 1))
+
+
+class HipEngine:
+    """loss/gradient, fields and Adam on one GPU, on flat fp32 parameter vectors.
+
+    All tensors are fp32 CUDA(HIP) tensors; points are SoA (x, y, t).  Methods enqueue on the
+    current torch stream and return device tensors without synchronising.
+    """
+
+    def __init__(self, layers: Sequence[int], precision: str = "f16x3", device: Optional[torch.device] = None,
+                 max_points: int = 1 << 18, lib_path: str = DEFAULT_LIB, workspace_bytes: Optional[int] = None):
+        if not torch.cuda.is_available():
+            raise PinnLibError("HipEngine needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.lib = PinnLib(lib_path)
+        self.layers = [int(v) for v in layers]
+        self.precision = precision
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.n_params = param_count(self.layers)
+        if self.lib.supported_width(self.layers[1]) == 0:
+            raise PinnLibError(f"hidden width {self.layers[1]} is not supported by the compiled kernels")
+        want = workspace_bytes if workspace_bytes is not None else self.lib.workspace_bytes(self.layers, max_points, precision)
+        want = max(want, self.lib.min_workspace_bytes(self.layers, precision))
+        if want == 0:
+            raise PinnLibError(f"no kernel variant for layers={self.layers} precision={precision}")
+        self.ws_bytes = int(want)
+        self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
+        self._ws_ptr = (self.ws.data_ptr() + 255) // 256 * 256
+
+    # ------------------------------------------------------------------------------------------
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    @staticmethod
+    def _chk(t: torch.Tensor, n: Optional[int] = None):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous(), "expect contiguous fp32 device tensors"
+        if n is not None:
+            assert t.numel() == n, f"expected {n} elements, got {t.numel()}"
+
+    def wave_loss_grad(self, params, x, y, t, lb, ub, normalize, term_weights, E=2.5, mu=0.25, rho=1.0, plane_strain=True,
+                       grad_out: Optional[torch.Tensor] = None, accumulate: bool = False, loss_out: Optional[torch.Tensor] = None):
+        """Returns (sumsq[7] device tensor, grad_flat).  grad = d/dparams sum_i term_weights[i]*sumsq[i]."""
+        n = x.numel()
+        for v in (x, y, t):
+            self._chk(v, n)
+        self._chk(params, self.n_params)
+        if grad_out is None:
+            grad_out = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+            accumulate = False
+        if loss_out is None:
+            loss_out = torch.empty(8, dtype=torch.float32, device=self.device)
+        self.lib.wave2d_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize,
+                                  E, mu, rho, plane_strain, term_weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate,
+                                  self.precision, self._ws_ptr, self.ws_bytes, self._stream())
+        return loss_out[:7], grad_out
+
+    def wave_loss_grad_profile(self, params, x, y, t, lb, ub, normalize, term_weights, E=2.5, mu=0.25, rho=1.0, plane_strain=True):
+        """Synchronous variant returning HIP-event kernel times in ms: dict(repack, chain, wgrad, reduce)."""
+        n = x.numel()
+        grad = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        loss = torch.empty(8, dtype=torch.float32, device=self.device)
+        ms = self.lib.wave2d_loss_grad_profile(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub,
+                                               normalize, E, mu, rho, plane_strain, term_weights, loss.data_ptr(), grad.data_ptr(),
+                                               False, self.precision, self._ws_ptr, self.ws_bytes, self._stream())
+        return dict(zip(("repack", "chain", "wgrad", "reduce"), ms))
+
+    def data_loss_grad(self, params, x, y, t, lb, ub, normalize, targets, out_weights,
+                       grad_out: Optional[torch.Tensor] = None, accumulate: bool = False, loss_out: Optional[torch.Tensor] = None):
+        """Value-only terms.  targets: [n_out, n] device tensor or None.  Returns (sumsq[n_out], grad)."""
+        n = x.numel()
+        nout = self.layers[-1]
+        for v in (x, y, t):
+            self._chk(v, n)
+        self._chk(params, self.n_params)
+        tptr = 0
+        if targets is not None:
+            self._chk(targets, nout * n)
+            tptr = targets.data_ptr()
+        if grad_out is None:
+            grad_out = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+            accumulate = False
+        if loss_out is None:
+            loss_out = torch.empty(8, dtype=torch.float32, device=self.device)
+        self.lib.data_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize,
+                                tptr, out_weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate, self.precision,
+                                self._ws_ptr, self.ws_bytes, self._stream())
+        return loss_out[:nout], grad_out
+
+    def fields(self, params, x, y, t, lb, ub, normalize):
+        """Returns [4, n_out, n]: Y and its derivatives w.r.t. x, y, t."""
+        n = x.numel()
+        nout = self.layers[-1]
+        for v in (x, y, t):
+            self._chk(v, n)
+        self._chk(params, self.n_params)
+        out = torch.empty((4, nout, n), dtype=torch.float32, device=self.device)
+        self.lib.wave2d_fields(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize,
+                               out.data_ptr(), self.precision, self._ws_ptr, self.ws_bytes, self._stream())
+        return out
+
+    def adam_step(self, params, m, v, grad, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+        for a in (params, m, v, grad):
+            self._chk(a, self.n_params)
+        self.lib.adam_step(params.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(), self.n_params, lr, step, beta1, beta2, eps,
+                           self._stream())

@@ -1,0 +1,128 @@
+"""CPU tests of the host-side mirror (pinn_elastodynamics_amd/elastic_wave.py): loss layouts,
+batching order, checkpoints, L-BFGS wiring and the 2-rank data-parallel path (gloo).  The GPU
+kernels are replaced by an oracle-backed stand-in injected through the ``engine=`` argument."""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from oracle import pinn_oracle as po
+from pinn_elastodynamics_amd.elastic_wave import DeepHPM, DeepHPMConfined, pack_params, unpack_params
+from tests._oracle_engine import OracleEngine
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAYERS = [3, 16, 16, 7]
+LB, UB = [0.0, 0.0, 0.0], [30.0, 30.0, 20.0]
+
+
+def small_sets(seed=0, n=300):
+    rng = np.random.default_rng(seed)
+    Collo = po.collocation_points(n, LB, UB, rng)
+    SRC = po.ricker_source_set(n_pt=7, n_time=9)
+    IC = po.ic_grid(num=6)
+    UP = np.stack([rng.random(20) * 30, np.full(20, 30.0), rng.random(20) * 20], 1)
+    return Collo, SRC, IC, UP
+
+
+@pytest.mark.parametrize("case", ["infinite", "semi_infinite", "confined"])
+def test_loss_layout_matches_reference_formula(case):
+    Collo, SRC, IC, UP = small_sets()
+    FIX = UP.copy() if case == "confined" else None
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, case=case, FIX=FIX, engine=OracleEngine(LAYERS), verbose=False, seed=3)
+    flat = m.theta.numpy().astype(np.float64)
+    terms, grad = po.wave_total_loss_grad(flat, LAYERS, dict(collo=Collo, IC=IC, SRC=SRC, UP=UP, FIX=FIX), LB, UB,
+                                          case == "infinite", case)
+    m._loss_and_grad(0, Collo.shape[0])
+    P = m.n_params
+    tm = m._terms_from_sums(m._buf[P:].numpy().reshape(5, 8), Collo.shape[0])
+    for k in ("loss_f_uv", "loss_f_s", "loss_IC", "loss_SRC", "loss"):
+        assert abs(tm[k] - terms[k]) <= 1e-5 * max(1.0, abs(terms[k])), k
+    np.testing.assert_allclose(m._buf[:P].numpy(), grad, rtol=2e-4, atol=1e-7)
+
+
+def test_train_block_order_and_adam():
+    """batch_num blocks are contiguous and visited block-major (INF:292-303); Adam follows the TF1 rule."""
+    Collo, SRC, IC, UP = small_sets(n=301)
+    eng = OracleEngine(LAYERS)
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=eng, verbose=False, seed=5)
+    th0 = m.theta.numpy().astype(np.float64).copy()
+    out = m.train(2, 1e-3, 3)
+    assert len(out) == 5 and all(len(v) == 6 for v in out)
+    waves = [c[1] for c in eng.calls if c[0] == "wave"]
+    assert waves == [100, 100, 100, 100, 101, 101]          # int(i*N/B) boundaries, 2 iterations per block
+    # replay with the oracle
+    th, mm, vv = th0, np.zeros_like(th0), np.zeros_like(th0)
+    step = 0
+    for b in range(3):
+        s, e = int(b * 301 / 3), int((b + 1) * 301 / 3)
+        for _ in range(2):
+            _, g = po.wave_total_loss_grad(th, LAYERS, dict(collo=Collo[s:e], IC=IC, SRC=SRC), LB, UB, True, "infinite")
+            step += 1
+            th, mm, vv = po.adam_tf1_step(th, g, mm, vv, step, 1e-3)
+    np.testing.assert_allclose(m.theta.numpy(), th, rtol=1e-4, atol=1e-6)
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    Collo, SRC, IC, UP = small_sets()
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), verbose=False)
+    p = str(tmp_path / "uv_NN.pickle")
+    m.save_NN(p)
+    with open(p, "rb") as f:
+        W, b = pickle.load(f)
+    assert [w.shape for w in W] == [(3, 16), (16, 16), (16, 7)] and [x.shape for x in b] == [(1, 16), (1, 16), (1, 7)]
+    m2 = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, ExistModel=1, modelDir=p, engine=OracleEngine(LAYERS), verbose=False)
+    np.testing.assert_array_equal(m.theta.numpy(), m2.theta.numpy())
+    with pytest.raises(AssertionError):
+        DeepHPM(Collo, SRC, IC, UP, [3, 16, 16, 16, 7], LB, UB, ExistModel=1, modelDir=p, engine=OracleEngine([3, 16, 16, 16, 7]),
+                verbose=False)
+    W2, b2 = unpack_params(pack_params(W, b), LAYERS)
+    assert all(np.array_equal(a, c) for a, c in zip(W, W2))
+
+
+def test_predict_columns_and_net_f_sig():
+    Collo, SRC, IC, UP = small_sets()
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), verbose=False)
+    x, y, t = Collo[:50, 0:1], Collo[:50, 1:2], Collo[:50, 2:3]
+    u, v, s11, s22, s12, e11, e22, e12 = m.predict(x, y, t)
+    ref = po.wave2d_fields(m.theta.numpy().astype(np.float64), LAYERS, x, y, t, LB, UB, True)
+    for a, k in zip((u, v, s11, s22, s12, e11, e22, e12), ("u", "v", "s11", "s22", "s12", "e11", "e22", "e12")):
+        assert a.shape == (50, 1)
+        np.testing.assert_allclose(a[:, 0], ref[k], rtol=1e-4, atol=1e-6)
+    f = m.net_f_sig(x, y, t)
+    _, _, fo = po.wave2d_loss_grad(m.theta.numpy().astype(np.float64), LAYERS, x, y, t, LB, UB, True, want_grad=False)
+    assert len(f) == 7
+    np.testing.assert_allclose(np.concatenate(f, 1), fo, rtol=1e-3, atol=1e-5)
+
+
+def test_train_bfgs_reduces_loss():
+    Collo, SRC, IC, UP = small_sets(n=200)
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), verbose=False)
+    l0 = m.getloss()[0]
+    m.train_bfgs(1, options=dict(maxiter=15, maxfun=20))
+    assert m.count >= 2 and m.getloss()[0] < l0
+
+
+def test_confined_signature():
+    Collo, SRC, IC, UP = small_sets()
+    m = DeepHPMConfined(Collo, SRC, IC, UP, None, LAYERS, [3, 30, 5], [3, 20, 5], LB, UB, engine=OracleEngine(LAYERS), verbose=False)
+    assert m.case == "confined" and not m.normalize and "FIX" in m._sides
+
+
+def test_data_parallel_two_ranks_matches_single(tmp_path):
+    """world_size-2 gloo run: sharded sets + one all-reduce give the single-process weights."""
+    script = os.path.join(ROOT, "tests", "_dp_worker.py")
+    out = str(tmp_path / "dp.npz")
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29511")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29511", script, out], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    z = np.load(out)
+    Collo, SRC, IC, UP = small_sets(n=257)
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, case="semi_infinite", engine=OracleEngine(LAYERS), verbose=False, seed=9)
+    losses = m.train(3, 1e-3, 2)
+    np.testing.assert_allclose(z["theta0"], z["theta1"], rtol=0, atol=0)              # ranks stay bit-identical
+    np.testing.assert_allclose(z["theta0"], m.theta.numpy(), rtol=2e-5, atol=2e-7)
+    np.testing.assert_allclose(z["loss"], np.array(losses[4]), rtol=1e-4)

@@ -1,0 +1,85 @@
+"""Dev script: run the emulated library (host pointers) against the float64 oracle."""
+import sys, time, ctypes, numpy as np
+sys.path.insert(0, '/root/repo')
+from oracle import pinn_oracle as po
+from pinn_elastodynamics_amd.capi import PinnLib
+
+lib = PinnLib('/root/repo/build/emu/libpinn_emu.so')
+
+def aligned(nbytes, dtype=np.uint8):
+    raw = np.zeros(nbytes + 256, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 256
+    return raw[off:off + nbytes]
+
+def run(layers, n, prec, normalize=True, seed=0, ws_tiles=None, bias=True):
+    rng = np.random.default_rng(seed)
+    Ws, bs = po.xavier_init(layers, rng)
+    if bias: bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
+    lb = [0., 0., 0.]; ub = [30., 30., 20.]
+    X = po.collocation_points(n, lb, ub, rng)
+    flat = po.pack_params(Ws, bs)
+    tw = np.array([1, 2, 3, 1, 0.5, 1, 2.]) / n
+    ss, g, f = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, normalize, term_weights=tw)
+    p32 = flat.astype(np.float32); x = X[:, 0].astype(np.float32).copy(); y = X[:, 1].astype(np.float32).copy(); t = X[:, 2].astype(np.float32).copy()
+    wsb = lib.workspace_bytes(layers, n, prec) if ws_tiles is None else lib.min_workspace_bytes(layers, prec)
+    ws = aligned(wsb)
+    loss = np.full(8, np.nan, np.float32); grad = np.full(p32.size, np.nan, np.float32)
+    t0 = time.time()
+    lib.wave2d_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, lb, ub, normalize, 2.5, 0.25, 1.0, True, tw,
+                         loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+    dt = time.time() - t0
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    print(f'{layers[1]}x{len(layers)-2} n={n} {prec:7s}: loss rel {rel(loss[:7], ss):.2e}  grad rel {rel(grad, g):.2e}  ({dt:.1f}s) ws={wsb/1e6:.1f}MB')
+    # per-layer breakdown
+    gW, gb = po.unpack_params(grad.astype(np.float64), layers); oW, ob = po.unpack_params(g, layers)
+    print('   per-layer W rel:', ' '.join(f'{rel(a, b):.1e}' for a, b in zip(gW, oW)))
+    print('   per-layer b rel:', ' '.join(f'{rel(a, b):.1e}' for a, b in zip(gb, ob)))
+    return loss, grad, ss, g
+
+if __name__ == '__main__':
+    layers = [3] + 4 * [32] + [7]
+    run(layers, 100, 'f16x3')
+    run(layers, 100, 'bf16')
+
+def run_data(layers, n, prec, normalize=False, seed=1):
+    rng = np.random.default_rng(seed)
+    Ws, bs = po.xavier_init(layers, rng); bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
+    lb = [-15., -15., 0.]; ub = [15., 15., 16.]
+    X = np.array(lb) + (np.array(ub) - np.array(lb)) * rng.random((n, 3))
+    flat = po.pack_params(Ws, bs)
+    tgt = rng.standard_normal((n, 7)); ow = np.array([1, 1, 0, 0, 0, 2, 0.5]) / n
+    ss, g, d = po.data_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, normalize, tgt, ow)
+    p32 = flat.astype(np.float32); x, y, t = [X[:, i].astype(np.float32).copy() for i in range(3)]
+    tg = np.ascontiguousarray(tgt.T.astype(np.float32))
+    wsb = lib.workspace_bytes(layers, n, prec); ws = aligned(wsb)
+    loss = np.full(8, np.nan, np.float32); grad = np.full(p32.size, np.nan, np.float32)
+    lib.data_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, lb, ub, normalize, tg.ctypes.data, ow,
+                       loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    print(f'DATA {layers[1]}x{len(layers)-2} n={n} {prec}: loss rel {rel(loss[:7], ss):.2e} grad rel {rel(grad, g):.2e}')
+
+def run_fields(layers, n, prec, normalize=True, seed=2):
+    rng = np.random.default_rng(seed)
+    Ws, bs = po.xavier_init(layers, rng); bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
+    lb = [0., 0., 0.]; ub = [30., 30., 20.]
+    X = po.collocation_points(n, lb, ub, rng); flat = po.pack_params(Ws, bs)
+    out = po.wave2d_fields(flat, layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, normalize)
+    p32 = flat.astype(np.float32); x, y, t = [X[:, i].astype(np.float32).copy() for i in range(3)]
+    wsb = lib.workspace_bytes(layers, n, prec); ws = aligned(wsb)
+    fo = np.full((28, n), np.nan, np.float32)
+    lib.wave2d_fields(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, lb, ub, normalize, fo.ctypes.data, prec, ws.ctypes.data, wsb)
+    ref = np.concatenate([out['Y'].T] + [d.T for d in out['dY']])
+    print(f'FIELDS {layers[1]}x{len(layers)-2} n={n} {prec}: rel {np.linalg.norm(fo-ref)/np.linalg.norm(ref):.2e}')
+
+if __name__ == '__main__' and len(sys.argv) > 1:
+    run([3] + 8 * [64] + [7], 150, 'f16x3')
+    run([3] + 3 * [80] + [7], 70, 'f16x3', normalize=False)
+    run([3] + 2 * [100] + [7], 40, 'f16x3')
+    run([3] + 2 * [140] + [7], 33, 'f16x3')
+    run([3] + 1 * [20] + [7], 33, 'f16x3')
+    run([3] + 8 * [64] + [7], 2500, 'bf16x3', ws_tiles='min')
+    run([3] + 3 * [64] + [7], 64, 'f16')
+    run_data([3] + 4 * [32] + [7], 100, 'f16x3')
+    run_data([3] + 3 * [80] + [7], 50, 'bf16')
+    run_fields([3] + 4 * [32] + [7], 100, 'f16x3')
+    run_fields([3] + 2 * [100] + [7], 37, 'bf16')
