@@ -159,7 +159,7 @@ def main():
                              "achieved_tflops": FLOP_PER_PT * value / 1e12, "frac_of_mfma_peak": FLOP_PER_PT * value / 1e12 / (MFMA_PEAK_TFLOPS * world)}
         if world == 1:
             modes = {}
-            for mode in [m for m in args.extra_modes.split(",") if m and m != args.precision]:
+            for mode in [m for m in args.extra_modes.split(",") if m in ("f16x3", "bf16", "f16", "bf16x3") and m != args.precision]:
                 e2 = HipEngine(LAYERS, precision=mode, device=dev, max_points=args.chunk_points)
                 m2 = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, case="infinite", engine=e2, seed=1111, verbose=False)
                 m2.train(2, 1e-3, 1)

@@ -1,0 +1,79 @@
+"""CPU tests: the C-ABI library builds for gfx950, loads without a GPU and exports every symbol
+include/pinn_hip.h declares; argument checking that needs no device work."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from pinn_elastodynamics_amd.capi import PinnLib
+    return PinnLib()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pinn_hip.h")).read()
+    return sorted(set(re.findall(r"\b(pinn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_symbols()
+    assert "pinn_wave2d_loss_grad" in names and "pinn_adam_step" in names and len(names) >= 9
+    for n in names:
+        assert hasattr(lib.lib, n), f"{n} declared in include/pinn_hip.h but not exported"
+
+
+def test_shared_object_carries_gfx950_code():
+    blob = open(os.path.join(ROOT, "pinn_elastodynamics_amd", "lib", "libpinn_hip.so"), "rb").read()
+    assert b"gfx950" in blob and b"chain_kernel" in blob and b"wgrad_kernel" in blob
+
+
+def test_host_only_entry_points(lib):
+    assert lib.abi_version() == 1
+    assert [lib.supported_width(h) for h in (1, 32, 33, 64, 80, 100, 128, 140, 160, 161)] == [32, 32, 64, 64, 96, 128, 128, 160, 160, 0]
+    layers = [3] + 8 * [64] + [7]
+    full = lib.workspace_bytes(layers, 2_000_000, "f16x3")
+    half = lib.workspace_bytes(layers, 2_000_000, "bf16")
+    mn = lib.min_workspace_bytes(layers, "f16x3")
+    assert 0 < mn < half < full and full < 40e9
+    assert lib.workspace_bytes([3, 64, 64, 9], 100, "f16x3") == 0       # more than 8 outputs
+    assert lib.workspace_bytes([2, 64, 64, 7], 100, "f16x3") == 0       # not (x,y,t) inputs
+    assert lib.lib.pinn_error_string(-4).decode().startswith("workspace")
+
+
+def test_argument_errors_return_codes_without_touching_the_gpu(lib):
+    from pinn_elastodynamics_amd.capi import PinnLibError
+    layers = [3, 32, 32, 7]
+    with pytest.raises(PinnLibError, match="NULL"):
+        lib.wave2d_loss_grad(0, layers, 0, 0, 0, 10, [0, 0, 0], [1, 1, 1], True, 2.5, 0.25, 1.0, True, [1] * 7, 0, 0, False, "f16x3", 0, 0)
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.addressof(buf)
+    with pytest.raises(PinnLibError, match="positive"):
+        lib.wave2d_loss_grad(p, layers, p, p, p, 0, [0, 0, 0], [1, 1, 1], True, 2.5, 0.25, 1.0, True, [1] * 7, p, p, False, "f16x3", p, 64)
+    with pytest.raises(PinnLibError, match="layer"):
+        lib.wave2d_loss_grad(p, [3, 32, 48, 7], p, p, p, 10, [0, 0, 0], [1, 1, 1], True, 2.5, 0.25, 1.0, True, [1] * 7, p, p, False,
+                             "f16x3", p, 64)
+    with pytest.raises(PinnLibError, match="workspace"):
+        lib.wave2d_loss_grad(p, layers, p, p, p, 10, [0, 0, 0], [1, 1, 1], True, 2.5, 0.25, 1.0, True, [1] * 7, p, p, False, "f16x3",
+                             (p + 255) // 256 * 256, 64)
+
+
+def test_product_has_no_oracle_or_cpu_fallback():
+    """The package must not import the oracle, and the engine must refuse to run without a GPU."""
+    import torch
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "pinn_elastodynamics_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in src.replace("no oracle", ""), f"{f} mentions the oracle"
+    if not torch.cuda.is_available():
+        from pinn_elastodynamics_amd.capi import PinnLibError
+        from pinn_elastodynamics_amd.hip_engine import HipEngine
+        with pytest.raises(PinnLibError):
+            HipEngine([3, 32, 32, 7])

@@ -1,0 +1,111 @@
+"""CPU tests: the UNMODIFIED device + host sources of libpinn_hip.so, compiled for x86 against the
+host SIMT emulator (tools/emu), checked against the float64 oracle.  This validates the MFMA
+fragment index math, the spill-panel layouts, the chunked-workspace walk and the launch geometry
+without a GPU.  (The emulator is test tooling; it is not a fallback of the product.)"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import pinn_oracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LB, UB = [0.0, 0.0, 0.0], [30.0, 30.0, 20.0]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "pinn_elastodynamics_amd", "csrc"), "-j", str(min(16, os.cpu_count() or 1)), "emu"],
+                   check=True, capture_output=True)
+    from pinn_elastodynamics_amd.capi import PinnLib
+    return PinnLib(os.path.join(ROOT, "build", "emu", "libpinn_emu.so"))
+
+
+def aligned(nbytes):
+    raw = np.zeros(nbytes + 256, dtype=np.uint8)
+    off = (-raw.ctypes.data) % 256
+    return raw[off:off + nbytes]
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
+
+
+def run_wave(emu, layers, n, prec, normalize=True, min_ws=False, seed=0):
+    rng = np.random.default_rng(seed)
+    Ws, bs = po.xavier_init(layers, rng)
+    bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
+    X = po.collocation_points(n, LB, UB, rng)
+    flat = po.pack_params(Ws, bs)
+    tw = np.array([1, 2, 3, 1, 0.5, 1, 2.0]) / n
+    ss, g, _ = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, normalize, term_weights=tw)
+    p32 = flat.astype(np.float32)
+    x, y, t = (X[:, k].astype(np.float32).copy() for k in range(3))
+    wsb = emu.min_workspace_bytes(layers, prec) if min_ws else emu.workspace_bytes(layers, n, prec)
+    ws = aligned(wsb)
+    loss = np.full(8, np.nan, np.float32)
+    grad = np.full(p32.size, np.nan, np.float32)
+    emu.wave2d_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, normalize, 2.5, 0.25, 1.0, True,
+                         tw, loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+    return rel(loss[:7], ss), rel(grad, g)
+
+
+@pytest.mark.parametrize("layers,n,prec,tol", [
+    ([3] + 4 * [32] + [7], 100, "f16x3", 2e-6),        # BASELINE configs[0] net
+    ([3] + 4 * [32] + [7], 100, "bf16", 2e-2),
+    ([3] + 8 * [64] + [7], 70, "f16x3", 2e-6),         # BASELINE configs[1] net
+    ([3] + 2 * [80] + [7], 33, "f16x3", 2e-6),         # reference INF width (padded to 96, 16-point tiles)
+    ([3] + 2 * [140] + [7], 20, "f16x3", 2e-6),        # reference CONF width (padded to 160)
+])
+def test_wave_loss_grad_emulated(emu, layers, n, prec, tol):
+    e_loss, e_grad = run_wave(emu, layers, n, prec)
+    assert e_loss < tol and e_grad < tol
+
+
+def test_chunked_workspace_emulated(emu):
+    """2100 points with the minimum workspace (64 tiles of 32 points) -> two passes."""
+    e_loss, e_grad = run_wave(emu, [3] + 2 * [32] + [7], 2100, "f16x3", min_ws=True)
+    assert e_loss < 2e-6 and e_grad < 2e-6
+
+
+def test_data_term_and_fields_emulated(emu):
+    layers = [3] + 3 * [32] + [7]
+    rng = np.random.default_rng(5)
+    Ws, bs = po.xavier_init(layers, rng)
+    bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
+    n = 75
+    X = -15 + 30 * rng.random((n, 3))
+    flat = po.pack_params(Ws, bs)
+    tgt = rng.standard_normal((n, 7))
+    ow = np.array([1, 1, 0, 0, 0, 2, 0.5]) / n
+    ss, g, _ = po.data_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, False, tgt, ow)
+    p32 = flat.astype(np.float32)
+    x, y, t = (X[:, k].astype(np.float32).copy() for k in range(3))
+    tg = np.ascontiguousarray(tgt.T.astype(np.float32))
+    wsb = emu.workspace_bytes(layers, n, "f16x3")
+    ws = aligned(wsb)
+    loss = np.zeros(8, np.float32)
+    grad = np.zeros(p32.size, np.float32)
+    emu.data_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, False, tg.ctypes.data, ow,
+                       loss.ctypes.data, grad.ctypes.data, False, "f16x3", ws.ctypes.data, wsb)
+    assert rel(loss[:7], ss) < 2e-6 and rel(grad, g) < 2e-6
+    out = po.wave2d_fields(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, False)
+    fo = np.zeros((28, n), np.float32)
+    emu.wave2d_fields(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, False, fo.ctypes.data, "f16x3",
+                      ws.ctypes.data, wsb)
+    ref = np.concatenate([out["Y"].T] + [d.T for d in out["dY"]])
+    assert rel(fo, ref) < 2e-6
+
+
+def test_adam_emulated(emu):
+    rng = np.random.default_rng(6)
+    P = 1000
+    th, m, v = rng.standard_normal(P), np.zeros(P), np.zeros(P)
+    a, b, c = th.astype(np.float32), m.astype(np.float32), v.astype(np.float32)
+    for step in range(1, 4):
+        g = rng.standard_normal(P)
+        th, m, v = po.adam_tf1_step(th, g, m, v, step, 1e-3)
+        g32 = g.astype(np.float32)
+        emu.adam_step(a.ctypes.data, b.ctypes.data, c.ctypes.data, g32.ctypes.data, P, 1e-3, step)
+    assert rel(a, th) < 1e-6
