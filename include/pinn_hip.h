@@ -103,6 +103,10 @@ int pinn_wave2d_fields(const float* params_flat, const int* layers, int n_layers
 int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_flat, int64_t n_params,
                    double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 
+/* Testing hook (process-wide): 0 forces the two-kernel path (chain + wgrad kernels) even where the
+ * fused kernel applies; returns the previous setting.  Both paths compute the same numbers. */
+int pinn_debug_set_fused(int enable);
+
 const char* pinn_error_string(int code);
 int pinn_abi_version(void);
 

@@ -74,6 +74,9 @@ class PinnLib:
     def abi_version(self) -> int:
         return self.lib.pinn_abi_version()
 
+    def set_fused(self, enable: bool) -> bool:
+        return bool(self.lib.pinn_debug_set_fused(int(bool(enable))))
+
     def supported_width(self, h: int) -> int:
         return self.lib.pinn_supported_width(int(h))
 

@@ -65,9 +65,17 @@ static void input_map(const double lb[3], const double ub[3], int normalize, Cal
 
 using namespace pinn;
 
+static int g_use_fused = 1;
+
 extern "C" {
 
 int pinn_abi_version(void) { return 1; }
+
+int pinn_debug_set_fused(int enable) {
+    const int old = g_use_fused;
+    g_use_fused = enable ? 1 : 0;
+    return old;
+}
 
 int pinn_supported_width(int h) {
     if (h < 1) return 0;
@@ -117,6 +125,7 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     c.targets = nullptr;
     c.fields_out = nullptr;
     c.prof_ms = nullptr;
+    c.use_fused = g_use_fused;
     return PINN_OK;
 }
 

@@ -1,0 +1,585 @@
+// Fused loss+gradient kernel for narrow nets (padded width <= 64): forward chain, residual head,
+// reverse chain AND the weight gradient in one persistent launch.
+//
+// Versus chain_kernel + wgrad_kernel (pinn_device.hpp) nothing per-point ever goes to HBM as a
+// [feature][point] panel:
+//   * a workgroup = 8 waves in two roles (2 waves per SIMD, <= 256 registers each): waves 0-3 are
+//     CHAIN waves, each owning a 16-point tile (64 points per workgroup step); waves 4-7 are
+//     WEIGHT-GRADIENT waves, each owning one quadrant of every Wbar_l in persistent accumulators.
+//     The matrix pipe of a SIMD is shared by one wave of each role, so weight-gradient MFMAs fill
+//     the gaps the chain wave leaves while it runs the tanh / tangent VALU chain;
+//   * forward state S_l is parked in a per-wave scratch slot in FRAGMENT order (one coalesced
+//     16-byte store per lane per fragment, re-read the same way; 128 KB per wave, reused every
+//     step, so it lives in L2 / Infinity Cache rather than streaming through HBM);
+//   * for the weight gradient  Wbar_l = sum_points S_l^T Z_l  the contraction runs over points, so
+//     both operands are needed "feature per lane, points in registers" -- the transpose of the
+//     chain layout.  Every chain wave drops its S_l and Z_l tiles into LDS as [point][feature] rows
+//     (ds_write_b64) and the weight-gradient waves rebuild MFMA fragments from all four tiles with
+//     ds_read_b64_tr_b16 (semantics probed in tools/probes/tr_read_probe.hip);
+//   * the weight-gradient accumulators are PERSISTENT MFMA accumulators, written once per launch
+//     as per-workgroup partials (deterministic two-stage reduction, no atomics).
+// Addressing discipline (this kernel is unrolled over 9 weight layers, so every loop-invariant
+// address the compiler can hoist costs a VGPR for the whole launch): weights, biases and scratch
+// go through buffer descriptors with ONE lane-offset VGPR and scalar (SGPR) offsets; LDS accesses
+// use one lane-base VGPR per tensor plus compile-time immediates.
+// Two workgroup barriers per weight layer (+1 per step).
+#pragma once
+#include "pinn_device.hpp"
+
+namespace pinn {
+
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+struct FusedArgs {
+    NetDesc net;
+    PackedWeights pw;
+    unsigned frags_bytes;      // size of pw.frags
+    const float* x;
+    const float* y;
+    const float* t;
+    long n;
+    long nsteps;               // workgroup steps = ceil(n / 64)
+    float sx[3], ox[3];
+    float c1, c2, G, rho;
+    float tw[8];
+    u32x4* scratch;            // [gridDim.x * 4 chain waves][NL-1][4 streams][KS][NP][64 lanes]
+    float* loss_part;          // [gridDim.x * 4][8]
+    float* partial;            // [gridDim.x][nparams]
+};
+
+template <class Op, int SPLIT, int WIDTH, int NL>
+struct Fused {
+    static constexpr int NS = 4, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1;
+    static_assert(WB == 2 || WB == 4, "fused kernel supports padded widths 32 and 64");
+    static_assert(NL >= 2, "fused kernel needs at least two hidden layers");
+    static constexpr int IBW = WB / 2, OBW = WB / 2;          // weight-gradient wave (i,o) owns IBW x OBW blocks of every mid Wbar
+    static constexpr float INV_LS = 1.0f / Op::LO_SCALE;
+    typedef Chain<Op, SPLIT, WIDTH, 1, NS, HEAD_WAVE> CH;
+    typedef FragIndex<WIDTH> FI;
+    // LDS: per chain wave [Z tensor | S tensor]; tensor = NS*NP panels of [16 points][ROWB bytes]
+    static constexpr int ROWB = WIDTH * 2 + 8;
+    static constexpr int PANEL_B = 16 * ROWB;
+    static constexpr int TENSOR_B = NS * NP * PANEL_B;
+    static constexpr int WAVE_B = 2 * TENSOR_B;
+    static constexpr int LDS_B = 4 * WAVE_B;
+    static constexpr long SCRATCH_FRAGS = (long)(NL - 1) * NS * KS * NP;     // u32x4[64] units per chain wave
+    static constexpr unsigned SCRATCH_BYTES = (unsigned)(SCRATCH_FRAGS * 1024);
+
+    struct Acc {                       // persistent across the whole launch, all statically indexed
+        f32x4 mid[NL - 1][IBW][OBW];
+        f32x4 first;                   // Wbar_0 block (in-block 0, out-block = quad) if quad < WB
+        f32x4 last;                    // Wbar_NL block (in-block = quad, out-block 0) if quad < WB
+        float bias[NL + 1];
+    };
+
+    // ---------------------------------------------------------------------------------------------
+    // weight-gradient role
+    // ---------------------------------------------------------------------------------------------
+    // MFMA fragment "16-feature block at byte column `off` of stream/part panel, 32 points of one k-step" rebuilt from the
+    // chain waves' [point][feature] rows.  k-slot (q, e) <-> chain wave 2j + (q>>1), local point 8(q&1) + e (same map for both
+    // operands); the lane-dependent part of the address lives in `base`, everything else is an immediate.
+    static __device__ __forceinline__ u32x4 get_frag(const char* base, int off) {
+        const v4i16 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(base + off));
+        const v4i16 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(base + off + 4 * ROWB));
+        const u32x2 d0 = __builtin_bit_cast(u32x2, v0), d1 = __builtin_bit_cast(u32x2, v1);
+        return u32x4{d0[0], d0[1], d1[0], d1[1]};
+    }
+
+    // NA x NBK blocks of one weight gradient:  acc[a][b] += sum over 64 points, 4 streams of  S(block fa+a)^T . Z(block fb+b).
+    // Operand fragments are fetched once per (k-step, stream) and shared by the NA*NBK blocks; a scheduling fence after every
+    // group keeps the compiler from hoisting all transpose-reads of a layer ahead of the MFMAs.
+    // sbase/zbase: lane base of the S / Z tensor of chain wave 0 (+ 32 bytes per feature block already added by the caller).
+    template <int NA, int NBK>
+    static __device__ __forceinline__ void wg_blocks(const char* sbase, const char* zbase, f32x4 (&acc)[NA][NBK], float (&bias_out)[NBK]) {
+        f32x4 cc[NA][NBK], bm[NBK], bc[NBK];
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) {
+            bm[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            bc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int a = 0; a < NA; ++a) cc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const uint32_t one2 = pack2<Op>(1.0f, 1.0f);
+        const u32x4 ones = {one2, one2, one2, one2};
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                u32x4 Ah[NA], Al[NA], Bh[NBK], Bl[NBK];
+#pragma unroll
+                for (int a = 0; a < NA; ++a) {
+                    Ah[a] = get_frag(sbase, 2 * j * WAVE_B + (s * NP) * PANEL_B + 32 * a);
+                    if (NP == 2) Al[a] = get_frag(sbase, 2 * j * WAVE_B + (s * NP + 1) * PANEL_B + 32 * a);
+                }
+#pragma unroll
+                for (int b = 0; b < NBK; ++b) {
+                    Bh[b] = get_frag(zbase, 2 * j * WAVE_B + (s * NP) * PANEL_B + 32 * b);
+                    if (NP == 2) Bl[b] = get_frag(zbase, 2 * j * WAVE_B + (s * NP + 1) * PANEL_B + 32 * b);
+                }
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int b = 0; b < NBK; ++b) {
+                        acc[a][b] = Op::mfma(Ah[a], Bh[b], acc[a][b]);
+                        if (NP == 2) {
+                            cc[a][b] = Op::mfma(Ah[a], Bl[b], cc[a][b]);
+                            cc[a][b] = Op::mfma(Al[a], Bh[b], cc[a][b]);
+                        }
+                    }
+                if (s == 0) {                   // bias gradient = ones^T . Z (value stream)
+#pragma unroll
+                    for (int b = 0; b < NBK; ++b) {
+                        bm[b] = Op::mfma(ones, Bh[b], bm[b]);
+                        if (NP == 2) bc[b] = Op::mfma(ones, Bl[b], bc[b]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) {
+            bias_out[b] = NP == 2 ? bm[b][0] + bc[b][0] * INV_LS : bm[b][0];
+            if (NP == 2) {
+#pragma unroll
+                for (int a = 0; a < NA; ++a)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[a][b][r] += cc[a][b][r] * INV_LS;
+            }
+        }
+    }
+
+    // weight gradient of weight layer L (quad = weight-gradient wave index 0..3); lanebase = LDS base + lane part of the address
+    template <int L>
+    static __device__ __forceinline__ void wgrad(const char* lanebase, Acc& A, int quad) {
+        const char* zl = lanebase;                  // Z tensor of chain wave 0
+        const char* sl = lanebase + TENSOR_B;       // S tensor of chain wave 0
+        const int wi = quad >> 1, wo = quad & 1;
+        if constexpr (L == 0) {
+            if (quad < WB) {
+                f32x4 t[1][1] = {{A.first}};
+                float b[1];
+                wg_blocks<1, 1>(sl, zl + 32 * quad, t, b);
+                A.first = t[0][0];
+                A.bias[0] += b[0];
+            }
+        } else if constexpr (L == NL) {
+            if (quad < WB) {
+                f32x4 t[1][1] = {{A.last}};
+                float b[1];
+                wg_blocks<1, 1>(sl + 32 * quad, zl, t, b);
+                A.last = t[0][0];
+                if (quad == 0) A.bias[NL] += b[0];
+            }
+        } else {
+            float b[OBW];
+            wg_blocks<IBW, OBW>(sl + 32 * (wi * IBW), zl + 32 * (wo * OBW), A.mid[L - 1], b);
+            // one bias block per wave per layer: out-block wo*OBW + wi (OBW == 2) or wo (OBW == 1, waves with wi == 0)
+            if (OBW == 1) { if (wi == 0) A.bias[L] += b[0]; }
+            else A.bias[L] += wi ? b[OBW - 1] : b[0];
+        }
+    }
+
+    template <int L>
+    struct WgDown {     // same barrier sequence as the chain role's Down<>
+        static __device__ __forceinline__ void run(const char* lanebase, Acc& A, int quad) {
+            __syncthreads();                                   // (chain waves now overwrite the tensors)
+            __syncthreads();                                   // tensors of layer L are complete
+            wgrad<L>(lanebase, A, quad);
+            if constexpr (L >= 1) WgDown<L - 1>::run(lanebase, A, quad);
+        }
+    };
+
+    static __device__ __forceinline__ void wgrad_role(const FusedArgs& a, const char* lds, int quad, int c, int q) {
+        Acc A;
+#pragma unroll
+        for (int l = 0; l < NL - 1; ++l)
+#pragma unroll
+            for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                for (int o = 0; o < OBW; ++o) A.mid[l][i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        A.first = f32x4{0.f, 0.f, 0.f, 0.f};
+        A.last = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
+        const char* lanebase = lds + (q >> 1) * WAVE_B + (8 * (q & 1) + (c >> 2)) * ROWB + 8 * (c & 3);
+        for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
+            __syncthreads();                                   // step start (chain waves reuse their S rows during the forward)
+            WgDown<NL>::run(lanebase, A, quad);
+        }
+        // ---- write this workgroup's partial gradient
+        float* part = a.partial + (long)blockIdx.x * a.net.nparams;
+        const int H = a.net.h, NO = a.net.nout, wi = quad >> 1, wo = quad & 1;
+        auto put_block = [&](const f32x4& v, int l, int ib, int ob, int n_in, int n_out) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int in = 16 * ib + 4 * q + r, out = 16 * ob + c;
+                if (in < n_in && out < n_out) part[a.net.w_off[l] + in * n_out + out] = v[r];
+            }
+        };
+        if (quad < WB) {
+            put_block(A.first, 0, 0, quad, 3, H);
+            put_block(A.last, NL, quad, 0, H, NO);
+            if (q == 0 && 16 * quad + c < H) part[a.net.b_off[0] + 16 * quad + c] = A.bias[0];
+        }
+        if (quad == 0 && q == 0 && c < NO) part[a.net.b_off[NL] + c] = A.bias[NL];
+#pragma unroll
+        for (int l = 1; l < NL; ++l) {
+#pragma unroll
+            for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                for (int o = 0; o < OBW; ++o) put_block(A.mid[l - 1][i][o], l, wi * IBW + i, wo * OBW + o, H, H);
+            const bool owner = OBW == 1 ? wi == 0 : true;
+            const int ob = wo * OBW + (OBW == 1 ? 0 : wi);
+            if (owner && q == 0 && 16 * ob + c < H) part[a.net.b_off[l] + 16 * ob + c] = A.bias[l];
+        }
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // chain role
+    // ---------------------------------------------------------------------------------------------
+    struct Ctx {                                   // wave-invariant addressing state of a chain wave
+        __amdgpu_buffer_rsrc_t frags, scr, bias, w0p;
+        unsigned lane16;                           // lane * 16: the only VGPR offset of the fragment / scratch traffic
+        char* rowZ;                                // this lane's row base in the wave's Z tensor: + c*ROWB + 8q
+        char* rowS;
+        int c, q;
+    };
+
+    // chain-layout fragments -> [point][feature] rows of this wave's LDS tensor (row = lane's point, 8 bytes per feature block)
+    template <int KSF, int NMB>     // NMB = 16-feature blocks actually present (WB for states/adjoints, 1 for inputs/outputs)
+    static __device__ __forceinline__ void put_tensor(char* row, const u32x4 (&F)[NS][1][KSF][NP]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb) {
+                    u32x2 v = {F[s][0][mb >> 1][p][(mb & 1) * 2 + 0], F[s][0][mb >> 1][p][(mb & 1) * 2 + 1]};
+                    *reinterpret_cast<u32x2*>(row + (s * NP + p) * PANEL_B + 32 * mb) = v;
+                }
+    }
+
+    // state (h, hdot_k) of feature block MB of this wave's own points, read back from its LDS S rows
+    template <int MB>
+    static __device__ __forceinline__ void state_from_lds(const char* rowS, float (&st)[NS][1][4]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const u32x2 h = *reinterpret_cast<const u32x2*>(rowS + (s * NP) * PANEL_B + 32 * MB);
+            u32x2 l = {0u, 0u};
+            if (NP == 2) l = *reinterpret_cast<const u32x2*>(rowS + (s * NP + 1) * PANEL_B + 32 * MB);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                float v0 = cvt16<Op>((uint16_t)(h[d] & 0xffffu)), v1 = cvt16<Op>((uint16_t)(h[d] >> 16));
+                if (NP == 2) {
+                    v0 += cvt16<Op>((uint16_t)(l[d] & 0xffffu)) * INV_LS;
+                    v1 += cvt16<Op>((uint16_t)(l[d] >> 16)) * INV_LS;
+                }
+                st[s][0][2 * d + 0] = v0;
+                st[s][0][2 * d + 1] = v1;
+            }
+        }
+    }
+
+    template <int KSB>
+    static __device__ __forceinline__ void load_afrags(const Ctx& x, int frag0, u32x4 (&Af)[KSB][NP]) {
+#pragma unroll
+        for (int kk = 0; kk < KSB; ++kk)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Af[kk][p] = __builtin_amdgcn_raw_buffer_load_b128(x.frags, x.lane16, ((frag0 + kk) * NP + p) * 1024, 0);
+    }
+    template <int KSB>
+    static __device__ __forceinline__ void gemm_pre(const u32x4 (&Af)[KSB][NP], const u32x4 (&B)[NS][1][KSB][NP], f32x4 (&acc)[NS][1],
+                                                    f32x4 (&accc)[NS][1]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            f32x4 m = {0.f, 0.f, 0.f, 0.f}, cc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < KSB; ++kk) {
+                m = Op::mfma(Af[kk][0], B[s][0][kk][0], m);
+                if (NP == 2) {
+                    cc = Op::mfma(Af[kk][0], B[s][0][kk][1], cc);
+                    cc = Op::mfma(Af[kk][1], B[s][0][kk][0], cc);
+                }
+            }
+            acc[s][0] = m;
+            accc[s][0] = cc;
+        }
+    }
+
+    // forward first layer (K = 3, VALU): INF:191-195 with the tangent seeds e_k * sx_k
+    template <int MB>
+    static __device__ __forceinline__ void first_mb(const FusedArgs& a, const Ctx& x, const float (&xin)[3], u32x4 (&Bn)[NS][1][KS][NP]) {
+        float vals[NS][1][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const u32x4 wu = __builtin_amdgcn_raw_buffer_load_b128(x.w0p, (unsigned)x.q * 64u, (16 * MB + r) * 16, 0);
+            const f32x4 w = __builtin_bit_cast(f32x4, wu);
+            float h, sd;
+            tanh_act(w[3] + w[0] * xin[0] + w[1] * xin[1] + w[2] * xin[2], h, sd);
+            vals[0][0][r] = h;
+#pragma unroll
+            for (int s = 1; s < NS; ++s) vals[s][0][r] = sd * (a.sx[s - 1] * w[s - 1]);
+        }
+        CH::template emit<KS, MB>(Bn, vals, nullptr, WIDTH, x.c, x.q);
+        if constexpr (MB + 1 < WB) first_mb<MB + 1>(a, x, xin, Bn);
+    }
+
+    // forward hidden layer, one 16-feature block per step; the next block's weight fragments are in flight while this
+    // block's MFMAs and tanh chain run
+    template <int MB>
+    static __device__ __forceinline__ void fwd_mb(const Ctx& x, int frag0, int bias_off, const u32x4 (&Af)[KS][NP],
+                                                  const u32x4 (&B)[NS][1][KS][NP], u32x4 (&Bn)[NS][1][KS][NP]) {
+        u32x4 An[KS][NP];
+        if constexpr (MB + 1 < WB) load_afrags<KS>(x, frag0 + (MB + 1) * KS, An);
+        const u32x4 bu = __builtin_amdgcn_raw_buffer_load_b128(x.bias, (unsigned)x.q * 16u, bias_off + 16 * MB * 4, 0);
+        const f32x4 bias = __builtin_bit_cast(f32x4, bu);
+        f32x4 acc[NS][1], accc[NS][1];
+        gemm_pre<KS>(Af, B, acc, accc);
+        float vals[NS][1][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float h, sd;
+            tanh_act(CH::comb(acc[0][0], accc[0][0], r) + bias[r], h, sd);
+            vals[0][0][r] = h;
+#pragma unroll
+            for (int s = 1; s < NS; ++s) vals[s][0][r] = sd * CH::comb(acc[s][0], accc[s][0], r);
+        }
+        CH::template emit<KS, MB>(Bn, vals, nullptr, WIDTH, x.c, x.q);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MB + 1 < WB) fwd_mb<MB + 1>(x, frag0, bias_off, An, B, Bn);
+    }
+
+    // reverse through a weight layer (KSB k-steps of its outputs) + the activation below; state from the wave's LDS rows
+    template <int MB, int KSB>
+    static __device__ __forceinline__ void bwd_mb(const Ctx& x, int frag0, const u32x4 (&Af)[KSB][NP], const u32x4 (&Zf)[NS][1][KSB][NP],
+                                                  u32x4 (&Zn)[NS][1][KS][NP]) {
+        u32x4 An[KSB][NP];
+        if constexpr (MB + 1 < WB) load_afrags<KSB>(x, frag0 + (MB + 1) * KSB, An);
+        f32x4 acc[NS][1], accc[NS][1];
+        gemm_pre<KSB>(Af, Zf, acc, accc);
+        float st[NS][1][4], vals[NS][1][4];
+        state_from_lds<MB>(x.rowS, st);
+        CH::act_bwd(st, acc, accc, vals);
+        CH::template emit<KS, MB>(Zn, vals, nullptr, WIDTH, x.c, x.q);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MB + 1 < WB) bwd_mb<MB + 1, KSB>(x, frag0, An, Zf, Zn);
+    }
+
+    // parked state S_l (fragment order in the per-wave scratch) -> this wave's LDS S rows, a fragment at a time
+    static __device__ __forceinline__ void scratch_to_lds(const Ctx& x, int l /*1..NL-1*/) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x.scr, x.lane16, ((((l - 1) * NS + s) * KS + kk) * NP + p) * 1024, 0);
+                    char* row = x.rowS + (s * NP + p) * PANEL_B;
+                    *reinterpret_cast<u32x2*>(row + 32 * (2 * kk)) = u32x2{f[0], f[1]};
+                    if (2 * kk + 1 < WB) *reinterpret_cast<u32x2*>(row + 32 * (2 * kk + 1)) = u32x2{f[2], f[3]};
+                }
+    }
+    static __device__ __forceinline__ void store_state(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][p], x.scr, x.lane16, ((((l - 1) * NS + s) * KS + kk) * NP + p) * 1024, 0);
+    }
+
+    // Weight layers L = NL-1 .. 1 (hidden-to-hidden) and finally L = 0, fully unrolled (static fragment indices / offsets).
+    template <int L>
+    struct Down {
+        // entry: Zc = Z_L (adjoint of weight layer L's pre-activation) in chain fragment order
+        static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&Zc)[NS][1][KS][NP]) {
+            __syncthreads();                                   // previous layer's fragment reads are done
+            put_tensor<KS, WB>(x.rowZ, Zc);
+            if constexpr (L >= 1) {
+                scratch_to_lds(x, L);
+            } else {
+                // S_0: the inputs as a 16-feature tensor (rows 0..2 = x', tangent stream k carries sx_k in row k)
+                float v0[NS][1][4];
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = 0.0f;
+                        if (x.q == 0 && r < 3) v = (s == 0) ? xin[r] : (r == s - 1 ? a.sx[r] : 0.0f);
+                        v0[s][0][r] = v;
+                    }
+                u32x4 S0[NS][1][1][NP];
+                CH::template emit<1, 0>(S0, v0, nullptr, 16, x.c, x.q);
+                put_tensor<1, 1>(x.rowS, S0);
+            }
+            __syncthreads();                                   // tensors visible to the weight-gradient waves
+            if constexpr (L >= 1) {
+                // reverse through W_L and the activation that produced S_L -> Z_{L-1}
+                u32x4 Zn[NS][1][KS][NP];
+                {
+                    const int frag0 = FI::bwd_mid(NL, L, 0, 0);
+                    u32x4 A0[KS][NP];
+                    load_afrags<KS>(x, frag0, A0);
+                    bwd_mb<0, KS>(x, frag0, A0, Zc, Zn);
+                }
+                Down<L - 1>::run(a, x, xin, Zn);
+            }
+        }
+    };
+
+    static __device__ __forceinline__ void chain_role(const FusedArgs& a, char* lds, int wave, int lane, int c, int q) {
+        const long gwave = (long)blockIdx.x * 4 + wave;
+        Ctx x;
+        x.frags = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.frags, 0, (int)a.frags_bytes, 0x00020000);
+        x.scr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.scratch + gwave * SCRATCH_FRAGS * 64), 0, (int)SCRATCH_BYTES, 0x00020000);
+        x.bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.bias_mid, 0, (NL - 1) * WIDTH * 4, 0x00020000);
+        x.w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * 16, 0x00020000);
+        x.lane16 = (unsigned)lane * 16u;
+        x.rowZ = lds + wave * WAVE_B + c * ROWB + 8 * q;
+        x.rowS = x.rowZ + TENSOR_B;
+        x.c = c;
+        x.q = q;
+        float lsum[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) lsum[i] = 0.0f;
+
+        for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
+            float xin[3];
+            const long p = (step * 4 + wave) * 16 + c;
+            const bool valid = p < a.n;
+            const long pidx = valid ? p : a.n - 1;
+            xin[0] = a.x[pidx] * a.sx[0] + a.ox[0];
+            xin[1] = a.y[pidx] * a.sx[1] + a.ox[1];
+            xin[2] = a.t[pidx] * a.sx[2] + a.ox[2];
+            __syncthreads();                                   // step start: last step's weight-gradient reads are done
+            // ---- forward (same arithmetic as chain_kernel), state parked in fragment order
+            u32x4 B[NS][1][KS][NP];
+            first_mb<0>(a, x, xin, B);
+            store_state(x, 1, B);
+            for (int l = 1; l < NL; ++l) {
+                u32x4 Bn[NS][1][KS][NP];
+                {
+                    const int frag0 = FI::fwd_mid(l, 0, 0);
+                    u32x4 A0[KS][NP];
+                    load_afrags<KS>(x, frag0, A0);
+                    fwd_mb<0>(x, frag0, (l - 1) * WIDTH * 4, A0, B, Bn);
+                }
+                if (l + 1 < NL) store_state(x, l + 1, Bn);      // S_NL stays in registers
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                        for (int pp = 0; pp < NP; ++pp) B[s][0][kk][pp] = Bn[s][0][kk][pp];
+            }
+            // ---- output layer + residual head (net_f_sig INF:221-265)
+            f32x4 yacc[NS][1], yaccc[NS][1];
+            {
+                u32x4 A0[KS][NP];
+                load_afrags<KS>(x, FI::fwd_last(NL, 0), A0);
+                gemm_pre<KS>(A0, B, yacc, yaccc);
+            }
+            const f32x4 bl = *reinterpret_cast<const f32x4*>(a.pw.bias_last + 4 * q);
+            float Y[NS][8];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float own = CH::comb(yacc[s][0], yaccc[s][0], r) + (s == 0 ? bl[r] : 0.0f);
+                    const float oth = __shfl_xor(own, 16);
+                    Y[s][r] = (q & 1) ? oth : own;
+                    Y[s][4 + r] = (q & 1) ? own : oth;
+                }
+            const float vm = valid ? 1.0f : 0.0f;
+            const float e11 = Y[1][0], e22 = Y[2][1], e12 = Y[2][0] + Y[1][1];
+            float f[7];
+            f[0] = Y[1][4] + Y[2][6] - a.rho * Y[3][2];
+            f[1] = Y[2][5] + Y[1][6] - a.rho * Y[3][3];
+            f[2] = Y[3][0] - Y[0][2];
+            f[3] = Y[3][1] - Y[0][3];
+            f[4] = Y[0][4] - (a.c1 * e11 + a.c2 * e22);
+            f[5] = Y[0][5] - (a.c2 * e11 + a.c1 * e22);
+            f[6] = Y[0][6] - a.G * e12;
+            float g[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                if (q == 0) lsum[i] += vm * f[i] * f[i];
+                g[i] = 2.0f * a.tw[i] * f[i] * vm;
+            }
+            float adj[NS][8];
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int o = 0; o < 8; ++o) adj[s][o] = 0.0f;
+            adj[0][2] = -g[2];
+            adj[0][3] = -g[3];
+            adj[0][4] = g[4];
+            adj[0][5] = g[5];
+            adj[0][6] = g[6];
+            adj[1][0] = -a.c1 * g[4] - a.c2 * g[5];
+            adj[1][1] = -a.G * g[6];
+            adj[1][4] = g[0];
+            adj[1][6] = g[1];
+            adj[2][0] = -a.G * g[6];
+            adj[2][1] = -a.c2 * g[4] - a.c1 * g[5];
+            adj[2][5] = g[1];
+            adj[2][6] = g[0];
+            adj[3][0] = g[2];
+            adj[3][1] = g[3];
+            adj[3][2] = -a.rho * g[0];
+            adj[3][3] = -a.rho * g[1];
+            u32x4 ZL[NS][1][1][NP];
+            {
+                float vals[NS][1][4];
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) vals[s][0][r] = q < 2 ? ((q & 1) ? adj[s][4 + r] : adj[s][r]) : 0.0f;
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp) ZL[s][0][0][pp] = u32x4{0u, 0u, 0u, 0u};
+                CH::template emit<1, 0>(ZL, vals, nullptr, 16, c, q);
+            }
+            // ---- top weight layer NL: hand Z_NL (16 outputs) and S_NL over, then reverse into the hidden chain
+            __syncthreads();
+            put_tensor<1, 1>(x.rowZ, ZL);
+            put_tensor<KS, WB>(x.rowS, B);                // B still holds S_NL
+            __syncthreads();
+            u32x4 Zn[NS][1][KS][NP];
+            {
+                const int frag0 = FI::bwd_last(NL, 0);
+                u32x4 A0[1][NP];
+                load_afrags<1>(x, frag0, A0);
+                bwd_mb<0, 1>(x, frag0, A0, ZL, Zn);
+            }
+            Down<NL - 1>::run(a, x, xin, Zn);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float v = lsum[i];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            if (lane == 0) a.loss_part[gwave * 8 + i] = v;
+        }
+    }
+
+    static __device__ void run(const FusedArgs& a) {
+        __shared__ __attribute__((aligned(16))) char lds[LDS_B];
+        const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
+        const int wave8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // provably wave-uniform
+        if (wave8 >= 4) wgrad_role(a, lds, wave8 - 4, c, q);
+        else chain_role(a, lds, wave8, lane, c, q);
+    }
+};
+
+template <class Op, int SPLIT, int WIDTH, int NL>
+__global__ __launch_bounds__(512) void fused_wave_kernel(const FusedArgs a) {
+    Fused<Op, SPLIT, WIDTH, NL>::run(a);
+}
+
+}  // namespace pinn

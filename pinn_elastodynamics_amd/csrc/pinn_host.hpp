@@ -8,6 +8,7 @@
 
 #include "../../include/pinn_hip.h"
 #include "pinn_device.hpp"
+#include "pinn_fused.hpp"
 
 namespace pinn {
 
@@ -34,6 +35,7 @@ struct Call {
     float* fields_out;
     // optional per-kernel timing (host pointer, 4 floats: repack, chain, wgrad, reductions) -- makes the call synchronous
     float* prof_ms;
+    int use_fused;             // 1: prefer the fused kernel where it applies (default), 0: force the two-kernel path
 };
 
 struct Impl {
@@ -51,6 +53,7 @@ struct Host {
     static constexpr int NP = SPLIT == 3 ? 2 : 1;
     static constexpr int TP = 16 * NB;
     static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
+    static constexpr int FUSED_GRID = 256;    // persistent workgroups of the fused kernel (one per MI355X CU)
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
     static constexpr long MIN_TILES = 64;
     typedef FragIndex<WIDTH> FI;
@@ -77,7 +80,7 @@ struct Host {
         p.loss_part = o;
         o = align_up(o + (size_t)MAX_BLOCKS * 4 * 8 * sizeof(float), 256);
         p.partial = o;
-        o = align_up(o + (size_t)NCHUNK * net.nparams * sizeof(float), 256);
+        o = align_up(o + (size_t)(NCHUNK > FUSED_GRID ? NCHUNK : FUSED_GRID) * net.nparams * sizeof(float), 256);
         p.panels = o;
         p.fixed_end = o;
         p.s_tile = PG::s_tile(net.nl);
@@ -234,7 +237,81 @@ struct Host {
         return rc;
     }
 
-    static int wave_loss_grad(const Call& c) { return loss_grad<4, HEAD_WAVE>(c, 7); }
+    // fused path (pinn_fused.hpp): padded width <= 64 and a compiled depth; needs the per-wave state scratch in the workspace
+    template <int NL>
+    static int fused_launch(const Call& c, const Plan& p, int grid) {
+        if constexpr (WIDTH <= 64) {
+            typedef Fused<Op, SPLIT, WIDTH, NL> F;
+            int rc = repack(c, p);
+            if (rc) return rc;
+            float twmax = 0.0f;
+            for (int i = 0; i < 8; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
+            char* b = static_cast<char*>(c.ws);
+            FusedArgs a;
+            a.net = c.net;
+            a.pw = packed(c, p);
+            a.frags_bytes = (unsigned)((size_t)FI::total(c.net.nl) * NP * 64 * sizeof(u32x4));
+            a.x = c.x;
+            a.y = c.y;
+            a.t = c.t;
+            a.n = c.n;
+            a.nsteps = (c.n + 63) / 64;
+            for (int k = 0; k < 3; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
+            a.c1 = c.c1;
+            a.c2 = c.c2;
+            a.G = c.G;
+            a.rho = c.rho;
+            for (int i = 0; i < 8; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
+            a.scratch = reinterpret_cast<u32x4*>(b + p.panels);
+            a.loss_part = reinterpret_cast<float*>(b + p.loss_part);
+            a.partial = reinterpret_cast<float*>(b + p.partial);
+            hipEvent_t ev[2] = {nullptr, nullptr};
+            if (c.prof_ms) { hipEventCreate(&ev[0]); hipEventCreate(&ev[1]); hipEventRecord(ev[0], c.stream); }
+            hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL>), dim3(grid), dim3(512), 0, c.stream, a);
+            if ((rc = (int)hipGetLastError())) return rc;
+            if (c.prof_ms) {
+                hipEventRecord(ev[1], c.stream);
+                hipEventSynchronize(ev[1]);
+                c.prof_ms[0] = c.prof_ms[2] = c.prof_ms[3] = 0.f;
+                hipEventElapsedTime(&c.prof_ms[1], ev[0], ev[1]);
+                hipEventDestroy(ev[0]);
+                hipEventDestroy(ev[1]);
+            }
+            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(64), 0, c.stream, (const float*)a.loss_part, (long)grid * 4, 7, c.loss_out, 0);
+            if ((rc = (int)hipGetLastError())) return rc;
+            hipLaunchKernelGGL((reduce_grad_kernel<0>), dim3((c.net.nparams + 255) / 256), dim3(256), 0, c.stream, (const float*)a.partial,
+                               grid, c.net.nparams, twmax, c.grad_out, c.accumulate);
+            return (int)hipGetLastError();
+        } else {
+            return PINN_ERR_LAYERS;
+        }
+    }
+
+    // returns 1 if the fused path ran (rc in *out), 0 if it does not apply
+    static int try_fused(const Call& c, int* out) {
+        if constexpr (WIDTH <= 64) {
+            if (c.net.nl != 4 && c.net.nl != 8) return 0;
+            Plan p;
+            if (((uintptr_t)c.ws & 255) != 0) return 0;
+            plan_fixed<4>(c.net, c.n, p);
+            const size_t per_wg = (size_t)4 * (c.net.nl - 1) * 4 * FI::KS * NP * 64 * sizeof(u32x4);
+            if (c.ws_bytes < p.fixed_end + per_wg) return 0;
+            long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
+            if (grid > FUSED_GRID) grid = FUSED_GRID;
+            const long nsteps = (c.n + 63) / 64;
+            if (grid > nsteps) grid = nsteps;
+            *out = c.net.nl == 4 ? fused_launch<4>(c, p, (int)grid) : fused_launch<8>(c, p, (int)grid);
+            return 1;
+        } else {
+            return 0;
+        }
+    }
+
+    static int wave_loss_grad(const Call& c) {
+        int rc = 0;
+        if (c.use_fused && try_fused(c, &rc)) return rc;
+        return loss_grad<4, HEAD_WAVE>(c, 7);
+    }
     static int data_loss_grad(const Call& c) { return loss_grad<1, HEAD_DATA>(c, c.net.nout); }
 
     static int fields(const Call& c) {

@@ -176,6 +176,36 @@ inline emu_f32x4 __builtin_amdgcn_mfma_f32_16x16x4f32(float a, float b, emu_f32x
     return d;
 }
 
+// LDS transpose read (gfx950 ds_read_b64_tr_b16), semantics measured with tools/probes/tr_read_probe.hip:
+// within each 16-lane group, out[lane c][e] = in[lane 4e + (c>>2)][c & 3], in[i][.] = the four 16-bit values at lane i's address.
+typedef short emu_v4i16 __attribute__((ext_vector_type(4)));
+inline emu_v4i16 __builtin_amdgcn_ds_read_tr16_b64_v4i16(__attribute__((address_space(3))) emu_v4i16* p) {
+    const short* mine = reinterpret_cast<const short*>(reinterpret_cast<uintptr_t>(p));
+    emu::cur_lane().xchg[0] = mine;
+    emu::wave_sync();
+    const int l = emu::lane_id(), g = l & ~15, c = l & 15;
+    emu_v4i16 r;
+    for (int e = 0; e < 4; ++e) r[e] = static_cast<const short*>(emu::wave_lane(g + 4 * e + (c >> 2)).xchg[0])[c & 3];
+    emu::wave_sync();
+    return r;
+}
+
+// buffer descriptors (raw, byte-addressed): base + per-lane voffset + wave-uniform soffset
+struct emu_buffer_rsrc { char* base; unsigned bytes; };
+#define __amdgpu_buffer_rsrc_t emu_buffer_rsrc
+typedef unsigned int emu_u32x4 __attribute__((ext_vector_type(4)));
+inline emu_buffer_rsrc __builtin_amdgcn_make_buffer_rsrc(void* p, short, int num_bytes, int) { return emu_buffer_rsrc{static_cast<char*>(p), (unsigned)num_bytes}; }
+inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
+    if (voff + soff + 16u > r.bytes) { fprintf(stderr, "emu: buffer load out of range (%u + %u > %u)\n", voff, soff, r.bytes); abort(); }
+    emu_u32x4 v;
+    memcpy(&v, r.base + voff + soff, 16);
+    return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
+    if (voff + soff + 16u > r.bytes) { fprintf(stderr, "emu: buffer store out of range (%u + %u > %u)\n", voff, soff, r.bytes); abort(); }
+    memcpy(r.base + voff + soff, &v, 16);
+}
+
 // ---- scalar math builtins ---------------------------------------------------------------------
 inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }

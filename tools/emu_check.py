@@ -83,3 +83,13 @@ if __name__ == '__main__' and len(sys.argv) > 1:
     run_data([3] + 3 * [80] + [7], 50, 'bf16')
     run_fields([3] + 4 * [32] + [7], 100, 'f16x3')
     run_fields([3] + 2 * [100] + [7], 37, 'bf16')
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] == 'fused':
+    for fused in (True, False):
+        lib.set_fused(fused)
+        print('fused =', fused)
+        run([3] + 4 * [32] + [7], 130, 'f16x3')
+        run([3] + 4 * [32] + [7], 130, 'bf16')
+        run([3] + 8 * [64] + [7], 200, 'f16x3')
+        run([3] + 4 * [64] + [7], 64, 'f16x3', normalize=False)
+        run([3] + 8 * [40] + [7], 77, 'bf16x3' if False else 'f16x3')
