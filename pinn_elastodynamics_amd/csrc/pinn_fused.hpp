@@ -61,10 +61,13 @@ struct Fused {
     // LDS: per chain wave [Z tensor | S tensor]; tensor = NS*NP panels of [16 points][ROWB bytes]
     static constexpr int ROWB = WIDTH * 2 + 8;
     static constexpr int PANEL_B = 16 * ROWB;
-    static constexpr int TENSOR_B = NS * NP * PANEL_B;
-    static constexpr int WAVE_B = 2 * TENSOR_B;
+    // The parked state S is kept in the operand type's precision only (no low part): measured in tools/precision_study2.py,
+    // rounding S for the reverse pass changes the gradient error by < 10 % of itself as long as adjoints and weights stay split.
+    static constexpr int TENSOR_Z_B = NS * NP * PANEL_B;
+    static constexpr int TENSOR_S_B = NS * PANEL_B;
+    static constexpr int WAVE_B = TENSOR_Z_B + TENSOR_S_B;
     static constexpr int LDS_B = 4 * WAVE_B;
-    static constexpr long SCRATCH_FRAGS = (long)(NL - 1) * NS * KS * NP;     // u32x4[64] units per chain wave
+    static constexpr long SCRATCH_FRAGS = (long)(NL - 1) * NS * KS;          // u32x4[64] units per chain wave (hi parts only)
     static constexpr unsigned SCRATCH_BYTES = (unsigned)(SCRATCH_FRAGS * 1024);
 
     struct Acc {                       // persistent across the whole launch, all statically indexed
@@ -107,12 +110,9 @@ struct Fused {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                u32x4 Ah[NA], Al[NA], Bh[NBK], Bl[NBK];
+                u32x4 Ah[NA], Bh[NBK], Bl[NBK];
 #pragma unroll
-                for (int a = 0; a < NA; ++a) {
-                    Ah[a] = get_frag(sbase, 2 * j * WAVE_B + (s * NP) * PANEL_B + 32 * a);
-                    if (NP == 2) Al[a] = get_frag(sbase, 2 * j * WAVE_B + (s * NP + 1) * PANEL_B + 32 * a);
-                }
+                for (int a = 0; a < NA; ++a) Ah[a] = get_frag(sbase, 2 * j * WAVE_B + s * PANEL_B + 32 * a);
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
                     Bh[b] = get_frag(zbase, 2 * j * WAVE_B + (s * NP) * PANEL_B + 32 * b);
@@ -123,10 +123,7 @@ struct Fused {
 #pragma unroll
                     for (int b = 0; b < NBK; ++b) {
                         acc[a][b] = Op::mfma(Ah[a], Bh[b], acc[a][b]);
-                        if (NP == 2) {
-                            cc[a][b] = Op::mfma(Ah[a], Bl[b], cc[a][b]);
-                            cc[a][b] = Op::mfma(Al[a], Bh[b], cc[a][b]);
-                        }
+                        if (NP == 2) cc[a][b] = Op::mfma(Ah[a], Bl[b], cc[a][b]);
                     }
                 if (s == 0) {                   // bias gradient = ones^T . Z (value stream)
 #pragma unroll
@@ -153,7 +150,7 @@ struct Fused {
     template <int L>
     static __device__ __forceinline__ void wgrad(const char* lanebase, Acc& A, int quad) {
         const char* zl = lanebase;                  // Z tensor of chain wave 0
-        const char* sl = lanebase + TENSOR_B;       // S tensor of chain wave 0
+        const char* sl = lanebase + TENSOR_Z_B;     // S tensor of chain wave 0
         const int wi = quad >> 1, wo = quad & 1;
         if constexpr (L == 0) {
             if (quad < WB) {
@@ -217,6 +214,14 @@ struct Fused {
                 if (in < n_in && out < n_out) part[a.net.w_off[l] + in * n_out + out] = v[r];
             }
         };
+        {
+            // Wbar_0 rows 4..6 hold the contribution of the inputs' low parts (see Down<0>): fold them into rows 0..2
+            f32x4 lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lo[r] = __shfl_xor(A.first[r], 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A.first[r] += lo[r] * INV_LS;
+        }
         if (quad < WB) {
             put_block(A.first, 0, 0, quad, 3, H);
             put_block(A.last, NL, quad, 0, H, NO);
@@ -247,16 +252,18 @@ struct Fused {
     };
 
     // chain-layout fragments -> [point][feature] rows of this wave's LDS tensor (row = lane's point, 8 bytes per feature block)
-    template <int KSF, int NMB>     // NMB = 16-feature blocks actually present (WB for states/adjoints, 1 for inputs/outputs)
+    // NMB = 16-feature blocks actually present (WB for states/adjoints, 1 for inputs/outputs); NPW = parts written (NP for
+    // adjoints, 1 for states)
+    template <int KSF, int NMB, int NPW>
     static __device__ __forceinline__ void put_tensor(char* row, const u32x4 (&F)[NS][1][KSF][NP]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+            for (int p = 0; p < NPW; ++p)
 #pragma unroll
                 for (int mb = 0; mb < NMB; ++mb) {
                     u32x2 v = {F[s][0][mb >> 1][p][(mb & 1) * 2 + 0], F[s][0][mb >> 1][p][(mb & 1) * 2 + 1]};
-                    *reinterpret_cast<u32x2*>(row + (s * NP + p) * PANEL_B + 32 * mb) = v;
+                    *reinterpret_cast<u32x2*>(row + (s * NPW + p) * PANEL_B + 32 * mb) = v;
                 }
     }
 
@@ -265,18 +272,11 @@ struct Fused {
     static __device__ __forceinline__ void state_from_lds(const char* rowS, float (&st)[NS][1][4]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const u32x2 h = *reinterpret_cast<const u32x2*>(rowS + (s * NP) * PANEL_B + 32 * MB);
-            u32x2 l = {0u, 0u};
-            if (NP == 2) l = *reinterpret_cast<const u32x2*>(rowS + (s * NP + 1) * PANEL_B + 32 * MB);
+            const u32x2 h = *reinterpret_cast<const u32x2*>(rowS + s * PANEL_B + 32 * MB);
 #pragma unroll
             for (int d = 0; d < 2; ++d) {
-                float v0 = cvt16<Op>((uint16_t)(h[d] & 0xffffu)), v1 = cvt16<Op>((uint16_t)(h[d] >> 16));
-                if (NP == 2) {
-                    v0 += cvt16<Op>((uint16_t)(l[d] & 0xffffu)) * INV_LS;
-                    v1 += cvt16<Op>((uint16_t)(l[d] >> 16)) * INV_LS;
-                }
-                st[s][0][2 * d + 0] = v0;
-                st[s][0][2 * d + 1] = v1;
+                st[s][0][2 * d + 0] = cvt16<Op>((uint16_t)(h[d] & 0xffffu));
+                st[s][0][2 * d + 1] = cvt16<Op>((uint16_t)(h[d] >> 16));
             }
         }
     }
@@ -366,28 +366,24 @@ struct Fused {
         if constexpr (MB + 1 < WB) bwd_mb<MB + 1, KSB>(x, frag0, An, Zf, Zn);
     }
 
-    // parked state S_l (fragment order in the per-wave scratch) -> this wave's LDS S rows, a fragment at a time
+    // parked state S_l (fragment order in the per-wave scratch, hi parts) -> this wave's LDS S rows, a fragment at a time
     static __device__ __forceinline__ void scratch_to_lds(const Ctx& x, int l /*1..NL-1*/) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) {
-                    const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x.scr, x.lane16, ((((l - 1) * NS + s) * KS + kk) * NP + p) * 1024, 0);
-                    char* row = x.rowS + (s * NP + p) * PANEL_B;
-                    *reinterpret_cast<u32x2*>(row + 32 * (2 * kk)) = u32x2{f[0], f[1]};
-                    if (2 * kk + 1 < WB) *reinterpret_cast<u32x2*>(row + 32 * (2 * kk + 1)) = u32x2{f[2], f[3]};
-                }
+            for (int kk = 0; kk < KS; ++kk) {
+                const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x.scr, x.lane16, (((l - 1) * NS + s) * KS + kk) * 1024, 0);
+                char* row = x.rowS + s * PANEL_B;
+                *reinterpret_cast<u32x2*>(row + 32 * (2 * kk)) = u32x2{f[0], f[1]};
+                if (2 * kk + 1 < WB) *reinterpret_cast<u32x2*>(row + 32 * (2 * kk + 1)) = u32x2{f[2], f[3]};
+            }
     }
     static __device__ __forceinline__ void store_state(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][p], x.scr, x.lane16, ((((l - 1) * NS + s) * KS + kk) * NP + p) * 1024, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][0], x.scr, x.lane16, (((l - 1) * NS + s) * KS + kk) * 1024, 0);
     }
 
     // Weight layers L = NL-1 .. 1 (hidden-to-hidden) and finally L = 0, fully unrolled (static fragment indices / offsets).
@@ -396,7 +392,7 @@ struct Fused {
         // entry: Zc = Z_L (adjoint of weight layer L's pre-activation) in chain fragment order
         static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&Zc)[NS][1][KS][NP]) {
             __syncthreads();                                   // previous layer's fragment reads are done
-            put_tensor<KS, WB>(x.rowZ, Zc);
+            put_tensor<KS, WB, NP>(x.rowZ, Zc);
             if constexpr (L >= 1) {
                 scratch_to_lds(x, L);
             } else {
@@ -406,13 +402,18 @@ struct Fused {
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
+                        // rows 0..2: hi parts; rows 4..6 (lanes q == 1): the 2^11-scaled low parts of the same numbers, so that the
+                        // first layer's weight gradient keeps full input precision (combined at write-out)
                         float v = 0.0f;
-                        if (x.q == 0 && r < 3) v = (s == 0) ? xin[r] : (r == s - 1 ? a.sx[r] : 0.0f);
+                        if (x.q < 2 && r < 3) {
+                            const float full = (s == 0) ? xin[r] : (r == s - 1 ? a.sx[r] : 0.0f);
+                            v = x.q == 0 ? full : (full - round16<Op>(full)) * Op::LO_SCALE;
+                        }
                         v0[s][0][r] = v;
                     }
                 u32x4 S0[NS][1][1][NP];
                 CH::template emit<1, 0>(S0, v0, nullptr, 16, x.c, x.q);
-                put_tensor<1, 1>(x.rowS, S0);
+                put_tensor<1, 1, 1>(x.rowS, S0);
             }
             __syncthreads();                                   // tensors visible to the weight-gradient waves
             if constexpr (L >= 1) {
@@ -438,7 +439,7 @@ struct Fused {
         x.w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * 16, 0x00020000);
         x.lane16 = (unsigned)lane * 16u;
         x.rowZ = lds + wave * WAVE_B + c * ROWB + 8 * q;
-        x.rowS = x.rowZ + TENSOR_B;
+        x.rowS = x.rowZ + TENSOR_Z_B;
         x.c = c;
         x.q = q;
         float lsum[8];
@@ -545,8 +546,8 @@ struct Fused {
             }
             // ---- top weight layer NL: hand Z_NL (16 outputs) and S_NL over, then reverse into the hidden chain
             __syncthreads();
-            put_tensor<1, 1>(x.rowZ, ZL);
-            put_tensor<KS, WB>(x.rowS, B);                // B still holds S_NL
+            put_tensor<1, 1, NP>(x.rowZ, ZL);
+            put_tensor<KS, WB, 1>(x.rowS, B);                // B still holds S_NL
             __syncthreads();
             u32x4 Zn[NS][1][KS][NP];
             {

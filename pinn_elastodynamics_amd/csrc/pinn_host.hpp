@@ -294,7 +294,7 @@ struct Host {
             Plan p;
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
-            const size_t per_wg = (size_t)4 * (c.net.nl - 1) * 4 * FI::KS * NP * 64 * sizeof(u32x4);
+            const size_t per_wg = (size_t)4 * (c.net.nl - 1) * 4 * FI::KS * 64 * sizeof(u32x4);
             if (c.ws_bytes < p.fixed_end + per_wg) return 0;
             long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
             if (grid > FUSED_GRID) grid = FUSED_GRID;
