@@ -106,6 +106,9 @@ int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_fla
 /* Testing hook (process-wide): 0 forces the two-kernel path (chain + wgrad kernels) even where the
  * fused kernel applies; returns the previous setting.  Both paths compute the same numbers. */
 int pinn_debug_set_fused(int enable);
+/* Profiling hook (process-wide): device buffer of 128 uint64 that the fused kernel fills with shader-clock
+ * stamps of its phases (workgroup 0 only); NULL turns it off. */
+void pinn_debug_set_stamp_buffer(void* device_u64x128);
 
 const char* pinn_error_string(int code);
 int pinn_abi_version(void);

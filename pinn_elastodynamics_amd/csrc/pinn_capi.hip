@@ -66,10 +66,13 @@ static void input_map(const double lb[3], const double ub[3], int normalize, Cal
 using namespace pinn;
 
 static int g_use_fused = 1;
+static unsigned long long* g_dbg_stamps = nullptr;
 
 extern "C" {
 
 int pinn_abi_version(void) { return 1; }
+
+void pinn_debug_set_stamp_buffer(void* device_u64x128) { g_dbg_stamps = static_cast<unsigned long long*>(device_u64x128); }
 
 int pinn_debug_set_fused(int enable) {
     const int old = g_use_fused;
@@ -126,6 +129,7 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     c.fields_out = nullptr;
     c.prof_ms = nullptr;
     c.use_fused = g_use_fused;
+    c.dbg_stamps = g_dbg_stamps;
     return PINN_OK;
 }
 

@@ -62,6 +62,18 @@ __device__ __forceinline__ uint32_t pack2(float a, float b) {
     v[1] = (typename Op::T)b;
     return __builtin_bit_cast(uint32_t, v);
 }
+// (a, b) -> packed hi pair and packed scaled-lo pair:  lo = T((x - float(T(x))) * LO_SCALE), written as one fused
+// multiply-add on the converted hi so that fp16 compiles to v_fma_mixlo/mixhi_f16 (x*LO_SCALE and hi*LO_SCALE are exact).
+template <class Op>
+__device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t& lo) {
+    typename Op::V2 h, l;
+    h[0] = (typename Op::T)a;
+    h[1] = (typename Op::T)b;
+    l[0] = (typename Op::T)__builtin_fmaf((float)h[0], -Op::LO_SCALE, a * Op::LO_SCALE);
+    l[1] = (typename Op::T)__builtin_fmaf((float)h[1], -Op::LO_SCALE, b * Op::LO_SCALE);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
 template <class Op>
 __device__ __forceinline__ float cvt16(uint16_t bits) {
     return (float)__builtin_bit_cast(typename Op::T, bits);
@@ -197,11 +209,13 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackArgs a) {
             hi[d] = pack2<Op>(w2[0], w2[1]);
             lo[d] = pack2<Op>((w2[0] - round16<Op>(w2[0])) * Op::LO_SCALE, (w2[1] - round16<Op>(w2[1])) * Op::LO_SCALE);
         }
+        // stored parts: [hi, lo] (split) or [hi]
+        constexpr int NPS = SPLIT == 3 ? 2 : 1;
         u32x4 vh = {hi[0], hi[1], hi[2], hi[3]};
-        a.frags[((long)frag * NP + 0) * 64 + lane] = vh;
+        a.frags[((long)frag * NPS + 0) * 64 + lane] = vh;
         if (NP == 2) {
             u32x4 vl = {lo[0], lo[1], lo[2], lo[3]};
-            a.frags[((long)frag * NP + 1) * 64 + lane] = vl;
+            a.frags[((long)frag * NPS + 1) * 64 + lane] = vl;
         }
     }
     // fp32 side tables
@@ -236,6 +250,7 @@ __device__ __forceinline__ void tanh_act(float z, float& h, float& sd) {
 template <class Op, int SPLIT, int WIDTH, int NB, int NS, int HEAD>
 struct Chain {
     static constexpr int WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1, TP = 16 * NB;
+    static constexpr int NPS = SPLIT == 3 ? 2 : 1;     // stored weight-fragment parts (see repack_kernel)
     static constexpr float INV_LS = 1.0f / Op::LO_SCALE;
     typedef PanelGeom<WIDTH, NB, NS, NP> PG;
     typedef FragIndex<WIDTH> FI;
@@ -251,16 +266,18 @@ struct Chain {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const float* v = vals[s][nb];
-                const uint32_t h0 = pack2<Op>(v[0], v[1]), h1 = pack2<Op>(v[2], v[3]);
+                uint32_t h0, h1, l0 = 0, l1 = 0;
+                if (NP == 2) {
+                    split2<Op>(v[0], v[1], h0, l0);
+                    split2<Op>(v[2], v[3], h1, l1);
+                    Bn[s][nb][MB >> 1][NP - 1][(MB & 1) * 2 + 0] = l0;
+                    Bn[s][nb][MB >> 1][NP - 1][(MB & 1) * 2 + 1] = l1;
+                } else {
+                    h0 = pack2<Op>(v[0], v[1]);
+                    h1 = pack2<Op>(v[2], v[3]);
+                }
                 Bn[s][nb][MB >> 1][0][(MB & 1) * 2 + 0] = h0;
                 Bn[s][nb][MB >> 1][0][(MB & 1) * 2 + 1] = h1;
-                uint32_t l0 = 0, l1 = 0;
-                if (NP == 2) {
-                    l0 = pack2<Op>((v[0] - round16<Op>(v[0])) * Op::LO_SCALE, (v[1] - round16<Op>(v[1])) * Op::LO_SCALE);
-                    l1 = pack2<Op>((v[2] - round16<Op>(v[2])) * Op::LO_SCALE, (v[3] - round16<Op>(v[3])) * Op::LO_SCALE);
-                    Bn[s][nb][MB >> 1][1][(MB & 1) * 2 + 0] = l0;
-                    Bn[s][nb][MB >> 1][1][(MB & 1) * 2 + 1] = l1;
-                }
                 if (panel) {
                     uint16_t* p = panel + ((long)(s * NP) * rows + 16 * MB + 4 * q) * TP + 16 * nb + c;
                     p[0 * TP] = (uint16_t)(h0 & 0xffffu);
@@ -287,7 +304,7 @@ struct Chain {
 #pragma unroll
         for (int kk = 0; kk < KSB; ++kk)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) A[kk][p] = Afr[((long)kk * NP + p) * 64 + lane];
+            for (int p = 0; p < NP; ++p) A[kk][p] = Afr[((long)kk * NPS + p) * 64 + lane];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -374,7 +391,7 @@ struct Chain {
         static __device__ __forceinline__ void fwd(const u32x4* Al, const float* bl, int lane, const u32x4 (&B)[NS][NB][KS][NP],
                                                    u32x4 (&Bn)[NS][NB][KS][NP], uint16_t* panel, int c, int q) {
             f32x4 acc[NS][NB], accc[NS][NB];
-            gemm_block<KS>(Al + (long)MB * KS * NP * 64, lane, B, acc, accc);
+            gemm_block<KS>(Al + (long)MB * KS * NPS * 64, lane, B, acc, accc);
             const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * MB + 4 * q);
             float vals[NS][NB][4];
 #pragma unroll
@@ -395,7 +412,7 @@ struct Chain {
         static __device__ __forceinline__ void bwd(const u32x4* Al, int lane, const u32x4 (&Zf)[NS][NB][KSB][NP],
                                                    const uint16_t* spanel, u32x4 (&Zn)[NS][NB][KS][NP], uint16_t* zpanel, int c, int q) {
             f32x4 acc[NS][NB], accc[NS][NB];
-            gemm_block<KSB>(Al + (long)MB * KSB * NP * 64, lane, Zf, acc, accc);
+            gemm_block<KSB>(Al + (long)MB * KSB * NPS * 64, lane, Zf, acc, accc);
             float st[NS][NB][4], vals[NS][NB][4];
             load_state<MB>(spanel, c, q, st);
             act_bwd(st, acc, accc, vals);
@@ -450,7 +467,7 @@ struct Chain {
             MbLoop<0>::first(a, xin, B, SPILL ? St + PG::s_off(1) : nullptr, c, q);
             for (int l = 1; l < nl; ++l) {
                 u32x4 Bn[NS][NB][KS][NP];
-                MbLoop<0>::fwd(a.pw.frags + (long)FI::fwd_mid(l, 0, 0) * NP * 64, a.pw.bias_mid + (long)(l - 1) * WIDTH, lane, B, Bn,
+                MbLoop<0>::fwd(a.pw.frags + (long)FI::fwd_mid(l, 0, 0) * NPS * 64, a.pw.bias_mid + (long)(l - 1) * WIDTH, lane, B, Bn,
                                SPILL ? St + PG::s_off(l + 1) : nullptr, c, q);
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
@@ -463,7 +480,7 @@ struct Chain {
             }
             // ---- output layer  Y = h W_L + b_L  (INF:196-198): lane holds outputs 4q+r of its point
             f32x4 yacc[NS][NB], yaccc[NS][NB];
-            gemm_block<KS>(a.pw.frags + (long)FI::fwd_last(nl, 0) * NP * 64, lane, B, yacc, yaccc);
+            gemm_block<KS>(a.pw.frags + (long)FI::fwd_last(nl, 0) * NPS * 64, lane, B, yacc, yaccc);
             const f32x4 bl = *reinterpret_cast<const f32x4*>(a.pw.bias_last + 4 * q);
             // Every lane gathers all 8 (padded) outputs of its point: own block + the q^1 partner's
             float Y[NS][NB][8];
@@ -566,11 +583,11 @@ struct Chain {
                 }
                 // ---- reverse chain
                 u32x4 Zc[NS][NB][KS][NP];
-                MbLoop<0>::template bwd<1>(a.pw.frags + (long)FI::bwd_last(nl, 0) * NP * 64, lane, ZL, St + PG::s_off(nl), Zc,
+                MbLoop<0>::template bwd<1>(a.pw.frags + (long)FI::bwd_last(nl, 0) * NPS * 64, lane, ZL, St + PG::s_off(nl), Zc,
                                            Zt + PG::z_off(nl - 1), c, q);
                 for (int l = nl - 1; l >= 1; --l) {
                     u32x4 Zn[NS][NB][KS][NP];
-                    MbLoop<0>::template bwd<KS>(a.pw.frags + (long)FI::bwd_mid(nl, l, 0, 0) * NP * 64, lane, Zc, St + PG::s_off(l), Zn,
+                    MbLoop<0>::template bwd<KS>(a.pw.frags + (long)FI::bwd_mid(nl, l, 0, 0) * NPS * 64, lane, Zc, St + PG::s_off(l), Zn,
                                                 Zt + PG::z_off(l - 1), c, q);
 #pragma unroll
                     for (int s = 0; s < NS; ++s)
@@ -723,23 +740,21 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* partial, 
     grad[p] = (accumulate ? grad[p] : 0.0f) + scale * s;
 }
 
-// loss_terms[i] (+)= sum over waves of loss_part[w][i]   (single block of 64 threads; nterms <= 8)
+// loss_terms[i] (+)= sum over waves of loss_part[w][i]   (one block of 256 threads: 32 lanes per term, nterms <= 8)
 template <int UNUSED = 0>
-__global__ __launch_bounds__(64) void reduce_loss_kernel(const float* loss_part, long nwaves, int nterms, float* loss_terms,
-                                                         int accumulate) {
-    const int lane = threadIdx.x;
-    for (int i = 0; i < nterms; ++i) {
-        double s = 0.0;
-        for (long w = lane; w < nwaves; w += 64) s += (double)loss_part[w * 8 + i];
-        float v = (float)s;
-        v += __shfl_xor(v, 1);
-        v += __shfl_xor(v, 2);
-        v += __shfl_xor(v, 4);
-        v += __shfl_xor(v, 8);
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        if (lane == 0) loss_terms[i] = (accumulate ? loss_terms[i] : 0.0f) + v;
-    }
+__global__ __launch_bounds__(256) void reduce_loss_kernel(const float* loss_part, long nwaves, int nterms, float* loss_terms,
+                                                          int accumulate) {
+    const int term = threadIdx.x >> 5, sub = threadIdx.x & 31;
+    double s = 0.0;
+    if (term < nterms)
+        for (long w = sub; w < nwaves; w += 32) s += (double)loss_part[w * 8 + term];
+    float v = (float)s;
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    if (sub == 0 && term < nterms) loss_terms[term] = (accumulate ? loss_terms[term] : 0.0f) + v;
 }
 
 // tf.train.AdamOptimizer (TF1 rule; INF:131-133): epsilon added to the UNCORRECTED sqrt(v); the bias

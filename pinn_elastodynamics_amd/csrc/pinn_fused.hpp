@@ -8,9 +8,10 @@
 //     WEIGHT-GRADIENT waves, each owning one quadrant of every Wbar_l in persistent accumulators.
 //     The matrix pipe of a SIMD is shared by one wave of each role, so weight-gradient MFMAs fill
 //     the gaps the chain wave leaves while it runs the tanh / tangent VALU chain;
-//   * forward state S_l is parked in a per-wave scratch slot in FRAGMENT order (one coalesced
-//     16-byte store per lane per fragment, re-read the same way; 128 KB per wave, reused every
-//     step, so it lives in L2 / Infinity Cache rather than streaming through HBM);
+//   * forward state S_l (fp16, see below) is parked in a per-wave scratch slot as the very
+//     [stream][point][feature] image the LDS hand-off needs and comes back by asynchronous LDS-DMA
+//     (buffer_load ... lds, probed in tools/probes/lds_dma_probe.hip) into a double-buffered LDS
+//     tensor one layer ahead of its use, so the reload costs no registers and no exposed latency;
 //   * for the weight gradient  Wbar_l = sum_points S_l^T Z_l  the contraction runs over points, so
 //     both operands are needed "feature per lane, points in registers" -- the transpose of the
 //     chain layout.  Every chain wave drops its S_l and Z_l tiles into LDS as [point][feature] rows
@@ -22,7 +23,7 @@
 // address the compiler can hoist costs a VGPR for the whole launch): weights, biases and scratch
 // go through buffer descriptors with ONE lane-offset VGPR and scalar (SGPR) offsets; LDS accesses
 // use one lane-base VGPR per tensor plus compile-time immediates.
-// Two workgroup barriers per weight layer (+1 per step).
+// Two workgroup barriers per weight layer.
 #pragma once
 #include "pinn_device.hpp"
 
@@ -30,6 +31,7 @@ namespace pinn {
 
 typedef short v4i16 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+typedef __attribute__((address_space(3))) void lds_void;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 struct FusedArgs {
@@ -47,11 +49,19 @@ struct FusedArgs {
     u32x4* scratch;            // [gridDim.x * 4 chain waves][NL-1][4 streams][KS][NP][64 lanes]
     float* loss_part;          // [gridDim.x * 4][8]
     float* partial;            // [gridDim.x][nparams]
+    unsigned long long* dbg;   // optional phase timestamps (s_memtime) of workgroup 0, chain wave 0 / weight-gradient wave 0; nullptr = off
 };
+
+__device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int slot) {
+    if (a.dbg != nullptr && who) a.dbg[slot] = __builtin_readcyclecounter();
+}
 
 template <class Op, int SPLIT, int WIDTH, int NL>
 struct Fused {
     static constexpr int NS = 4, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1;
+    // weight fragments as stored by repack_kernel: [hi, lo, hi*LO_SCALE] when split; the fused kernel accumulates
+    //   acc = (hi*LS).x_hi + hi.x_lo + lo.x_hi = LS * (W.x)   in ONE accumulator per stream (x_lo, lo carry the 2^11 scale)
+    static constexpr int NPS = NP;                     // stored parts per weight fragment: [hi, lo] when split
     static_assert(WB == 2 || WB == 4, "fused kernel supports padded widths 32 and 64");
     static_assert(NL >= 2, "fused kernel needs at least two hidden layers");
     static constexpr int IBW = WB / 2, OBW = WB / 2;          // weight-gradient wave (i,o) owns IBW x OBW blocks of every mid Wbar
@@ -65,10 +75,13 @@ struct Fused {
     // rounding S for the reverse pass changes the gradient error by < 10 % of itself as long as adjoints and weights stay split.
     static constexpr int TENSOR_Z_B = NS * NP * PANEL_B;
     static constexpr int TENSOR_S_B = NS * PANEL_B;
-    static constexpr int WAVE_B = TENSOR_Z_B + TENSOR_S_B;
+    // The S tensor is double buffered (layer parity) and filled by LDS-DMA straight from the scratch image, so it is padded
+    // to whole 1 KB DMA chunks; the scratch holds the same [stream][point][feature] image per parked layer.
+    static constexpr int SBUF_B = (TENSOR_S_B + 1023) / 1024 * 1024;
+    static constexpr int WAVE_B = TENSOR_Z_B + 2 * SBUF_B;
     static constexpr int LDS_B = 4 * WAVE_B;
-    static constexpr long SCRATCH_FRAGS = (long)(NL - 1) * NS * KS;          // u32x4[64] units per chain wave (hi parts only)
-    static constexpr unsigned SCRATCH_BYTES = (unsigned)(SCRATCH_FRAGS * 1024);
+    static_assert(LDS_B <= 160 * 1024, "LDS budget");
+    static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * SBUF_B);   // per chain wave
 
     struct Acc {                       // persistent across the whole launch, all statically indexed
         f32x4 mid[NL - 1][IBW][OBW];
@@ -106,34 +119,41 @@ struct Fused {
         }
         const uint32_t one2 = pack2<Op>(1.0f, 1.0f);
         const u32x4 ones = {one2, one2, one2, one2};
+        // software pipeline over the 8 (k-step, stream) groups: the transpose-reads of group g+1 are issued before the MFMAs
+        // of group g, so LDS latency hides behind matrix work; the fence after each group bounds how far the compiler may hoist
+        struct Frags { u32x4 Ah[NA], Bh[NBK], Bl[NBK]; };
+        auto fetch = [&](int g, Frags& f) {
+            const int j = g >> 2, st = g & 3;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int a = 0; a < NA; ++a) f.Ah[a] = get_frag(sbase, 2 * j * WAVE_B + st * PANEL_B + 32 * a);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                u32x4 Ah[NA], Bh[NBK], Bl[NBK];
+            for (int b = 0; b < NBK; ++b) {
+                f.Bh[b] = get_frag(zbase, 2 * j * WAVE_B + (st * NP) * PANEL_B + 32 * b);
+                if (NP == 2) f.Bl[b] = get_frag(zbase, 2 * j * WAVE_B + (st * NP + 1) * PANEL_B + 32 * b);
+            }
+        };
+        Frags cur, nxt;
+        fetch(0, cur);
 #pragma unroll
-                for (int a = 0; a < NA; ++a) Ah[a] = get_frag(sbase, 2 * j * WAVE_B + s * PANEL_B + 32 * a);
+        for (int g = 0; g < 2 * NS; ++g) {
+            if (g + 1 < 2 * NS) fetch(g + 1, nxt);
+#pragma unroll
+            for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
-                    Bh[b] = get_frag(zbase, 2 * j * WAVE_B + (s * NP) * PANEL_B + 32 * b);
-                    if (NP == 2) Bl[b] = get_frag(zbase, 2 * j * WAVE_B + (s * NP + 1) * PANEL_B + 32 * b);
+                    acc[a][b] = Op::mfma(cur.Ah[a], cur.Bh[b], acc[a][b]);
+                    if (NP == 2) cc[a][b] = Op::mfma(cur.Ah[a], cur.Bl[b], cc[a][b]);
                 }
+            if ((g & 3) == 0) {                   // bias gradient = ones^T . Z (value stream)
 #pragma unroll
-                for (int a = 0; a < NA; ++a)
-#pragma unroll
-                    for (int b = 0; b < NBK; ++b) {
-                        acc[a][b] = Op::mfma(Ah[a], Bh[b], acc[a][b]);
-                        if (NP == 2) cc[a][b] = Op::mfma(Ah[a], Bl[b], cc[a][b]);
-                    }
-                if (s == 0) {                   // bias gradient = ones^T . Z (value stream)
-#pragma unroll
-                    for (int b = 0; b < NBK; ++b) {
-                        bm[b] = Op::mfma(ones, Bh[b], bm[b]);
-                        if (NP == 2) bc[b] = Op::mfma(ones, Bl[b], bc[b]);
-                    }
+                for (int b = 0; b < NBK; ++b) {
+                    bm[b] = Op::mfma(ones, cur.Bh[b], bm[b]);
+                    if (NP == 2) bc[b] = Op::mfma(ones, cur.Bl[b], bc[b]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < 2 * NS) cur = nxt;
+        }
 #pragma unroll
         for (int b = 0; b < NBK; ++b) {
             bias_out[b] = NP == 2 ? bm[b][0] + bc[b][0] * INV_LS : bm[b][0];
@@ -150,7 +170,7 @@ struct Fused {
     template <int L>
     static __device__ __forceinline__ void wgrad(const char* lanebase, Acc& A, int quad) {
         const char* zl = lanebase;                  // Z tensor of chain wave 0
-        const char* sl = lanebase + TENSOR_Z_B;     // S tensor of chain wave 0
+        const char* sl = lanebase + TENSOR_Z_B + (L & 1) * SBUF_B;     // S tensor (parity buffer of layer L) of chain wave 0
         const int wi = quad >> 1, wo = quad & 1;
         if constexpr (L == 0) {
             if (quad < WB) {
@@ -179,11 +199,14 @@ struct Fused {
 
     template <int L>
     struct WgDown {     // same barrier sequence as the chain role's Down<>
-        static __device__ __forceinline__ void run(const char* lanebase, Acc& A, int quad) {
+        static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const char* lanebase, Acc& A, int quad) {
             __syncthreads();                                   // (chain waves now overwrite the tensors)
+            fused_stamp(a, tracer, 64 + 3 * (NL - L));
             __syncthreads();                                   // tensors of layer L are complete
+            fused_stamp(a, tracer, 65 + 3 * (NL - L));
             wgrad<L>(lanebase, A, quad);
-            if constexpr (L >= 1) WgDown<L - 1>::run(lanebase, A, quad);
+            fused_stamp(a, tracer, 66 + 3 * (NL - L));
+            if constexpr (L >= 1) WgDown<L - 1>::run(a, tracer, lanebase, A, quad);
         }
     };
 
@@ -201,8 +224,7 @@ struct Fused {
         for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
         const char* lanebase = lds + (q >> 1) * WAVE_B + (8 * (q & 1) + (c >> 2)) * ROWB + 8 * (c & 3);
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
-            __syncthreads();                                   // step start (chain waves reuse their S rows during the forward)
-            WgDown<NL>::run(lanebase, A, quad);
+            WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0, lanebase, A, quad);
         }
         // ---- write this workgroup's partial gradient
         float* part = a.partial + (long)blockIdx.x * a.net.nparams;
@@ -246,9 +268,12 @@ struct Fused {
     struct Ctx {                                   // wave-invariant addressing state of a chain wave
         __amdgpu_buffer_rsrc_t frags, scr, bias, w0p;
         unsigned lane16;                           // lane * 16: the only VGPR offset of the fragment / scratch traffic
-        char* rowZ;                                // this lane's row base in the wave's Z tensor: + c*ROWB + 8q
-        char* rowS;
+        unsigned rowoff;                           // c*ROWB + 8q: this lane's row/column offset inside a tensor image
+        char* tenZ;                                // wave's Z tensor (uniform); S buffers follow at +TENSOR_Z_B (+SBUF_B)
         int c, q;
+        bool tracer;                               // workgroup 0, chain wave 0, lane 0
+        __device__ __forceinline__ char* rowZ() const { return tenZ + rowoff; }
+        __device__ __forceinline__ char* rowS(int L) const { return tenZ + TENSOR_Z_B + (L & 1) * SBUF_B + rowoff; }
     };
 
     // chain-layout fragments -> [point][feature] rows of this wave's LDS tensor (row = lane's point, 8 bytes per feature block)
@@ -286,11 +311,12 @@ struct Fused {
 #pragma unroll
         for (int kk = 0; kk < KSB; ++kk)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) Af[kk][p] = __builtin_amdgcn_raw_buffer_load_b128(x.frags, x.lane16, ((frag0 + kk) * NP + p) * 1024, 0);
+            for (int p = 0; p < NP; ++p) Af[kk][p] = __builtin_amdgcn_raw_buffer_load_b128(x.frags, x.lane16, ((frag0 + kk) * NPS + p) * 1024, 0);
     }
+    // acc[s] + accc[s]/LS = sum_k W[.,k] x_s[k]: eight independent MFMA chains (4 streams x {main, correction})
     template <int KSB>
-    static __device__ __forceinline__ void gemm_pre(const u32x4 (&Af)[KSB][NP], const u32x4 (&B)[NS][1][KSB][NP], f32x4 (&acc)[NS][1],
-                                                    f32x4 (&accc)[NS][1]) {
+    static __device__ __forceinline__ void gemm_pre(const u32x4 (&Af)[KSB][NP], const u32x4 (&B)[NS][1][KSB][NP], f32x4 (&acc)[NS],
+                                                    f32x4 (&accc)[NS]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             f32x4 m = {0.f, 0.f, 0.f, 0.f}, cc = {0.f, 0.f, 0.f, 0.f};
@@ -302,10 +328,11 @@ struct Fused {
                     cc = Op::mfma(Af[kk][1], B[s][0][kk][0], cc);
                 }
             }
-            acc[s][0] = m;
-            accc[s][0] = cc;
+            acc[s] = m;
+            accc[s] = cc;
         }
     }
+    static __device__ __forceinline__ float comb(const f32x4& m, const f32x4& cc, int r) { return NP == 2 ? m[r] + cc[r] * INV_LS : m[r]; }
 
     // forward first layer (K = 3, VALU): INF:191-195 with the tangent seeds e_k * sx_k
     template <int MB>
@@ -334,16 +361,16 @@ struct Fused {
         if constexpr (MB + 1 < WB) load_afrags<KS>(x, frag0 + (MB + 1) * KS, An);
         const u32x4 bu = __builtin_amdgcn_raw_buffer_load_b128(x.bias, (unsigned)x.q * 16u, bias_off + 16 * MB * 4, 0);
         const f32x4 bias = __builtin_bit_cast(f32x4, bu);
-        f32x4 acc[NS][1], accc[NS][1];
+        f32x4 acc[NS], accc[NS];
         gemm_pre<KS>(Af, B, acc, accc);
         float vals[NS][1][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float h, sd;
-            tanh_act(CH::comb(acc[0][0], accc[0][0], r) + bias[r], h, sd);
+            tanh_act(comb(acc[0], accc[0], r) + bias[r], h, sd);
             vals[0][0][r] = h;
 #pragma unroll
-            for (int s = 1; s < NS; ++s) vals[s][0][r] = sd * CH::comb(acc[s][0], accc[s][0], r);
+            for (int s = 1; s < NS; ++s) vals[s][0][r] = sd * comb(acc[s], accc[s], r);
         }
         CH::template emit<KS, MB>(Bn, vals, nullptr, WIDTH, x.c, x.q);
         __builtin_amdgcn_sched_barrier(0);
@@ -352,50 +379,77 @@ struct Fused {
 
     // reverse through a weight layer (KSB k-steps of its outputs) + the activation below; state from the wave's LDS rows
     template <int MB, int KSB>
-    static __device__ __forceinline__ void bwd_mb(const Ctx& x, int frag0, const u32x4 (&Af)[KSB][NP], const u32x4 (&Zf)[NS][1][KSB][NP],
-                                                  u32x4 (&Zn)[NS][1][KS][NP]) {
+    static __device__ __forceinline__ void bwd_mb(const Ctx& x, int frag0, const char* rowS, const u32x4 (&Af)[KSB][NP],
+                                                  const u32x4 (&Zf)[NS][1][KSB][NP], u32x4 (&Zn)[NS][1][KS][NP]) {
         u32x4 An[KSB][NP];
         if constexpr (MB + 1 < WB) load_afrags<KSB>(x, frag0 + (MB + 1) * KSB, An);
-        f32x4 acc[NS][1], accc[NS][1];
+        f32x4 acc[NS], accc[NS];
         gemm_pre<KSB>(Af, Zf, acc, accc);
         float st[NS][1][4], vals[NS][1][4];
-        state_from_lds<MB>(x.rowS, st);
-        CH::act_bwd(st, acc, accc, vals);
+        state_from_lds<MB>(rowS, st);
+        // reverse of (h = tanh z, hdot_k = (1-h^2) zdot_k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float h = st[0][0][r];
+            const float sd = 1.0f - h * h;
+            float dot = 0.0f;
+#pragma unroll
+            for (int s = 1; s < NS; ++s) {
+                const float hdb = comb(acc[s], accc[s], r);
+                dot += hdb * st[s][0][r];
+                vals[s][0][r] = sd * hdb;
+            }
+            vals[0][0][r] = sd * comb(acc[0], accc[0], r) - 2.0f * h * dot;
+        }
         CH::template emit<KS, MB>(Zn, vals, nullptr, WIDTH, x.c, x.q);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MB + 1 < WB) bwd_mb<MB + 1, KSB>(x, frag0, An, Zf, Zn);
+        if constexpr (MB + 1 < WB) bwd_mb<MB + 1, KSB>(x, frag0, rowS, An, Zf, Zn);
     }
 
-    // parked state S_l (fragment order in the per-wave scratch, hi parts) -> this wave's LDS S rows, a fragment at a time
-    static __device__ __forceinline__ void scratch_to_lds(const Ctx& x, int l /*1..NL-1*/) {
+    // parked state S_l: asynchronous LDS-DMA of the scratch image into the parity buffer of layer l (no registers involved;
+    // completion is covered by the vmcnt(0) of the next workgroup barrier)
+    static __device__ __forceinline__ void dma_state(const Ctx& x, int l /*1..NL-1*/) {
+        char* dst = x.tenZ + TENSOR_Z_B + (l & 1) * SBUF_B;
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int kk = 0; kk < KS; ++kk) {
-                const u32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x.scr, x.lane16, (((l - 1) * NS + s) * KS + kk) * 1024, 0);
-                char* row = x.rowS + s * PANEL_B;
-                *reinterpret_cast<u32x2*>(row + 32 * (2 * kk)) = u32x2{f[0], f[1]};
-                if (2 * kk + 1 < WB) *reinterpret_cast<u32x2*>(row + 32 * (2 * kk + 1)) = u32x2{f[2], f[3]};
-            }
+        for (int i = 0; i < SBUF_B / 1024; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(x.scr, (lds_void*)(dst + i * 1024), 16, x.lane16, (l - 1) * SBUF_B + i * 1024, 0, 0);
     }
-    static __device__ __forceinline__ void store_state(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
+    // forward: park feature block MB of S_l (hi parts) as rows of the scratch image
+    template <int MB>
+    static __device__ __forceinline__ void park_block(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const u32x2 v = {Sf[s][0][MB >> 1][0][(MB & 1) * 2 + 0], Sf[s][0][MB >> 1][0][(MB & 1) * 2 + 1]};
+            __builtin_amdgcn_raw_buffer_store_b64(v, x.scr, x.rowoff, (l - 1) * SBUF_B + s * PANEL_B + 32 * MB, 0);
+        }
+    }
+    template <int MB>
+    static __device__ __forceinline__ void park_state(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
+        park_block<MB>(x, l, Sf);
+        if constexpr (MB + 1 < WB) park_state<MB + 1>(x, l, Sf);
+    }
+
+    // Force the fragments to be fully computed at this point: without it the compiler sinks the reverse elementwise work past
+    // the next workgroup barrier, where the weight-gradient waves can no longer overlap with it.
+    template <int KSF>
+    static __device__ __forceinline__ void pin(const u32x4 (&F)[NS][1][KSF][NP]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
-                __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][0], x.scr, x.lane16, (((l - 1) * NS + s) * KS + kk) * 1024, 0);
+            for (int kk = 0; kk < KSF; ++kk)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(F[s][0][kk][p]));
     }
 
     // Weight layers L = NL-1 .. 1 (hidden-to-hidden) and finally L = 0, fully unrolled (static fragment indices / offsets).
     template <int L>
     struct Down {
-        // entry: Zc = Z_L (adjoint of weight layer L's pre-activation) in chain fragment order
+        // entry: Zc = Z_L (adjoint of weight layer L's pre-activation) in chain fragment order; S_L is (being) DMA'd into its parity buffer
         static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&Zc)[NS][1][KS][NP]) {
             __syncthreads();                                   // previous layer's fragment reads are done
-            put_tensor<KS, WB, NP>(x.rowZ, Zc);
-            if constexpr (L >= 1) {
-                scratch_to_lds(x, L);
-            } else {
+            fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
+            put_tensor<KS, WB, NP>(x.rowZ(), Zc);
+            if constexpr (L == 0) {
                 // S_0: the inputs as a 16-feature tensor (rows 0..2 = x', tangent stream k carries sx_k in row k)
                 float v0[NS][1][4];
 #pragma unroll
@@ -413,18 +467,23 @@ struct Fused {
                     }
                 u32x4 S0[NS][1][1][NP];
                 CH::template emit<1, 0>(S0, v0, nullptr, 16, x.c, x.q);
-                put_tensor<1, 1, 1>(x.rowS, S0);
+                put_tensor<1, 1, 1>(x.rowS(0), S0);
             }
-            __syncthreads();                                   // tensors visible to the weight-gradient waves
+            __syncthreads();                                   // tensors visible to the weight-gradient waves (also drains the S_L DMA)
+            fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
             if constexpr (L >= 1) {
-                // reverse through W_L and the activation that produced S_L -> Z_{L-1}
+                // reverse through W_L and the activation that produced S_L -> Z_{L-1}; meanwhile S_{L-1} streams into the other buffer
                 u32x4 Zn[NS][1][KS][NP];
                 {
                     const int frag0 = FI::bwd_mid(NL, L, 0, 0);
                     u32x4 A0[KS][NP];
                     load_afrags<KS>(x, frag0, A0);
-                    bwd_mb<0, KS>(x, frag0, A0, Zc, Zn);
+                    if constexpr (L >= 2) dma_state(x, L - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bwd_mb<0, KS>(x, frag0, x.rowS(L), A0, Zc, Zn);
+                    pin<KS>(Zn);
                 }
+                fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
                 Down<L - 1>::run(a, x, xin, Zn);
             }
         }
@@ -434,14 +493,16 @@ struct Fused {
         const long gwave = (long)blockIdx.x * 4 + wave;
         Ctx x;
         x.frags = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.frags, 0, (int)a.frags_bytes, 0x00020000);
-        x.scr = __builtin_amdgcn_make_buffer_rsrc((void*)(a.scratch + gwave * SCRATCH_FRAGS * 64), 0, (int)SCRATCH_BYTES, 0x00020000);
+        x.scr = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gwave * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES,
+                                                  0x00020000);
         x.bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.bias_mid, 0, (NL - 1) * WIDTH * 4, 0x00020000);
         x.w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * 16, 0x00020000);
         x.lane16 = (unsigned)lane * 16u;
-        x.rowZ = lds + wave * WAVE_B + c * ROWB + 8 * q;
-        x.rowS = x.rowZ + TENSOR_Z_B;
+        x.tenZ = lds + wave * WAVE_B;
+        x.rowoff = (unsigned)(c * ROWB + 8 * q);
         x.c = c;
         x.q = q;
+        x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0;
         float lsum[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) lsum[i] = 0.0f;
@@ -454,11 +515,11 @@ struct Fused {
             xin[0] = a.x[pidx] * a.sx[0] + a.ox[0];
             xin[1] = a.y[pidx] * a.sx[1] + a.ox[1];
             xin[2] = a.t[pidx] * a.sx[2] + a.ox[2];
-            __syncthreads();                                   // step start: last step's weight-gradient reads are done
+            fused_stamp(a, x.tracer, 0);
             // ---- forward (same arithmetic as chain_kernel), state parked in fragment order
             u32x4 B[NS][1][KS][NP];
             first_mb<0>(a, x, xin, B);
-            store_state(x, 1, B);
+            park_state<0>(x, 1, B);
             for (int l = 1; l < NL; ++l) {
                 u32x4 Bn[NS][1][KS][NP];
                 {
@@ -467,7 +528,7 @@ struct Fused {
                     load_afrags<KS>(x, frag0, A0);
                     fwd_mb<0>(x, frag0, (l - 1) * WIDTH * 4, A0, B, Bn);
                 }
-                if (l + 1 < NL) store_state(x, l + 1, Bn);      // S_NL stays in registers
+                if (l + 1 < NL) park_state<0>(x, l + 1, Bn);      // S_NL stays in registers
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -475,8 +536,9 @@ struct Fused {
 #pragma unroll
                         for (int pp = 0; pp < NP; ++pp) B[s][0][kk][pp] = Bn[s][0][kk][pp];
             }
+            fused_stamp(a, x.tracer, 1);
             // ---- output layer + residual head (net_f_sig INF:221-265)
-            f32x4 yacc[NS][1], yaccc[NS][1];
+            f32x4 yacc[NS], yaccc[NS];
             {
                 u32x4 A0[KS][NP];
                 load_afrags<KS>(x, FI::fwd_last(NL, 0), A0);
@@ -488,7 +550,7 @@ struct Fused {
             for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float own = CH::comb(yacc[s][0], yaccc[s][0], r) + (s == 0 ? bl[r] : 0.0f);
+                    const float own = comb(yacc[s], yaccc[s], r) + (s == 0 ? bl[r] : 0.0f);
                     const float oth = __shfl_xor(own, 16);
                     Y[s][r] = (q & 1) ? oth : own;
                     Y[s][4 + r] = (q & 1) ? own : oth;
@@ -545,17 +607,24 @@ struct Fused {
                 CH::template emit<1, 0>(ZL, vals, nullptr, 16, c, q);
             }
             // ---- top weight layer NL: hand Z_NL (16 outputs) and S_NL over, then reverse into the hidden chain
+            fused_stamp(a, x.tracer, 2);
             __syncthreads();
-            put_tensor<1, 1, NP>(x.rowZ, ZL);
-            put_tensor<KS, WB, 1>(x.rowS, B);                // B still holds S_NL
+            fused_stamp(a, x.tracer, 3);
+            put_tensor<1, 1, NP>(x.rowZ(), ZL);
+            put_tensor<KS, WB, 1>(x.rowS(NL), B);         // B still holds S_NL
             __syncthreads();
+            fused_stamp(a, x.tracer, 4);
             u32x4 Zn[NS][1][KS][NP];
             {
                 const int frag0 = FI::bwd_last(NL, 0);
                 u32x4 A0[1][NP];
                 load_afrags<1>(x, frag0, A0);
-                bwd_mb<0, 1>(x, frag0, A0, ZL, Zn);
+                dma_state(x, NL - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                bwd_mb<0, 1>(x, frag0, x.rowS(NL), A0, ZL, Zn);
+                pin<KS>(Zn);
             }
+            fused_stamp(a, x.tracer, 5);
             Down<NL - 1>::run(a, x, xin, Zn);
         }
 #pragma unroll
@@ -573,8 +642,12 @@ struct Fused {
         __shared__ __attribute__((aligned(16))) char lds[LDS_B];
         const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
         const int wave8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // provably wave-uniform
-        if (wave8 >= 4) wgrad_role(a, lds, wave8 - 4, c, q);
-        else chain_role(a, lds, wave8, lane, c, q);
+        if (wave8 >= 4) {
+            wgrad_role(a, lds, wave8 - 4, c, q);
+        } else {
+            __builtin_amdgcn_s_setprio(2);          // the chain wave is the critical path of its SIMD: issue it first
+            chain_role(a, lds, wave8, lane, c, q);
+        }
     }
 };
 

@@ -35,6 +35,7 @@ struct Call {
     float* fields_out;
     // optional per-kernel timing (host pointer, 4 floats: repack, chain, wgrad, reductions) -- makes the call synchronous
     float* prof_ms;
+    unsigned long long* dbg_stamps;   // optional device buffer for the fused kernel's phase timestamps (128 x u64)
     int use_fused;             // 1: prefer the fused kernel where it applies (default), 0: force the two-kernel path
 };
 
@@ -51,6 +52,7 @@ template <class Op, int SPLIT, int WIDTH>
 struct Host {
     static constexpr int NB = WIDTH <= 64 ? 2 : 1;
     static constexpr int NP = SPLIT == 3 ? 2 : 1;
+    static constexpr int NPS = SPLIT == 3 ? 2 : 1;    // stored weight-fragment parts
     static constexpr int TP = 16 * NB;
     static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
     static constexpr int FUSED_GRID = 256;    // persistent workgroups of the fused kernel (one per MI355X CU)
@@ -76,7 +78,7 @@ struct Host {
         p.bias_last = o;
         o = align_up(o + NOUT_PAD * sizeof(float), 256);
         p.frags = o;
-        o = align_up(o + (size_t)FI::total(net.nl) * NP * 64 * sizeof(u32x4), 256);
+        o = align_up(o + (size_t)FI::total(net.nl) * NPS * 64 * sizeof(u32x4), 256);
         p.loss_part = o;
         o = align_up(o + (size_t)MAX_BLOCKS * 4 * 8 * sizeof(float), 256);
         p.partial = o;
@@ -213,7 +215,7 @@ struct Host {
             if ((rc = (int)hipGetLastError())) return rc;
             toc(1);
             tic();
-            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(64), 0, c.stream, (const float*)a.loss_part, (long)blocks * 4, nterms,
+            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)blocks * 4, nterms,
                                c.loss_out, pass > 0 ? 1 : 0);
             if ((rc = (int)hipGetLastError())) return rc;
             toc(3);
@@ -250,7 +252,7 @@ struct Host {
             FusedArgs a;
             a.net = c.net;
             a.pw = packed(c, p);
-            a.frags_bytes = (unsigned)((size_t)FI::total(c.net.nl) * NP * 64 * sizeof(u32x4));
+            a.frags_bytes = (unsigned)((size_t)FI::total(c.net.nl) * NPS * 64 * sizeof(u32x4));
             a.x = c.x;
             a.y = c.y;
             a.t = c.t;
@@ -265,6 +267,7 @@ struct Host {
             a.scratch = reinterpret_cast<u32x4*>(b + p.panels);
             a.loss_part = reinterpret_cast<float*>(b + p.loss_part);
             a.partial = reinterpret_cast<float*>(b + p.partial);
+            a.dbg = c.dbg_stamps;
             hipEvent_t ev[2] = {nullptr, nullptr};
             if (c.prof_ms) { hipEventCreate(&ev[0]); hipEventCreate(&ev[1]); hipEventRecord(ev[0], c.stream); }
             hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL>), dim3(grid), dim3(512), 0, c.stream, a);
@@ -277,7 +280,7 @@ struct Host {
                 hipEventDestroy(ev[0]);
                 hipEventDestroy(ev[1]);
             }
-            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(64), 0, c.stream, (const float*)a.loss_part, (long)grid * 4, 7, c.loss_out, 0);
+            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * 4, 7, c.loss_out, 0);
             if ((rc = (int)hipGetLastError())) return rc;
             hipLaunchKernelGGL((reduce_grad_kernel<0>), dim3((c.net.nparams + 255) / 256), dim3(256), 0, c.stream, (const float*)a.partial,
                                grid, c.net.nparams, twmax, c.grad_out, c.accumulate);
@@ -294,7 +297,7 @@ struct Host {
             Plan p;
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
-            const size_t per_wg = (size_t)4 * (c.net.nl - 1) * 4 * FI::KS * 64 * sizeof(u32x4);
+            const size_t per_wg = (size_t)4 * (c.net.nl - 1) * ((4 * 16 * (WIDTH * 2 + 8) + 1023) / 1024 * 1024);
             if (c.ws_bytes < p.fixed_end + per_wg) return 0;
             long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
             if (grid > FUSED_GRID) grid = FUSED_GRID;

@@ -32,7 +32,8 @@ def rel(a, b):
     return float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
 
 
-def run_wave(emu, layers, n, prec, normalize=True, min_ws=False, seed=0):
+def run_wave(emu, layers, n, prec, normalize=True, min_ws=False, seed=0, fused=False):
+    emu.set_fused(fused)
     rng = np.random.default_rng(seed)
     Ws, bs = po.xavier_init(layers, rng)
     bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
@@ -59,13 +60,32 @@ def run_wave(emu, layers, n, prec, normalize=True, min_ws=False, seed=0):
     ([3] + 2 * [140] + [7], 20, "f16x3", 2e-6),        # reference CONF width (padded to 160)
 ])
 def test_wave_loss_grad_emulated(emu, layers, n, prec, tol):
-    e_loss, e_grad = run_wave(emu, layers, n, prec)
+    """two-kernel path (chain_kernel + wgrad_kernel): everything split, fp32-class agreement"""
+    e_loss, e_grad = run_wave(emu, layers, n, prec, fused=False)
     assert e_loss < tol and e_grad < tol
 
 
+@pytest.mark.parametrize("layers,n,prec,tol_loss,tol_grad", [
+    ([3] + 4 * [32] + [7], 130, "f16x3", 2e-6, 1e-4),   # fused kernel parks the state in fp16 for the reverse pass:
+    ([3] + 8 * [64] + [7], 200, "f16x3", 2e-6, 1e-4),   # loss exact, gradient ~5e-4/sqrt(n) (tools/precision_study2.py)
+    ([3] + 8 * [64] + [7], 100, "bf16", 2e-2, 2e-2),
+    ([3] + 4 * [64] + [7], 70, "bf16x3", 1e-4, 1e-3),
+])
+def test_fused_kernel_emulated(emu, layers, n, prec, tol_loss, tol_grad):
+    """fused persistent kernel (role-specialised waves, LDS transpose hand-off, LDS-DMA state reload)"""
+    e_loss, e_grad = run_wave(emu, layers, n, prec, fused=True)
+    assert e_loss < tol_loss and e_grad < tol_grad
+
+
+def test_fused_persistent_accumulation_emulated(emu):
+    """minimum workspace => fewer workgroups than steps: accumulators persist across steps of a workgroup"""
+    e_loss, e_grad = run_wave(emu, [3] + 4 * [32] + [7], 9000, "f16x3", min_ws=True, fused=True)
+    assert e_loss < 2e-6 and e_grad < 2e-5
+
+
 def test_chunked_workspace_emulated(emu):
-    """2100 points with the minimum workspace (64 tiles of 32 points) -> two passes."""
-    e_loss, e_grad = run_wave(emu, [3] + 2 * [32] + [7], 2100, "f16x3", min_ws=True)
+    """2100 points with the minimum workspace (64 tiles of 32 points) -> two passes of the two-kernel path."""
+    e_loss, e_grad = run_wave(emu, [3] + 2 * [32] + [7], 2100, "f16x3", min_ws=True, fused=False)
     assert e_loss < 2e-6 and e_grad < 2e-6
 
 

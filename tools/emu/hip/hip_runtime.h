@@ -206,6 +206,28 @@ inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, emu_buffer_rsrc 
     memcpy(r.base + voff + soff, &v, 16);
 }
 
+// LDS-DMA (buffer_load ... lds), semantics measured with tools/probes/lds_dma_probe.hip:
+//   LDS dst = ldsptr (wave-uniform) + inst_offset + lane*size ;  src = base + voffset + soffset + inst_offset
+// (executed synchronously here; on hardware it completes asynchronously under vmcnt)
+inline void __builtin_amdgcn_raw_ptr_buffer_load_lds(emu_buffer_rsrc r, __attribute__((address_space(3))) void* ldsptr, unsigned size,
+                                                     unsigned voff, unsigned soff, int inst_off, int) {
+    char* mine = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(ldsptr));
+    emu::cur_lane().xchg[0] = mine;
+    emu::wave_sync();
+    char* base = static_cast<char*>(const_cast<void*>(emu::wave_lane(0).xchg[0]));
+    emu::wave_sync();
+    if (voff + soff + inst_off + size > r.bytes) { fprintf(stderr, "emu: lds-dma out of range\n"); abort(); }
+    memcpy(base + inst_off + emu::lane_id() * size, r.base + voff + soff + inst_off, size);
+}
+typedef unsigned int emu_u32x2 __attribute__((ext_vector_type(2)));
+inline void __builtin_amdgcn_raw_buffer_store_b64(emu_u32x2 v, emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
+    if (voff + soff + 8u > r.bytes) { fprintf(stderr, "emu: buffer store out of range (%u + %u > %u)\n", voff, soff, r.bytes); abort(); }
+    memcpy(r.base + voff + soff, &v, 8);
+}
+
+inline unsigned long long emu_cycle_counter() { static unsigned long long t = 0; return t += 100; }
+#define __builtin_readcyclecounter emu_cycle_counter
+
 // ---- scalar math builtins ---------------------------------------------------------------------
 inline float __builtin_amdgcn_exp2f(float x) { return exp2f(x); }
 inline float __builtin_amdgcn_rcpf(float x) { return 1.0f / x; }
