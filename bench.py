@@ -138,7 +138,7 @@ def main():
                    "parallelism": f"dp{world}", "final_loss": losses[4][-1]},
     }
     if rank == 0:
-        # ---- roofline of the dominant kernel (chain kernel: forward + reverse chain), HIP events on the launch stream
+        # ---- roofline of the dominant kernel, HIP events on the launch stream (pinn_wave2d_loss_grad_profile)
         x, y, t = (a[:args.points_per_gpu] for a in model._collo)
         tw = [1.0 / args.points_per_gpu] * 7
         eng.wave_loss_grad_profile(model.theta, x, y, t, LB, UB, True, tw)
@@ -148,12 +148,23 @@ def main():
             ms = eng.wave_loss_grad_profile(model.theta, x, y, t, LB, UB, True, tw)
             for k in acc:
                 acc[k] += ms[k] / reps
-        n_launch = -(-args.points_per_gpu // args.chunk_points)
-        chain_tflops = CHAIN_FLOP_PER_PT * args.points_per_gpu / (acc["chain"] * 1e-3) / 1e12
-        out["roofline"] = {"kernel": "chain_kernel (forward + reverse chain, wave head)", "bound": "mfma",
-                           "achieved": chain_tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": chain_tflops / MFMA_PEAK_TFLOPS,
-                           "traffic": None, "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch,
-                           "algorithmic_flop_per_point": CHAIN_FLOP_PER_PT}
+        fused = acc["wgrad"] == 0.0          # the fused persistent kernel reports its whole time in the "chain" slot
+        n_launch = 1 if fused else -(-args.points_per_gpu // args.chunk_points)
+        flop_pt = FLOP_PER_PT if fused else CHAIN_FLOP_PER_PT
+        tflops = flop_pt * args.points_per_gpu / (acc["chain"] * 1e-3) / 1e12
+        traffic = None
+        try:    # HBM-side bytes per launch from the committed PMC passes of this kernel (profiles/README.md), if present
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_fused_pmc_summary.json")))
+            traffic = pm.get("hbm_bytes_per_launch") if fused and args.precision == "f16x3" else None
+        except Exception:
+            pass
+        out["roofline"] = {"kernel": "fused_wave_kernel (forward + reverse chain + weight gradient)" if fused
+                           else "chain_kernel (forward + reverse chain)", "bound": "mfma",
+                           "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
+                           "traffic": traffic, "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch,
+                           "algorithmic_flop_per_point": flop_pt,
+                           "note": "algorithmic flops: one product per contraction; the f16x3 mode issues 3 (forward/reverse chain) "
+                                   "or 2 (weight gradient) MFMAs per product"}
         out["kernel_ms_per_step"] = acc
         out["whole_path"] = {"algorithmic_flop_per_point": FLOP_PER_PT,
                              "achieved_tflops": FLOP_PER_PT * value / 1e12, "frac_of_mfma_peak": FLOP_PER_PT * value / 1e12 / (MFMA_PEAK_TFLOPS * world)}
