@@ -26,6 +26,7 @@ import numpy as np
 import scipy.io
 
 from . import pinn_oracle as po
+from . import plate_oracle as pl
 
 REF = "/root/reference"
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -102,5 +103,56 @@ def main():
             print("  FEM rel-L2 per frame  u:", np.round(rel["u"], 3), " s11:", np.round(rel["s11"], 3))
 
 
+def plate():
+    """PLATE fixtures: the three trained nets (PLATE:885-887 layer lists), a seeded 1024-point set in the quarter plate
+    outside the hole (lb/ub PLATE:881-882, hole r = 0.1 PLATE:42), composite streams, residuals, sums and the gradient
+    w.r.t. the uv net; 64 hole points for the traction term; FEM frames (frame k <-> t = k/8 s, PLATE:890,992-994)."""
+    rng = np.random.default_rng(2222)
+    base = os.path.join(REF, "PlateHoleQuarter", "train")
+    nets = {}
+    for key, fn in (("uv", "uvNN_float64.pickle"), ("dist", "distNN_float64.pickle"), ("part", "partNN_float64.pickle")):
+        W, b = load_pickle(os.path.join(base, fn))
+        layers = [W[0].shape[0]] + [w.shape[1] for w in W]
+        np.savez_compressed(os.path.join(OUT, f"weights_plate_{key}.npz"), layers=np.array(layers),
+                            **{f"W{i}": w for i, w in enumerate(W)}, **{f"b{i}": x for i, x in enumerate(b)})
+        nets[key] = (po.pack_params(W, b), layers)
+    lb, ub, r = np.array([0.0, 0.0, 0.0]), np.array([0.5, 0.5, 10.0]), 0.1
+    N = 1024
+    X = lb + (ub - lb) * rng.random((4 * N, 3))
+    X = X[X[:, 0] ** 2 + X[:, 1] ** 2 > r * r][:N]
+    st = {k: pl.net_streams(nets[k][0], nets[k][1], X[:, 0], X[:, 1], X[:, 2]) for k in nets}
+    F = pl.composite(st["uv"], st["dist"], st["part"])
+    tw = np.ones(5) / N
+    ss, g, f = pl.plate_loss_grad(nets["uv"][0], nets["uv"][1], X[:, 0], X[:, 1], X[:, 2], st["dist"], st["part"], term_weights=tw)
+    th = np.linspace(0.0, np.pi / 2, 8)
+    tt = np.linspace(0.0, 10.0, 8)
+    H = np.stack([np.repeat(r * np.cos(th), 8), np.repeat(r * np.sin(th), 8), np.tile(tt, 8)], 1)
+    DH = pl.net_streams(nets["dist"][0], nets["dist"][1], H[:, 0], H[:, 1], H[:, 2])[0]
+    PH = pl.net_streams(nets["part"][0], nets["part"][1], H[:, 0], H[:, 1], H[:, 2])[0]
+    ssh, gh = pl.traction_loss_grad(nets["uv"][0], nets["uv"][1], H[:, 0], H[:, 1], H[:, 2], DH, PH, r, weight=1.0 / 64)
+    np.savez_compressed(os.path.join(OUT, "golden_plate.npz"), X=X, H=H, N_streams=st["uv"], D_streams=st["dist"].astype(np.float32),
+                        P_streams=st["part"].astype(np.float32), F=F, f=f, sumsq=ss, grad=g.astype(np.float32), hole_sumsq=ssh,
+                        hole_grad=gh.astype(np.float32))
+    print("plate: loss_f_uv", ss[:2].sum() / N, "loss_f_s", ss[2:].sum() / N, "loss_HOLE", ssh.sum() / 64)
+    rows, frames = [], (10, 20, 30, 60)   # frame 40 (t = 5 s) is the zero crossing of the load: FEM fields ~ 0
+    for k in frames:
+        d = scipy.io.loadmat(os.path.join(REF, "PlateHoleQuarter", "FEM_result", "Quarter_plate_hole_dynamic", f"ProbeData-{k}.mat"))
+        fx, fy = d["x"].reshape(-1), d["y"].reshape(-1)
+        ok = (fx ** 2 + fy ** 2 > (r + 0.01) ** 2) & (fx <= 0.5) & (fy <= 0.5)
+        idx = rng.choice(np.nonzero(ok)[0], size=500, replace=False)
+        rows.append(np.stack([fx[idx], fy[idx], np.full(500, k / 8.0)] + [d[q].reshape(-1)[idx] for q in ("u", "v", "s11", "s22", "s12")], 1))
+    fem = np.concatenate(rows, 0)
+    stf = {k: pl.net_streams(nets[k][0], nets[k][1], fem[:, 0], fem[:, 1], fem[:, 2]) for k in nets}
+    Ff = pl.composite(stf["uv"], stf["dist"], stf["part"])[0]
+    rel = np.array([[np.linalg.norm(Ff[j, 500 * i:500 * (i + 1)] - fem[500 * i:500 * (i + 1), 3 + j])
+                     / np.linalg.norm(fem[500 * i:500 * (i + 1), 3 + j]) for i in range(len(frames))] for j in range(5)])
+    np.savez_compressed(os.path.join(OUT, "fem_plate.npz"), fem=fem.astype(np.float32), frames=np.array(frames), rel_l2=rel)
+    print("  FEM rel-L2 per frame u:", np.round(rel[0], 3), "v:", np.round(rel[1], 3), "s11:", np.round(rel[2], 3))
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if len(sys.argv) < 2 or sys.argv[1] == "wave":
+        main()
+    if len(sys.argv) < 2 or sys.argv[1] == "plate":
+        plate()
