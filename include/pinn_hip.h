@@ -98,6 +98,48 @@ int pinn_wave2d_fields(const float* params_flat, const int* layers, int n_layers
                        const double lb[3], const double ub[3], int normalize,
                        float* fields_out, int precision_mode, void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- plate-with-hole family (PLATE = PlateHoleQuarter/train/train.py); precision_mode must be a split mode ---------------
+ * Streams of one net at raw or normalised (x,y,t): streams_out is SoA [5][n_out][n] = Y, dY/dx, dY/dy, dY/dt, d2Y/dt2.
+ * Replaces the tf.gradients calls of net_dist_dt / net_part / net_vel (PLATE:330-356,398-402) and provides the frozen
+ * distance / particular streams the composite needs. */
+int pinn_net_streams(const float* params_flat, const int* layers, int n_layers,
+                     const float* x, const float* y, const float* t, int64_t n,
+                     const double lb[3], const double ub[3], int normalize,
+                     float* streams_out, int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
+/* Replaces net_f_sig of the plate (composite u = P + D*N, PLATE:358-388; nested u_tt, plane stress, PLATE:404-439), the
+ * five mean-squares PLATE:187-191 and their gradient w.r.t. the uv net only (D, P frozen, PLATE:240-241,249-250).
+ *   frozen_streams: SoA [2][5][5][n] = streams (value,x,y,t,tt) x fields (u,v,s11,s22,s12) of D, then of P (pinn_net_streams)
+ *   loss_terms_out[i] = sum_n f_i(n)^2, i in (f_u, f_v, f_s11, f_s22, f_s12)   (PLATE:439 order) */
+int pinn_plate2d_loss_grad(const float* params_flat, const int* layers, int n_layers,
+                           const float* x, const float* y, const float* t, int64_t n,
+                           const double lb[3], const double ub[3], int normalize,
+                           const float* frozen_streams, double E, double mu, double rho,
+                           const float term_weights[5],
+                           float* loss_terms_out, float* grad_flat_out, int accumulate,
+                           int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
+/* Replaces net_t + loss_HOLE (PLATE:452-461,192-193) and its gradient w.r.t. the uv net.
+ *   frozen_and_normals: SoA [12][n] = D values (5 fields), P values (5 fields), nx, ny at the hole points
+ *   loss_terms_out = (sum tx^2, sum ty^2) */
+int pinn_plate2d_traction_loss_grad(const float* params_flat, const int* layers, int n_layers,
+                                    const float* x, const float* y, const float* t, int64_t n,
+                                    const double lb[3], const double ub[3], int normalize,
+                                    const float* frozen_and_normals, const float weights[2],
+                                    float* loss_terms_out, float* grad_flat_out, int accumulate,
+                                    int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
+/* Replaces the pre-training losses loss_DIST / loss_PART (PLATE:194-215) and their gradients: a weighted sum of squares
+ * over streams and outputs of ONE net,  sum_{s,o} weights[s*n_out+o] * sum_n (Y[s][o][n] - targets[s][o][n])^2
+ * (targets SoA [5][n_out][n] or NULL = 0; weights is a host array of 5*n_out floats).
+ *   loss_terms_out[o] = sum_s (weights[s][o]/max|weights|) * sum_n (...)^2 */
+int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_layers,
+                          const float* x, const float* y, const float* t, int64_t n,
+                          const double lb[3], const double ub[3], int normalize,
+                          const float* targets, const float* weights,
+                          float* loss_terms_out, float* grad_flat_out, int accumulate,
+                          int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
 /* Replaces tf.train.AdamOptimizer's update (INF:131-133; TF1 rule: epsilon outside the bias
  * correction).  step is 1-based.  All arrays are length n_params, updated in place. */
 int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_flat, int64_t n_params,

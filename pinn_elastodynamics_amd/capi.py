@@ -49,6 +49,14 @@ class PinnLib:
         L.pinn_data_loss_grad.restype = i32
         L.pinn_wave2d_fields.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, i32, vp, sz, vp]
         L.pinn_wave2d_fields.restype = i32
+        L.pinn_net_streams.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, i32, vp, sz, vp]
+        L.pinn_net_streams.restype = i32
+        L.pinn_plate2d_loss_grad.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, f64, f64, f64, pf32, vp, vp, i32, i32, vp, sz, vp]
+        L.pinn_plate2d_loss_grad.restype = i32
+        L.pinn_plate2d_traction_loss_grad.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, pf32, vp, vp, i32, i32, vp, sz, vp]
+        L.pinn_plate2d_traction_loss_grad.restype = i32
+        L.pinn_stream_loss_grad.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, pf32, vp, vp, i32, i32, vp, sz, vp]
+        L.pinn_stream_loss_grad.restype = i32
         L.pinn_adam_step.argtypes = [vp, vp, vp, vp, i64, f64, f64, f64, f64, i64, vp]
         L.pinn_adam_step.restype = i32
 
@@ -116,6 +124,34 @@ class PinnLib:
         rc = self.lib.pinn_wave2d_fields(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
                                          int(bool(normalize)), fields_out, PREC[prec], ws, int(ws_bytes), stream)
         self.check(rc, "pinn_wave2d_fields")
+
+    def net_streams(self, params, layers, x, y, t, n, lb, ub, normalize, streams_out, prec, ws, ws_bytes, stream=0):
+        rc = self.lib.pinn_net_streams(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
+                                       int(bool(normalize)), streams_out, PREC[prec], ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_net_streams")
+
+    def plate2d_loss_grad(self, params, layers, x, y, t, n, lb, ub, normalize, frozen, E, mu, rho, term_weights, loss_out, grad_out,
+                          accumulate, prec, ws, ws_bytes, stream=0):
+        rc = self.lib.pinn_plate2d_loss_grad(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
+                                             int(bool(normalize)), frozen, float(E), float(mu), float(rho),
+                                             self._floats(term_weights, 5), loss_out, grad_out, int(bool(accumulate)), PREC[prec],
+                                             ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_plate2d_loss_grad")
+
+    def plate2d_traction_loss_grad(self, params, layers, x, y, t, n, lb, ub, normalize, aux, weights, loss_out, grad_out, accumulate,
+                                   prec, ws, ws_bytes, stream=0):
+        rc = self.lib.pinn_plate2d_traction_loss_grad(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb),
+                                                      self._d3(ub), int(bool(normalize)), aux, self._floats(weights, 2), loss_out,
+                                                      grad_out, int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_plate2d_traction_loss_grad")
+
+    def stream_loss_grad(self, params, layers, x, y, t, n, lb, ub, normalize, targets, weights, loss_out, grad_out, accumulate, prec,
+                         ws, ws_bytes, stream=0):
+        w = [float(v) for row in weights for v in row]
+        rc = self.lib.pinn_stream_loss_grad(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
+                                            int(bool(normalize)), targets, (C.c_float * len(w))(*w), loss_out, grad_out,
+                                            int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_stream_loss_grad")
 
     def adam_step(self, params, m, v, grad, n_params, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, stream=0):
         rc = self.lib.pinn_adam_step(params, m, v, grad, int(n_params), float(lr), float(beta1), float(beta2), float(eps),

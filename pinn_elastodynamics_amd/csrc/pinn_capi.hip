@@ -127,6 +127,9 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     for (int i = 0; i < 8; ++i) c.tw[i] = 0.0f;
     c.targets = nullptr;
     c.fields_out = nullptr;
+    c.aux = nullptr;
+    for (int i = 0; i < 5; ++i)
+        for (int o = 0; o < 8; ++o) c.w5[i][o] = 0.0f;
     c.prof_ms = nullptr;
     c.use_fused = g_use_fused;
     c.dbg_stamps = g_dbg_stamps;
@@ -225,6 +228,78 @@ int pinn_wave2d_fields(const float* params_flat, const int* layers, int n_layers
     if (!fields_out) return PINN_ERR_NULL;
     c.fields_out = fields_out;
     return impl->fields(c);
+}
+
+int pinn_net_streams(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t, int64_t n,
+                     const double lb[3], const double ub[3], int normalize, float* streams_out, int precision_mode, void* workspace,
+                     size_t ws_bytes, void* stream) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+    if (rc) return rc;
+    if (!streams_out) return PINN_ERR_NULL;
+    c.fields_out = streams_out;
+    return impl->streams(c);
+}
+
+int pinn_plate2d_loss_grad(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
+                           int64_t n, const double lb[3], const double ub[3], int normalize, const float* frozen_streams, double E,
+                           double mu, double rho, const float term_weights[5], float* loss_terms_out, float* grad_flat_out,
+                           int accumulate, int precision_mode, void* workspace, size_t ws_bytes, void* stream) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+    if (rc) return rc;
+    if (!frozen_streams || !term_weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
+    if (c.net.nout != 5) return PINN_ERR_LAYERS;
+    c.c1 = (float)(E / (1.0 - mu * mu));               // plane stress, PLATE:416-418
+    c.c2 = (float)(E * mu / (1.0 - mu * mu));
+    c.G = (float)(E / (2.0 * (1.0 + mu)));
+    c.rho = (float)rho;
+    for (int i = 0; i < 5; ++i) c.tw[i] = term_weights[i];
+    c.aux = frozen_streams;
+    c.loss_out = loss_terms_out;
+    c.grad_out = grad_flat_out;
+    c.accumulate = accumulate;
+    return impl->plate_loss_grad(c);
+}
+
+int pinn_plate2d_traction_loss_grad(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y,
+                                    const float* t, int64_t n, const double lb[3], const double ub[3], int normalize,
+                                    const float* frozen_and_normals, const float weights[2], float* loss_terms_out,
+                                    float* grad_flat_out, int accumulate, int precision_mode, void* workspace, size_t ws_bytes,
+                                    void* stream) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+    if (rc) return rc;
+    if (!frozen_and_normals || !weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
+    if (c.net.nout != 5) return PINN_ERR_LAYERS;
+    c.tw[0] = weights[0];
+    c.tw[1] = weights[1];
+    c.aux = frozen_and_normals;
+    c.loss_out = loss_terms_out;
+    c.grad_out = grad_flat_out;
+    c.accumulate = accumulate;
+    return impl->traction_loss_grad(c);
+}
+
+int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
+                          int64_t n, const double lb[3], const double ub[3], int normalize, const float* targets,
+                          const float* weights, float* loss_terms_out, float* grad_flat_out, int accumulate, int precision_mode,
+                          void* workspace, size_t ws_bytes, void* stream) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+    if (rc) return rc;
+    if (!weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
+    for (int s = 0; s < 5; ++s)
+        for (int o = 0; o < c.net.nout; ++o) c.w5[s][o] = weights[s * c.net.nout + o];
+    c.aux = targets;
+    c.loss_out = loss_terms_out;
+    c.grad_out = grad_flat_out;
+    c.accumulate = accumulate;
+    return impl->stream_loss_grad(c);
 }
 
 int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_flat, int64_t n_params, double lr, double beta1,

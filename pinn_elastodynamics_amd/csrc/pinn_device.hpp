@@ -102,7 +102,13 @@ struct PackedWeights {         // produced by repack_kernel, consumed by chain_k
     const u32x4* frags;        // fragment store, see frag_index()
 };
 
-enum { HEAD_WAVE = 0, HEAD_DATA = 1, HEAD_FIELDS = 2 };
+// HEAD_WAVE   : 4 streams, residuals of net_f_sig (INF:221-265)
+// HEAD_DATA   : 1 stream, sum_o w_o (Y_o - target_o)^2 (INF:111-118)
+// HEAD_FIELDS : forward only, writes all NS streams of the outputs
+// HEAD_PLATE  : 5 streams (value, x, y, t, tt), composite P + D*N with frozen D/P streams in `aux`, plane-stress residuals (PLATE:358-439)
+// HEAD_TRACTION: 1 stream, hole traction of the composite (PLATE:452-461); aux = D0[5], P0[5], nx, ny per point
+// HEAD_STREAMS: 5 streams, sum_{s,o} w[s][o] (Y[s][o] - target[s][o])^2 -- the D / P pre-training losses (PLATE:194-215)
+enum { HEAD_WAVE = 0, HEAD_DATA = 1, HEAD_FIELDS = 2, HEAD_PLATE = 3, HEAD_TRACTION = 4, HEAD_STREAMS = 5 };
 
 struct ChainArgs {
     NetDesc net;
@@ -122,7 +128,9 @@ struct ChainArgs {
     long S_tile_stride;        // in 16-bit elements
     long Z_tile_stride;
     float* loss_part;          // [total waves][8] per-wave partial sums of squares
-    float* fields_out;         // HEAD_FIELDS: [4*nout][n]  (Y, dY/dx, dY/dy, dY/dt)
+    float* fields_out;         // HEAD_FIELDS: [NS*nout][n]  (Y, dY/dx, dY/dy, dY/dt [, d2Y/dt2])
+    const float* aux;          // HEAD_PLATE: [2 nets (D,P)][5 streams][5 fields][n]; HEAD_TRACTION: [12][n]; HEAD_STREAMS: targets [5][nout][n] or null
+    float w5[5][8];            // HEAD_STREAMS: per (stream, output) weights, max-normalised
 };
 
 struct WgradArgs {
@@ -251,6 +259,8 @@ template <class Op, int SPLIT, int WIDTH, int NB, int NS, int HEAD>
 struct Chain {
     static constexpr int WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1, TP = 16 * NB;
     static constexpr int NPS = SPLIT == 3 ? 2 : 1;     // stored weight-fragment parts (see repack_kernel)
+    static constexpr bool SECOND = NS == 5;            // stream 4 = second time derivative (plate, PLATE:427-433)
+    static constexpr int NT = NS >= 4 ? 3 : 0;         // first-order tangent streams 1..NT
     static constexpr float INV_LS = 1.0f / Op::LO_SCALE;
     typedef PanelGeom<WIDTH, NB, NS, NP> PG;
     typedef FragIndex<WIDTH> FI;
@@ -344,7 +354,8 @@ struct Chain {
             }
     }
 
-    // reverse of (h = tanh z, hdot_k = (1-h^2) zdot_k):   INF:131-133 (gradient of TanhGrad)
+    // reverse of (h = tanh z, h_k = (1-h^2) z_k [, h_tt = (1-h^2) z_tt - 2 h h_t z_t]):   INF:131-133 (gradient of TanhGrad).
+    // Only post-activation state is needed:  d h_tt/d z = -2 h h_tt - 2 h_t^2 ,  d h_tt/d z_t = -4 h h_t.
     static __device__ __forceinline__ void act_bwd(const float (&st)[NS][NB][4], const f32x4 (&acc)[NS][NB],
                                                    const f32x4 (&accc)[NS][NB], float (&vals)[NS][NB][4]) {
 #pragma unroll
@@ -356,12 +367,20 @@ struct Chain {
                 const float hb = comb(acc[0][nb], accc[0][nb], r);
                 float dot = 0.0f;
 #pragma unroll
-                for (int s = 1; s < NS; ++s) {
+                for (int s = 1; s <= NT; ++s) {
                     const float hdb = comb(acc[s][nb], accc[s][nb], r);
                     dot += hdb * st[s][nb][r];
                     vals[s][nb][r] = sd * hdb;
                 }
-                vals[0][nb][r] = sd * hb - 2.0f * h * dot;
+                float zb = sd * hb - 2.0f * h * dot;
+                if constexpr (SECOND) {
+                    const float httb = comb(acc[4][nb], accc[4][nb], r);
+                    const float ht = st[3][nb][r], htt = st[4][nb][r];
+                    vals[4][nb][r] = sd * httb;
+                    vals[3][nb][r] -= 4.0f * h * ht * httb;
+                    zb += httb * (-2.0f * h * htt - 2.0f * ht * ht);
+                }
+                vals[0][nb][r] = zb;
             }
     }
 
@@ -381,7 +400,11 @@ struct Chain {
                     tanh_act(z, h, sd);
                     vals[0][nb][r] = h;
 #pragma unroll
-                    for (int s = 1; s < NS; ++s) vals[s][nb][r] = sd * (a.sx[s - 1] * w[s - 1]);
+                    for (int s = 1; s <= NT; ++s) vals[s][nb][r] = sd * (a.sx[s - 1] * w[s - 1]);
+                    if constexpr (SECOND) {                  // z_tt = 0 at the first layer: h_tt = -2 h h_t z_t
+                        const float zt = a.sx[2] * w[2];
+                        vals[4][nb][r] = -2.0f * h * vals[3][nb][r] * zt;
+                    }
                 }
             }
             emit<KS, MB>(Bn, vals, panel, WIDTH, c, q);
@@ -402,7 +425,11 @@ struct Chain {
                     tanh_act(comb(acc[0][nb], accc[0][nb], r) + bias[r], h, sd);
                     vals[0][nb][r] = h;
 #pragma unroll
-                    for (int s = 1; s < NS; ++s) vals[s][nb][r] = sd * comb(acc[s][nb], accc[s][nb], r);
+                    for (int s = 1; s <= NT; ++s) vals[s][nb][r] = sd * comb(acc[s][nb], accc[s][nb], r);
+                    if constexpr (SECOND) {                  // h_tt = (1-h^2) z_tt - 2 h h_t z_t
+                        const float zt = comb(acc[3][nb], accc[3][nb], r);
+                        vals[4][nb][r] = sd * comb(acc[4][nb], accc[4][nb], r) - 2.0f * h * vals[3][nb][r] * zt;
+                    }
                 }
             emit<KS, MB>(Bn, vals, panel, WIDTH, c, q);
             if constexpr (MB + 1 < WB) MbLoop<MB + 1>::fwd(Al, bl, lane, B, Bn, panel, c, q);
@@ -456,7 +483,7 @@ struct Chain {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = 0.0f;
-                            if (q == 0 && r < 3) v = (s == 0) ? xin[nb][r] : (r == s - 1 ? a.sx[r] : 0.0f);
+                            if (q == 0 && r < 3 && s <= 3) v = (s == 0) ? xin[nb][r] : (r == s - 1 ? a.sx[r] : 0.0f);
                             v0[s][nb][r] = v;
                         }
                 u32x4 dummy[NS][NB][1][NP];
@@ -496,7 +523,7 @@ struct Chain {
                         Y[s][nb][4 + r] = (q & 1) ? own : oth;
                     }
             // ---- head
-            float adj[NS][NB][8];     // dL/dY (s=0) and dL/d(dY/dx_k) (s=k+1) for the 8 padded outputs
+            float adj[NS][NB][8];     // dL/d(stream s of output o) for the 8 padded outputs
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const float vm = valid[nb] ? 1.0f : 0.0f;
@@ -542,6 +569,100 @@ struct Chain {
                     adj[3][nb][1] = g[3];
                     adj[3][nb][2] = -a.rho * g[0];
                     adj[3][nb][3] = -a.rho * g[1];
+                } else if constexpr (HEAD == HEAD_PLATE) {
+                    // composite F = P + D*N (PLATE:383-387) with product-rule derivatives, then net_f_sig PLATE:404-439
+                    // outputs (u,v,s11,s22,s12); streams (value, x, y, t, tt); aux = [D|P][stream][field][n]
+                    float D[5][5], F[5][5];
+#pragma unroll
+                    for (int st = 0; st < 5; ++st)
+#pragma unroll
+                        for (int o = 0; o < 5; ++o) {
+                            D[st][o] = a.aux[((long)(0 * 5 + st) * 5 + o) * a.n + pidx[nb]];
+                            F[st][o] = a.aux[((long)(1 * 5 + st) * 5 + o) * a.n + pidx[nb]];      // start from P
+                        }
+#pragma unroll
+                    for (int o = 0; o < 5; ++o) {
+                        const float n0 = Y[0][nb][o];
+                        F[0][o] += D[0][o] * n0;
+#pragma unroll
+                        for (int k = 1; k <= 3; ++k) F[k][o] += D[k][o] * n0 + D[0][o] * Y[k][nb][o];
+                        F[4][o] += D[4][o] * n0 + 2.0f * D[3][o] * Y[3][nb][o] + D[0][o] * Y[4][nb][o];
+                    }
+                    const float e11 = F[1][0], e22 = F[2][1], e12 = F[2][0] + F[1][1];
+                    float f[5];
+                    f[0] = F[1][2] + F[2][4] - a.rho * F[4][0];                       // f_u   PLATE:436
+                    f[1] = F[2][3] + F[1][4] - a.rho * F[4][1];                       // f_v   PLATE:437
+                    f[2] = F[0][2] - (a.c1 * e11 + a.c2 * e22);                       // f_s11 PLATE:421
+                    f[3] = F[0][3] - (a.c2 * e11 + a.c1 * e22);                       // f_s22 PLATE:423
+                    f[4] = F[0][4] - a.G * e12;                                       // f_s12 PLATE:422
+                    float g[5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) {
+                        if (q == 0) lsum[i] += vm * f[i] * f[i];
+                        g[i] = 2.0f * a.tw[i] * f[i] * vm;
+                    }
+                    float Fb[5][5];
+#pragma unroll
+                    for (int st = 0; st < 5; ++st)
+#pragma unroll
+                        for (int o = 0; o < 5; ++o) Fb[st][o] = 0.0f;
+                    Fb[0][2] = g[2];
+                    Fb[0][3] = g[3];
+                    Fb[0][4] = g[4];
+                    Fb[1][0] = -a.c1 * g[2] - a.c2 * g[3];
+                    Fb[2][1] = -a.c2 * g[2] - a.c1 * g[3];
+                    Fb[2][0] = -a.G * g[4];
+                    Fb[1][1] = -a.G * g[4];
+                    Fb[1][2] = g[0];
+                    Fb[2][4] = g[0];
+                    Fb[4][0] = -a.rho * g[0];
+                    Fb[2][3] = g[1];
+                    Fb[1][4] = g[1];
+                    Fb[4][1] = -a.rho * g[1];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int o = 0; o < 8; ++o) adj[s][nb][o] = 0.0f;
+#pragma unroll
+                    for (int o = 0; o < 5; ++o) {
+                        adj[0][nb][o] = Fb[0][o] * D[0][o] + Fb[1][o] * D[1][o] + Fb[2][o] * D[2][o] + Fb[3][o] * D[3][o] + Fb[4][o] * D[4][o];
+                        adj[1][nb][o] = Fb[1][o] * D[0][o];
+                        adj[2][nb][o] = Fb[2][o] * D[0][o];
+                        adj[3][nb][o] = Fb[3][o] * D[0][o] + 2.0f * Fb[4][o] * D[3][o];
+                        adj[4][nb][o] = Fb[4][o] * D[0][o];
+                    }
+                } else if constexpr (HEAD == HEAD_TRACTION) {
+                    // net_t PLATE:452-461 on the composite values; aux rows: D0[0..4], P0[5..9], nx[10], ny[11]
+                    float Fv[5], D0[5];
+#pragma unroll
+                    for (int o = 0; o < 5; ++o) {
+                        D0[o] = a.aux[(long)o * a.n + pidx[nb]];
+                        Fv[o] = a.aux[(long)(5 + o) * a.n + pidx[nb]] + D0[o] * Y[0][nb][o];
+                    }
+                    const float nx = a.aux[10L * a.n + pidx[nb]], ny = a.aux[11L * a.n + pidx[nb]];
+                    const float tx = Fv[2] * nx + Fv[4] * ny, ty = Fv[4] * nx + Fv[3] * ny;
+                    if (q == 0) {
+                        lsum[0] += vm * tx * tx;
+                        lsum[1] += vm * ty * ty;
+                    }
+                    const float gx = 2.0f * a.tw[0] * tx * vm, gy = 2.0f * a.tw[1] * ty * vm;
+#pragma unroll
+                    for (int o = 0; o < 8; ++o) adj[0][nb][o] = 0.0f;
+                    adj[0][nb][2] = gx * nx * D0[2];
+                    adj[0][nb][3] = gy * ny * D0[3];
+                    adj[0][nb][4] = (gx * ny + gy * nx) * D0[4];
+                } else if constexpr (HEAD == HEAD_STREAMS) {
+                    // sum_{s,o} w[s][o] (Y[s][o] - target[s][o])^2 ; lsum[o] accumulates the weight-normalised sum over streams
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int o = 0; o < 8; ++o) {
+                            float d = 0.0f;
+                            if (o < a.net.nout) d = Y[s][nb][o] - (a.aux ? a.aux[((long)s * a.net.nout + o) * a.n + pidx[nb]] : 0.0f);
+                            const float w = a.w5[s][o];
+                            if (q == 0) lsum[o] += vm * w * d * d;
+                            adj[s][nb][o] = 2.0f * w * d * vm;
+                        }
                 } else if constexpr (HEAD == HEAD_DATA) {
                     // loss_IC / loss_SRC / loss_NB / loss_FIX (INF:111-118, CONF:145-146): sum_o w_o (Y_o - target_o)^2
 #pragma unroll
@@ -552,7 +673,7 @@ struct Chain {
                         adj[0][nb][o] = 2.0f * a.tw[o] * d * vm;
                     }
                 } else {
-                    // predict (INF:337-347): write Y and the three tangents, [4*nout][n]
+                    // predict (INF:337-347): write Y and its tangent streams, [NS*nout][n]
                     if (q == 0 && valid[nb]) {
 #pragma unroll
                         for (int s = 0; s < NS; ++s)

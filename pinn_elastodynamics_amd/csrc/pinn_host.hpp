@@ -33,6 +33,9 @@ struct Call {
     const float* targets;
     // fields head
     float* fields_out;
+    // plate / traction / stream-target heads
+    const float* aux;
+    float w5[5][8];
     // optional per-kernel timing (host pointer, 4 floats: repack, chain, wgrad, reductions) -- makes the call synchronous
     float* prof_ms;
     unsigned long long* dbg_stamps;   // optional device buffer for the fused kernel's phase timestamps (128 x u64)
@@ -44,16 +47,22 @@ struct Impl {
     int (*data_loss_grad)(const Call&);
     int (*fields)(const Call&);
     size_t (*ws_bytes)(const NetDesc&, long n, int minimum);
+    // 5-stream family (second time derivative), compiled for the split-precision variants only
+    int (*plate_loss_grad)(const Call&);
+    int (*traction_loss_grad)(const Call&);
+    int (*stream_loss_grad)(const Call&);
+    int (*streams)(const Call&);
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 template <class Op, int SPLIT, int WIDTH>
 struct Host {
-    static constexpr int NB = WIDTH <= 64 ? 2 : 1;
+    // points per wave tile = 16*NB: two blocks for narrow nets, one when the register budget is tight (wide nets, 5 streams)
+    template <int NS>
+    static constexpr int nb() { return (WIDTH <= 64 && NS != 5) ? 2 : 1; }
     static constexpr int NP = SPLIT == 3 ? 2 : 1;
     static constexpr int NPS = SPLIT == 3 ? 2 : 1;    // stored weight-fragment parts
-    static constexpr int TP = 16 * NB;
     static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
     static constexpr int FUSED_GRID = 256;    // persistent workgroups of the fused kernel (one per MI355X CU)
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
@@ -69,6 +78,7 @@ struct Host {
 
     template <int NS>
     static void plan_fixed(const NetDesc& net, long n, Plan& p) {
+        constexpr int NB = nb<NS>(), TP = 16 * NB;
         typedef PanelGeom<WIDTH, NB, NS, NP> PG;
         size_t o = 0;
         p.w0p = o;
@@ -91,11 +101,20 @@ struct Host {
         p.ntiles = (nt + 1) & ~1L;
     }
 
-    static size_t ws_bytes(const NetDesc& net, long n, int minimum) {
+    template <int NS>
+    static size_t ws_bytes_ns(const NetDesc& net, long n, int minimum) {
         Plan p;
-        plan_fixed<4>(net, n, p);
+        plan_fixed<NS>(net, n, p);
         const long tiles = minimum ? (p.ntiles < MIN_TILES ? p.ntiles : MIN_TILES) : p.ntiles;
         return p.fixed_end + (size_t)tiles * (size_t)(p.s_tile + p.z_tile) * 2;
+    }
+    static size_t ws_bytes(const NetDesc& net, long n, int minimum) {
+        const size_t a = ws_bytes_ns<4>(net, n, minimum);
+        if constexpr (SPLIT == 3) {
+            const size_t b = ws_bytes_ns<5>(net, n, minimum);
+            return a > b ? a : b;
+        }
+        return a;
     }
 
     template <int NS>
@@ -151,6 +170,9 @@ struct Host {
         a.rho = c.rho;
         a.targets = c.targets;
         a.fields_out = c.fields_out;
+        a.aux = c.aux;
+        for (int i = 0; i < 5; ++i)
+            for (int o = 0; o < 8; ++o) a.w5[i][o] = 0.0f;
         a.S = nullptr;
         a.Z = nullptr;
         a.S_tile_stride = p.s_tile;
@@ -168,6 +190,7 @@ struct Host {
     // forward + reverse chain + weight gradient for one head (NS streams)
     template <int NS, int HEAD>
     static int loss_grad(const Call& c, int nterms) {
+        constexpr int NB = nb<NS>();
         Plan p;
         int rc = make_plan<NS>(c, p, true);
         if (rc) return rc;
@@ -194,6 +217,13 @@ struct Host {
         ChainArgs a;
         fill_common(c, p, a);
         for (int i = 0; i < 8; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
+        if (HEAD == HEAD_STREAMS) {
+            twmax = 0.0f;
+            for (int i = 0; i < 5; ++i)
+                for (int o = 0; o < 8; ++o) { const float v = c.w5[i][o] < 0 ? -c.w5[i][o] : c.w5[i][o]; if (v > twmax) twmax = v; }
+            for (int i = 0; i < 5; ++i)
+                for (int o = 0; o < 8; ++o) a.w5[i][o] = twmax > 0.0f ? c.w5[i][o] / twmax : 0.0f;
+        }
         char* b = static_cast<char*>(c.ws);
         a.S = reinterpret_cast<uint16_t*>(b + p.panels);
         a.Z = a.S + p.chunk_tiles * p.s_tile;
@@ -317,9 +347,10 @@ struct Host {
     }
     static int data_loss_grad(const Call& c) { return loss_grad<1, HEAD_DATA>(c, c.net.nout); }
 
-    static int fields(const Call& c) {
+    template <int NS>
+    static int fields_ns(const Call& c) {
         Plan p;
-        int rc = make_plan<4>(c, p, false);
+        int rc = make_plan<NS>(c, p, false);
         if (rc) return rc;
         rc = repack(c, p);
         if (rc) return rc;
@@ -328,12 +359,32 @@ struct Host {
         for (int i = 0; i < 8; ++i) a.tw[i] = 0.0f;
         a.tile0 = 0;
         a.ntiles = p.ntiles;
-        hipLaunchKernelGGL((chain_kernel<Op, SPLIT, WIDTH, NB, 4, HEAD_FIELDS>), dim3(chain_blocks(p.ntiles)), dim3(256), 0, c.stream, a);
+        hipLaunchKernelGGL((chain_kernel<Op, SPLIT, WIDTH, nb<NS>(), NS, HEAD_FIELDS>), dim3(chain_blocks(p.ntiles)), dim3(256), 0, c.stream, a);
         return (int)hipGetLastError();
+    }
+    static int fields(const Call& c) { return fields_ns<4>(c); }
+
+    // 5-stream family (plate): split-precision variants only
+    static int plate_loss_grad(const Call& c) {
+        if constexpr (SPLIT == 3) return loss_grad<5, HEAD_PLATE>(c, 5);
+        return PINN_ERR_PRECISION;
+    }
+    static int traction_loss_grad(const Call& c) {
+        if constexpr (SPLIT == 3) return loss_grad<1, HEAD_TRACTION>(c, 2);
+        return PINN_ERR_PRECISION;
+    }
+    static int stream_loss_grad(const Call& c) {
+        if constexpr (SPLIT == 3) return loss_grad<5, HEAD_STREAMS>(c, c.net.nout);
+        return PINN_ERR_PRECISION;
+    }
+    static int streams(const Call& c) {
+        if constexpr (SPLIT == 3) return fields_ns<5>(c);
+        return PINN_ERR_PRECISION;
     }
 
     static const Impl* impl() {
-        static const Impl I = {&wave_loss_grad, &data_loss_grad, &fields, &ws_bytes};
+        static const Impl I = {&wave_loss_grad, &data_loss_grad, &fields, &ws_bytes,
+                               &plate_loss_grad, &traction_loss_grad, &stream_loss_grad, &streams};
         return &I;
     }
 };

@@ -113,6 +113,60 @@ class HipEngine:
                                out.data_ptr(), self.precision, self._ws_ptr, self.ws_bytes, self._stream())
         return out
 
+    # ---- plate family (5 streams: value, d/dx, d/dy, d/dt, d2/dt2) --------------------------------------------------
+    def net_streams(self, params, x, y, t, lb, ub, normalize):
+        """Returns [5, n_out, n]: the net's outputs, their first derivatives and the second time derivative."""
+        n, nout = x.numel(), self.layers[-1]
+        for v in (x, y, t):
+            self._chk(v, n)
+        self._chk(params, self.n_params)
+        out = torch.empty((5, nout, n), dtype=torch.float32, device=self.device)
+        self.lib.net_streams(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize,
+                             out.data_ptr(), self.precision, self._ws_ptr, self.ws_bytes, self._stream())
+        return out
+
+    def _outs(self, grad_out, accumulate, loss_out):
+        if grad_out is None:
+            grad_out = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+            accumulate = False
+        if loss_out is None:
+            loss_out = torch.empty(8, dtype=torch.float32, device=self.device)
+        return grad_out, accumulate, loss_out
+
+    def plate_loss_grad(self, params, x, y, t, lb, ub, normalize, frozen, term_weights, E=20.0, mu=0.25, rho=1.0,
+                        grad_out=None, accumulate=False, loss_out=None):
+        """frozen: [2, 5, 5, n] streams of the distance and particular nets.  Returns (sumsq[5], grad wrt this net)."""
+        n = x.numel()
+        self._chk(frozen, 50 * n)
+        grad_out, accumulate, loss_out = self._outs(grad_out, accumulate, loss_out)
+        self.lib.plate2d_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize,
+                                   frozen.data_ptr(), E, mu, rho, term_weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate,
+                                   self.precision, self._ws_ptr, self.ws_bytes, self._stream())
+        return loss_out[:5], grad_out
+
+    def traction_loss_grad(self, params, x, y, t, lb, ub, normalize, aux, weights, grad_out=None, accumulate=False, loss_out=None):
+        """aux: [12, n] = D values, P values, nx, ny.  Returns ((sum tx^2, sum ty^2), grad)."""
+        n = x.numel()
+        self._chk(aux, 12 * n)
+        grad_out, accumulate, loss_out = self._outs(grad_out, accumulate, loss_out)
+        self.lib.plate2d_traction_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub,
+                                            normalize, aux.data_ptr(), weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate,
+                                            self.precision, self._ws_ptr, self.ws_bytes, self._stream())
+        return loss_out[:2], grad_out
+
+    def stream_loss_grad(self, params, x, y, t, lb, ub, normalize, targets, weights, grad_out=None, accumulate=False, loss_out=None):
+        """targets: [5, n_out, n] or None; weights: 5 x n_out nested list.  Returns (per-output normalised sums, grad)."""
+        n, nout = x.numel(), self.layers[-1]
+        tptr = 0
+        if targets is not None:
+            self._chk(targets, 5 * nout * n)
+            tptr = targets.data_ptr()
+        grad_out, accumulate, loss_out = self._outs(grad_out, accumulate, loss_out)
+        self.lib.stream_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize, tptr,
+                                  weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate, self.precision, self._ws_ptr,
+                                  self.ws_bytes, self._stream())
+        return loss_out[:nout], grad_out
+
     def adam_step(self, params, m, v, grad, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
         for a in (params, m, v, grad):
             self._chk(a, self.n_params)

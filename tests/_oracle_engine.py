@@ -4,6 +4,7 @@ import numpy as np
 import torch
 
 from oracle import pinn_oracle as po
+from oracle import plate_oracle as pl
 
 
 class OracleEngine:
@@ -52,6 +53,38 @@ class OracleEngine:
         out = po.wave2d_fields(self._np(params), self.layers, self._np(x), self._np(y), self._np(t), lb, ub, normalize)
         F = np.stack([out["Y"].T] + [d.T for d in out["dY"]])
         return torch.from_numpy(F.astype(np.float32))
+
+    def net_streams(self, params, x, y, t, lb, ub, normalize):
+        return torch.from_numpy(pl.net_streams(self._np(params), self.layers, self._np(x), self._np(y), self._np(t)).astype(np.float32))
+
+    def _put(self, g, ss, n, grad_out, accumulate, loss_out):
+        if grad_out is None:
+            grad_out = torch.zeros(self.n_params, dtype=torch.float32)
+            accumulate = False
+        if loss_out is None:
+            loss_out = torch.zeros(8, dtype=torch.float32)
+        gt = torch.from_numpy(g.astype(np.float32))
+        grad_out.copy_(grad_out + gt if accumulate else gt)
+        loss_out[:n].copy_(torch.from_numpy(np.asarray(ss, dtype=np.float32)))
+        return loss_out[:n], grad_out
+
+    def plate_loss_grad(self, params, x, y, t, lb, ub, normalize, frozen, term_weights, E=20.0, mu=0.25, rho=1.0,
+                        grad_out=None, accumulate=False, loss_out=None):
+        fr = self._np(frozen)
+        ss, g, _ = pl.plate_loss_grad(self._np(params), self.layers, self._np(x), self._np(y), self._np(t), fr[0], fr[1], E, mu, rho,
+                                      np.asarray(term_weights, dtype=np.float64))
+        return self._put(g, ss, 5, grad_out, accumulate, loss_out)
+
+    def traction_loss_grad(self, params, x, y, t, lb, ub, normalize, aux, weights, grad_out=None, accumulate=False, loss_out=None):
+        a = self._np(aux)
+        ss, g = pl.traction_loss_grad(self._np(params), self.layers, self._np(x), self._np(y), self._np(t), a[0:5], a[5:10], 0.1, float(weights[0]))
+        return self._put(g, ss, 2, grad_out, accumulate, loss_out)
+
+    def stream_loss_grad(self, params, x, y, t, lb, ub, normalize, targets, weights, grad_out=None, accumulate=False, loss_out=None):
+        w = np.asarray(weights, dtype=np.float64)
+        ss, g = pl.stream_loss_grad(self._np(params), self.layers, self._np(x), self._np(y), self._np(t),
+                                    None if targets is None else self._np(targets), w)
+        return self._put(g, ((w / np.abs(w).max()) * ss).sum(0), self.layers[-1], grad_out, accumulate, loss_out)
 
     def adam_step(self, params, m, v, grad, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
         th, mm, vv = po.adam_tf1_step(self._np(params), self._np(grad), self._np(m), self._np(v), step, lr, beta1, beta2, eps)

@@ -1,0 +1,56 @@
+"""Dev script: emulated plate-family entry points vs oracle/plate_oracle.py."""
+import sys, numpy as np
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tools')
+from oracle import pinn_oracle as po, plate_oracle as pl
+from pinn_elastodynamics_amd.capi import PinnLib
+lib = PinnLib('/root/repo/build/emu/libpinn_emu.so')
+def aligned(nbytes):
+    raw = np.zeros(nbytes + 256, dtype=np.uint8); off = (-raw.ctypes.data) % 256; return raw[off:off + nbytes]
+rel = lambda a, b: np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b)
+rng = np.random.default_rng(0)
+def mk(l):
+    W, b = po.xavier_init(l, rng); b = [0.2 * rng.standard_normal(x.shape) for x in b]; return po.pack_params(W, b)
+prec = 'f16x3'; LB = [0, 0, 0]; UB = [0.5, 0.5, 10]
+def run(lN, lD, n):
+    fN, fD, fP = mk(lN), mk(lD), mk(lD)
+    C = np.stack([rng.random(n) * 0.5, rng.random(n) * 0.5, rng.random(n) * 10], 1)
+    x, y, t = (C[:, k].astype(np.float32).copy() for k in range(3))
+    def streams(flat, layers):
+        wsb = lib.workspace_bytes(layers, n, prec); ws = aligned(wsb)
+        out = np.full((5, layers[-1], n), np.nan, np.float32); p32 = flat.astype(np.float32)
+        lib.net_streams(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, False, out.ctypes.data, prec, ws.ctypes.data, wsb)
+        return out
+    Dst, Pst = streams(fD, lD), streams(fP, lD)
+    Dref = pl.net_streams(fD, lD, C[:, 0], C[:, 1], C[:, 2]); Pref = pl.net_streams(fP, lD, C[:, 0], C[:, 1], C[:, 2])
+    print(f'streams D rel {rel(Dst, Dref):.2e}  per stream', ' '.join(f'{rel(Dst[i], Dref[i]):.1e}' for i in range(5)))
+    tw = np.array([10, 10, 10, 10, 10.]) / n
+    ss, g, f = pl.plate_loss_grad(fN, lN, C[:, 0], C[:, 1], C[:, 2], Dref, Pref, term_weights=tw)
+    frozen = np.ascontiguousarray(np.stack([Dref, Pref]).astype(np.float32))
+    wsb = lib.workspace_bytes(lN, n, prec); ws = aligned(wsb)
+    p32 = fN.astype(np.float32); loss = np.full(8, np.nan, np.float32); grad = np.full(p32.size, np.nan, np.float32)
+    lib.plate2d_loss_grad(p32.ctypes.data, lN, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, False, frozen.ctypes.data, 20.0, 0.25, 1.0, tw,
+                          loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+    print(f'plate {lN[1]}x{len(lN)-2} n={n}: loss rel {rel(loss[:5], ss):.2e} grad rel {rel(grad, g):.2e}')
+    # traction
+    th = rng.random(n) * np.pi / 2; H = np.stack([0.1 * np.cos(th), 0.1 * np.sin(th), rng.random(n) * 10], 1)
+    hx, hy, ht = (H[:, k].astype(np.float32).copy() for k in range(3))
+    DH = pl.net_streams(fD, lD, H[:, 0], H[:, 1], H[:, 2])[0]; PH = pl.net_streams(fP, lD, H[:, 0], H[:, 1], H[:, 2])[0]
+    ssh, gh = pl.traction_loss_grad(fN, lN, H[:, 0], H[:, 1], H[:, 2], DH, PH, weight=10.0 / n)
+    aux = np.ascontiguousarray(np.concatenate([DH, PH, (-H[:, 0] / 0.1)[None], (-H[:, 1] / 0.1)[None]]).astype(np.float32))
+    loss2 = np.full(8, np.nan, np.float32); grad2 = np.full(p32.size, np.nan, np.float32)
+    lib.plate2d_traction_loss_grad(p32.ctypes.data, lN, hx.ctypes.data, hy.ctypes.data, ht.ctypes.data, n, LB, UB, False, aux.ctypes.data, [10.0 / n, 10.0 / n],
+                                   loss2.ctypes.data, grad2.ctypes.data, False, prec, ws.ctypes.data, wsb)
+    print(f'traction: loss rel {rel(loss2[:2], ssh):.2e} grad rel {rel(grad2, gh):.2e}')
+    # stream targets on the D net (loss_DIST-like): value targets on all outputs + dt of outputs 0,1
+    tg = rng.standard_normal((5, 5, n)); w = np.zeros((5, 5)); w[0, :] = 1000.0 / n; w[3, 0] = w[3, 1] = 1000.0 / n
+    ss3, g3 = pl.stream_loss_grad(fD, lD, C[:, 0], C[:, 1], C[:, 2], tg, w)
+    tg32 = np.ascontiguousarray(tg.astype(np.float32)); pD = fD.astype(np.float32)
+    wsb = lib.workspace_bytes(lD, n, prec); ws = aligned(wsb)
+    loss3 = np.full(8, np.nan, np.float32); grad3 = np.full(pD.size, np.nan, np.float32)
+    lib.stream_loss_grad(pD.ctypes.data, lD, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, False, tg32.ctypes.data, w, loss3.ctypes.data, grad3.ctypes.data,
+                         False, prec, ws.ctypes.data, wsb)
+    ref3 = ((w / w.max()) * ss3).sum(0)
+    print(f'stream-loss: loss rel {rel(loss3[:5], ref3):.2e} grad rel {rel(grad3, g3):.2e}')
+run([3, 20, 20, 20, 5], [3, 10, 10, 5], 50)
+run([3] + 3 * [70] + [5], [3] + 4 * [20] + [5], 24)
+run([3] + 8 * [64] + [5], [3] + 4 * [20] + [5], 40)
