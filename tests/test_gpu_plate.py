@@ -96,7 +96,7 @@ def test_plate_reference_weights_golden(dev, golden_dir):
         for s in range(5):
             assert rel(st[k][s].cpu().numpy(), ref[s]) < 1e-4, (k, s)
     n = X.shape[0]
-    tw = [10.0 / n] * 5
+    tw = [1.0 / n] * 5                                  # the weights oracle/make_golden.py used
     frozen = torch.stack([to_dev(g["D_streams"], dev), to_dev(g["P_streams"], dev)]).contiguous()
     ss, gr = eng["uv"].plate_loss_grad(flat["uv"], x, y, t, LB, UB, False, frozen, tw)
     assert rel(ss.cpu().numpy(), g["sumsq"]) < 2e-2
@@ -105,7 +105,7 @@ def test_plate_reference_weights_golden(dev, golden_dir):
     D0 = eng["dist"].net_streams(flat["dist"], hx, hy, ht, LB, UB, False)[0]
     P0 = eng["part"].net_streams(flat["part"], hx, hy, ht, LB, UB, False)[0]
     aux = torch.cat([D0, P0, (-hx / 0.1)[None], (-hy / 0.1)[None]]).contiguous()
-    ssh, gh = eng["uv"].traction_loss_grad(flat["uv"], hx, hy, ht, LB, UB, False, aux, [10.0 / H.shape[0]] * 2)
+    ssh, gh = eng["uv"].traction_loss_grad(flat["uv"], hx, hy, ht, LB, UB, False, aux, [1.0 / H.shape[0]] * 2)
     assert rel(ssh.cpu().numpy(), g["hole_sumsq"]) < 2e-2
     assert rel(gh.cpu().numpy(), g["hole_grad"]) < 5e-2
 
