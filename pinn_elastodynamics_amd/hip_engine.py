@@ -35,6 +35,8 @@ class HipEngine:
         if self.lib.supported_width(self.layers[1]) == 0:
             raise PinnLibError(f"hidden width {self.layers[1]} is not supported by the compiled kernels")
         want = workspace_bytes if workspace_bytes is not None else self.lib.workspace_bytes(self.layers, max_points, precision)
+        if workspace_bytes is None:
+            want = min(want, 8 << 30)      # larger point sets are walked in several passes; 8 GiB already amortises the launches
         want = max(want, self.lib.min_workspace_bytes(self.layers, precision))
         if want == 0:
             raise PinnLibError(f"no kernel variant for layers={self.layers} precision={precision}")

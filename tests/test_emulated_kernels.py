@@ -129,3 +129,55 @@ def test_adam_emulated(emu):
         g32 = g.astype(np.float32)
         emu.adam_step(a.ctypes.data, b.ctypes.data, c.ctypes.data, g32.ctypes.data, P, 1e-3, step)
     assert rel(a, th) < 1e-6
+
+
+# ---- plate family (5-stream chain kernels) -------------------------------------------------------------------------
+@pytest.mark.parametrize("lN,lD,n", [([3, 20, 20, 20, 5], [3, 10, 10, 5], 50),          # reference dist/part widths (PLATE:700-702)
+                                     ([3] + 3 * [70] + [5], [3] + 4 * [20] + [5], 24)])  # reference uv width (padded to 96)
+def test_emulated_plate_entry_points(emu, lN, lD, n):
+    from oracle import plate_oracle as pl
+    prec, LBp, UBp = "f16x3", [0, 0, 0], [0.5, 0.5, 10]
+    rng = np.random.default_rng(0)
+
+    def mk(l):
+        W, b = po.xavier_init(l, rng)
+        return po.pack_params(W, [0.2 * rng.standard_normal(x.shape) for x in b])
+
+    fN, fD, fP = mk(lN), mk(lD), mk(lD)
+    C = np.stack([rng.random(n) * 0.5, rng.random(n) * 0.5, rng.random(n) * 10], 1)
+    x, y, t = (C[:, k].astype(np.float32).copy() for k in range(3))
+    wsb = max(emu.workspace_bytes(lN, n, prec), emu.workspace_bytes(lD, n, prec))
+    ws = aligned(wsb)
+    Dref, Pref = pl.net_streams(fD, lD, C[:, 0], C[:, 1], C[:, 2]), pl.net_streams(fP, lD, C[:, 0], C[:, 1], C[:, 2])
+    out = np.full((5, 5, n), np.nan, np.float32)
+    pD = fD.astype(np.float32)
+    emu.net_streams(pD.ctypes.data, lD, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, out.ctypes.data, prec, ws.ctypes.data, wsb)
+    for s in range(5):
+        assert rel(out[s], Dref[s]) < 2e-6, s
+    tw = np.array([10, 7, 13, 9, 11.0]) / n
+    ss, g, _ = pl.plate_loss_grad(fN, lN, C[:, 0], C[:, 1], C[:, 2], Dref, Pref, term_weights=tw)
+    frozen = np.ascontiguousarray(np.stack([Dref, Pref]).astype(np.float32))
+    pN = fN.astype(np.float32)
+    loss, grad = np.full(8, np.nan, np.float32), np.full(pN.size, np.nan, np.float32)
+    emu.plate2d_loss_grad(pN.ctypes.data, lN, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, frozen.ctypes.data, 20.0, 0.25, 1.0,
+                          tw, loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+    assert rel(loss[:5], ss) < 2e-6 and rel(grad, g) < 2e-6
+    th = rng.random(n) * np.pi / 2
+    H = np.stack([0.1 * np.cos(th), 0.1 * np.sin(th), rng.random(n) * 10], 1)
+    hx, hy, ht = (H[:, k].astype(np.float32).copy() for k in range(3))
+    DH, PH = pl.net_streams(fD, lD, H[:, 0], H[:, 1], H[:, 2])[0], pl.net_streams(fP, lD, H[:, 0], H[:, 1], H[:, 2])[0]
+    ssh, gh = pl.traction_loss_grad(fN, lN, H[:, 0], H[:, 1], H[:, 2], DH, PH, weight=10.0 / n)
+    aux = np.ascontiguousarray(np.concatenate([DH, PH, (-H[:, 0] / 0.1)[None], (-H[:, 1] / 0.1)[None]]).astype(np.float32))
+    emu.plate2d_traction_loss_grad(pN.ctypes.data, lN, hx.ctypes.data, hy.ctypes.data, ht.ctypes.data, n, LBp, UBp, False, aux.ctypes.data,
+                                   [10.0 / n] * 2, loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+    assert rel(loss[:2], ssh) < 2e-6 and rel(grad, gh) < 2e-6
+    tg = rng.standard_normal((5, 5, n))
+    w = np.zeros((5, 5))
+    w[0, :] = 1000.0 / n
+    w[3, 0] = w[3, 1] = 500.0 / n
+    s3, g3 = pl.stream_loss_grad(fD, lD, C[:, 0], C[:, 1], C[:, 2], tg, w)
+    tg32 = np.ascontiguousarray(tg.astype(np.float32))
+    gradD = np.full(pD.size, np.nan, np.float32)
+    emu.stream_loss_grad(pD.ctypes.data, lD, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, tg32.ctypes.data, w, loss.ctypes.data,
+                         gradD.ctypes.data, False, prec, ws.ctypes.data, wsb)
+    assert rel(loss[:5], ((w / w.max()) * s3).sum(0)) < 2e-6 and rel(gradD, g3) < 2e-6
