@@ -2,9 +2,13 @@
 // decoding into pinn::Call, and dispatch to the kernel family for (precision_mode, hidden width).
 #include "pinn_host.hpp"
 
+#ifndef PINN_VARIANTS_DEF
+#define PINN_VARIANTS_DEF "pinn_variants.def"     // experiments (tools/exp_build.sh) build a one-variant library
+#endif
+
 namespace pinn {
 #define PINN_VARIANT(op, split, width) const Impl* impl_##op##_##split##_##width();
-#include "pinn_variants.def"
+#include PINN_VARIANTS_DEF
 #undef PINN_VARIANT
 
 static const Impl* find_impl(int precision_mode, int width) {
@@ -19,7 +23,7 @@ static const Impl* find_impl(int precision_mode, int width) {
     }
     auto same = [](const char* a, const char* b) { while (*a && *a == *b) { ++a; ++b; } return *a == *b; };
 #define PINN_VARIANT(o, s, w) if (same(op, #o) && split == s && width == w) return impl_##o##_##s##_##w();
-#include "pinn_variants.def"
+#include PINN_VARIANTS_DEF
 #undef PINN_VARIANT
     return nullptr;
 }

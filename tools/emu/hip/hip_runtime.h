@@ -235,6 +235,7 @@ inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 
 template <class T>
 inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

@@ -3,13 +3,15 @@ import sys, ctypes, numpy as np, torch
 sys.path.insert(0, '/root/repo' if __import__('os').path.exists('/root/repo/bench.py') else '.')
 from oracle import pinn_oracle as po
 from pinn_elastodynamics_amd.hip_engine import HipEngine
-prec = sys.argv[1] if len(sys.argv) > 1 else 'f16x3'
+prec = 'f16x3'
+import os
+libp = os.path.join('build/exp', sys.argv[1], 'libpinn_hip.so') if len(sys.argv) > 1 else None
 dev = torch.device('cuda:0'); NL = 8
 layers = [3] + NL * [64] + [7]
 rng = np.random.default_rng(0); Ws, bs = po.xavier_init(layers, rng); flat = po.pack_params(Ws, bs)
 n = 2_000_000
 X = np.random.default_rng(1).random((n, 3)) * np.array([30, 30, 20.])
-eng = HipEngine(layers, precision=prec, device=dev, max_points=1 << 18)
+eng = HipEngine(layers, precision=prec, device=dev, max_points=1 << 18, **({'lib_path': libp} if libp else {}))
 eng.lib.lib.pinn_debug_set_stamp_buffer.argtypes = [ctypes.c_void_p]
 stamps = torch.zeros(128, dtype=torch.int64, device=dev)
 theta = torch.from_numpy(flat.astype(np.float32)).to(dev)

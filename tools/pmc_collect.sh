@@ -1,0 +1,29 @@
+#!/bin/bash
+# Dev tool (GPU box): per-kernel PMC counters of an experiment library's fused launch, several passes of <= 4 counters.
+#   tools/pmc_collect.sh NAME      (library build/exp/NAME/libpinn_hip.so; output gpurun_out/pmc_NAME/)
+NAME=$1
+OUT=$PWD/gpurun_out/pmc_$NAME
+mkdir -p $OUT
+cd /tmp; export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
+           "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" \
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_IFETCH"; do
+  i=$((i+1))
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p -- python $GRAFT_REPO_ROOT/tools/exp_run.py $NAME > $OUT/p$i.log 2>&1
+done
+python - <<PY
+import csv, glob, collections
+acc = collections.defaultdict(list)
+for f in glob.glob('$OUT/p*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'fused' in r['Kernel_Name'] and int(r['Grid_Size']) >= 256 * 512:
+            acc[r['Counter_Name']].append(float(r['Counter_Value']))
+with open('$OUT/summary.txt', 'w') as o:
+    for k in sorted(acc):
+        v = acc[k]
+        # the 2M-point launches are the largest values; take the median of the top half
+        v = sorted(v)[len(v) // 2:]
+        line = f'{k:32s} {sorted(v)[len(v)//2]:.4e}  (n={len(acc[k])})'
+        print(line); o.write(line + '\n')
+PY
