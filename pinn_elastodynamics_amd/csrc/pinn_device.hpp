@@ -851,14 +851,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 // small reductions / optimizer
 // ------------------------------------------------------------------------------------------
 // grad[p] = (accumulate ? grad[p] : 0) + scale * sum_c partial[c][p]
+// A block owns 64 parameters; its 4 waves each sum every 4th partial with four independent accumulators (the loop is
+// latency-bound otherwise), then the 16 sub-sums are combined in a fixed order: deterministic, no atomics.
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* partial, int nchunks, int nparams, float scale,
                                                           float* grad, int accumulate) {
-    const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= nparams) return;
-    float s = 0.0f;
-    for (int cidx = 0; cidx < nchunks; ++cidx) s += partial[(long)cidx * nparams + p];
-    grad[p] = (accumulate ? grad[p] : 0.0f) + scale * s;
+    __shared__ float sub[4][64];
+    const int pl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long p = (long)blockIdx.x * 64 + pl;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (p < nparams) {
+        int cidx = sl;
+        for (; cidx + 12 < nchunks; cidx += 16) {
+            s0 += partial[(long)cidx * nparams + p];
+            s1 += partial[(long)(cidx + 4) * nparams + p];
+            s2 += partial[(long)(cidx + 8) * nparams + p];
+            s3 += partial[(long)(cidx + 12) * nparams + p];
+        }
+        for (; cidx < nchunks; cidx += 4) s0 += partial[(long)cidx * nparams + p];
+    }
+    sub[sl][pl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && p < nparams) {
+        const float s = (sub[0][pl] + sub[1][pl]) + (sub[2][pl] + sub[3][pl]);
+        grad[p] = (accumulate ? grad[p] : 0.0f) + scale * s;
+    }
 }
 
 // loss_terms[i] (+)= sum over waves of loss_part[w][i]   (one block of 256 threads: 32 lanes per term, nterms <= 8)

@@ -257,7 +257,7 @@ struct Host {
             toc(2);
         }
         tic();
-        hipLaunchKernelGGL((reduce_grad_kernel<0>), dim3((c.net.nparams + 255) / 256), dim3(256), 0, c.stream, (const float*)w.partial,
+        hipLaunchKernelGGL((reduce_grad_kernel<0>), dim3((c.net.nparams + 63) / 64), dim3(256), 0, c.stream, (const float*)w.partial,
                            (int)NCHUNK, c.net.nparams, twmax, c.grad_out, c.accumulate);
         rc = (int)hipGetLastError();
         toc(3);
@@ -312,7 +312,7 @@ struct Host {
             }
             hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * 4, 7, c.loss_out, 0);
             if ((rc = (int)hipGetLastError())) return rc;
-            hipLaunchKernelGGL((reduce_grad_kernel<0>), dim3((c.net.nparams + 255) / 256), dim3(256), 0, c.stream, (const float*)a.partial,
+            hipLaunchKernelGGL((reduce_grad_kernel<0>), dim3((c.net.nparams + 63) / 64), dim3(256), 0, c.stream, (const float*)a.partial,
                                grid, c.net.nparams, twmax, c.grad_out, c.accumulate);
             return (int)hipGetLastError();
         } else {
