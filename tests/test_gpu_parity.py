@@ -208,6 +208,31 @@ def test_full_size_properties(dev):
     assert rel(l_s.cpu().numpy(), ss) < 2e-5 and rel(g_s.cpu().numpy(), g) < 2e-5
 
 
+def test_sixteen_million_points_additivity(dev):
+    """BASELINE config 4 size (8x64, 16M points, one GPU): the sums over the whole set equal the sum over eight 2M shards, i.e.
+    the persistent accumulators and the two-stage reductions hold up at the largest single-GPU configuration."""
+    layers = [3] + 8 * [64] + [7]
+    Ws, bs, _ = make_net(layers, 8, bias=0.1)
+    n, k = 16_000_000, 8
+    theta = to_dev(po.pack_params(Ws, bs), dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(5)
+    xs = [torch.rand(n, device=dev, generator=gen) * s for s in (30.0, 30.0, 20.0)]
+    eng = engine(layers, "f16x3", dev, 1 << 18)
+    tw = np.ones(7) / n
+    l_all, g_all = eng.wave_loss_grad(theta, *xs, LB, UB, True, tw)
+    l_all, g_all = l_all.clone(), g_all.clone()
+    l_sum, g_sum = torch.zeros_like(l_all), torch.zeros_like(g_all)
+    for i in range(k):
+        sl = slice(i * n // k, (i + 1) * n // k)
+        l, g = eng.wave_loss_grad(theta, *(v[sl] for v in xs), LB, UB, True, tw)
+        l_sum += l
+        g_sum += g
+    torch.cuda.synchronize()
+    assert torch.isfinite(g_all).all()
+    assert rel(l_sum.cpu().numpy(), l_all.cpu().numpy()) < 1e-5 and rel(g_sum.cpu().numpy(), g_all.cpu().numpy()) < 1e-4
+
+
 def test_error_paths(dev):
     from pinn_elastodynamics_amd.capi import PinnLib, PinnLibError
     lib = PinnLib()

@@ -145,3 +145,38 @@ def test_plate_model_on_device(dev, golden_dir, tmp_path):
     for j, tol in zip(range(5), (0.03, 0.05, 0.02, 0.12, 0.06)):
         r = rel(pred[j][:, 0], fem[:, 3 + j])
         assert r < tol, (j, r)
+
+
+def test_plate_full_size_properties(dev):
+    """BASELINE config 3 size (8x64 uv net + frozen 4x20 D / P nets, 2M points): additivity over a split of the point set,
+    linearity of the gradient in the term weights, and an oracle spot check on the first 10k points."""
+    lN, lD = [3] + 8 * [64] + [5], [3] + 4 * [20] + [5]
+    rng = np.random.default_rng(21)
+    fN, fD, fP = rand_net(lN, rng), rand_net(lD, rng), rand_net(lD, rng)
+    n = 2_000_000
+    C = np.stack([rng.random(n) * 0.5, rng.random(n) * 0.5, rng.random(n) * 10], 1)
+    xs = [to_dev(C[:, k], dev) for k in range(3)]
+    eN, eD = engine(lN, dev, 1 << 18), engine(lD, dev, 1 << 18)
+    thN = to_dev(fN, dev)
+    frozen = torch.stack([eD.net_streams(to_dev(fD, dev), *xs, LB, UB, False), eD.net_streams(to_dev(fP, dev), *xs, LB, UB, False)]).contiguous()
+    tw = np.array([1.0, 1.0, 1.0, 1.0, 1.0]) * 10.0 / n
+    l_all, g_all = eN.plate_loss_grad(thN, *xs, LB, UB, False, frozen, tw.tolist())
+    l_all, g_all = l_all.clone(), g_all.clone()
+    h = 777_777
+    parts = []
+    for sl in (slice(0, h), slice(h, n)):
+        l, g = eN.plate_loss_grad(thN, *(v[sl].contiguous() for v in xs), LB, UB, False, frozen[:, :, :, sl].contiguous(), tw.tolist())
+        parts.append((l.clone(), g.clone()))
+    assert rel((parts[0][0] + parts[1][0]).cpu().numpy(), l_all.cpu().numpy()) < 1e-5
+    assert rel((parts[0][1] + parts[1][1]).cpu().numpy(), g_all.cpu().numpy()) < 1e-4
+    # gradient is linear in the term weights: g(w) = g(w1) + g(w2) for w = w1 + w2
+    w1, w2 = tw * np.array([1, 0, 1, 0, 0.5]), tw * np.array([0, 1, 0, 1, 0.5])
+    g1 = eN.plate_loss_grad(thN, *xs, LB, UB, False, frozen, w1.tolist())[1].clone()
+    g2 = eN.plate_loss_grad(thN, *xs, LB, UB, False, frozen, w2.tolist())[1].clone()
+    assert rel((g1 + g2).cpu().numpy(), g_all.cpu().numpy()) < 1e-4
+    m = 10000
+    Dst, Pst = pl.net_streams(fD, lD, C[:m, 0], C[:m, 1], C[:m, 2]), pl.net_streams(fP, lD, C[:m, 0], C[:m, 1], C[:m, 2])
+    assert rel(frozen[0, :, :, :m].cpu().numpy(), Dst) < 2e-5
+    ss, g, _ = pl.plate_loss_grad(fN, lN, C[:m, 0], C[:m, 1], C[:m, 2], Dst, Pst, term_weights=np.full(5, 10.0 / m))
+    l_s, g_s = eN.plate_loss_grad(thN, *(v[:m].contiguous() for v in xs), LB, UB, False, frozen[:, :, :, :m].contiguous(), [10.0 / m] * 5)
+    assert rel(l_s.cpu().numpy(), ss) < 5e-5 and rel(g_s.cpu().numpy(), g) < 5e-5
