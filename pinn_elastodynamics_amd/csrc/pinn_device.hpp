@@ -743,12 +743,18 @@ __global__ __launch_bounds__(256) void chain_kernel(const ChainArgs a) {
 
 // ------------------------------------------------------------------------------------------
 // weight-gradient kernel:  Wbar_l[in,out] = sum_tiles sum_streams S_l[in, pts] . Z_l[out, pts]^T
-// grid = (chunks, nl+1); wave w of a block owns in-blocks w, w+4, ...; contraction over points
+// grid = (chunks, nl+1); wave w of a block owns in-blocks w, w+NW, ...; contraction over points
 // (32 per MFMA k-step) read straight from the [feature][point] panels -- no LDS.
 // ------------------------------------------------------------------------------------------
+// waves per weight-gradient block: 8 for the 128-wide variant so that a wave owns ONE in-block (with 4 waves the
+// 2 x 8 accumulator blocks, main + correction, spilled 629 VGPRs and the kernel ran 6x slower than the 160-wide one)
+template <int WIDTH>
+struct WgradCfg { static constexpr int NW = WIDTH == 128 ? 8 : 4; };
+
 template <class Op, int SPLIT, int WIDTH, int NB, int NS>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
-    constexpr int WB = WIDTH / 16, NP = SPLIT == 3 ? 2 : 1, TP = 16 * NB, IBW = (WB + 3) / 4;
+__global__ __launch_bounds__(64 * WgradCfg<WIDTH>::NW) void wgrad_kernel(const WgradArgs a) {
+    constexpr int WB = WIDTH / 16, NP = SPLIT == 3 ? 2 : 1, TP = 16 * NB, NW = WgradCfg<WIDTH>::NW, IBW = (WB + NW - 1) / NW;
+    constexpr int OBN = WB, ob0 = 0;
     constexpr float INV_LS = 1.0f / Op::LO_SCALE;
     typedef PanelGeom<WIDTH, NB, NS, NP> PG;
     const int l = blockIdx.y, nl = a.net.nl;
@@ -757,9 +763,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int rowsS = l == 0 ? 16 : WIDTH, rowsZ = l == nl ? 16 : WIDTH;
     const int real_in = l == 0 ? 3 : a.net.h, real_out = l == nl ? a.net.nout : a.net.h;
 
-    f32x4 acc[IBW][WB], accc[IBW][WB], bacc[WB], baccc[WB];
+    f32x4 acc[IBW][OBN], accc[IBW][OBN], bacc[OBN], baccc[OBN];
 #pragma unroll
-    for (int ob = 0; ob < WB; ++ob) {
+    for (int ob = 0; ob < OBN; ++ob) {
         bacc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
         baccc[ob] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -778,23 +784,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         for (int s = 0; s < NS; ++s) {
             const uint16_t* Sp = a.S + tile * a.S_tile_stride + PG::s_off(l) + (long)(s * NP) * rowsS * TP + col0;
             const uint16_t* Zp = a.Z + tile * a.Z_tile_stride + PG::z_off(l) + (long)(s * NP) * rowsZ * TP + col0;
-            u32x4 Zh[WB], Zl[WB];
+            u32x4 Zh[OBN], Zl[OBN];
 #pragma unroll
-            for (int ob = 0; ob < WB; ++ob)
-                if (ob < OB) {
-                    Zh[ob] = *reinterpret_cast<const u32x4*>(Zp + (long)(16 * ob + c) * TP);
-                    if (NP == 2) Zl[ob] = *reinterpret_cast<const u32x4*>(Zp + (long)rowsZ * TP + (long)(16 * ob + c) * TP);
+            for (int ob = 0; ob < OBN; ++ob)
+                if (ob0 + ob < OB) {
+                    Zh[ob] = *reinterpret_cast<const u32x4*>(Zp + (long)(16 * (ob0 + ob) + c) * TP);
+                    if (NP == 2) Zl[ob] = *reinterpret_cast<const u32x4*>(Zp + (long)rowsZ * TP + (long)(16 * (ob0 + ob) + c) * TP);
                 }
 #pragma unroll
             for (int i = 0; i < IBW; ++i) {
-                const int ib = wave + 4 * i;
+                const int ib = wave + NW * i;
                 if (ib < IB) {
                     const u32x4 Ah = *reinterpret_cast<const u32x4*>(Sp + (long)(16 * ib + c) * TP);
                     u32x4 Al = {0u, 0u, 0u, 0u};
                     if (NP == 2) Al = *reinterpret_cast<const u32x4*>(Sp + (long)rowsS * TP + (long)(16 * ib + c) * TP);
 #pragma unroll
-                    for (int ob = 0; ob < WB; ++ob)
-                        if (ob < OB) {
+                    for (int ob = 0; ob < OBN; ++ob)
+                        if (ob0 + ob < OB) {
                             acc[i][ob] = Op::mfma(Ah, Zh[ob], acc[i][ob]);
                             if (NP == 2) {
                                 accc[i][ob] = Op::mfma(Ah, Zl[ob], accc[i][ob]);
@@ -805,8 +811,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             }
             if (s == 0 && wave == 0) {   // bias gradient: ones^T . Z (value stream)
 #pragma unroll
-                for (int ob = 0; ob < WB; ++ob)
-                    if (ob < OB) {
+                for (int ob = 0; ob < OBN; ++ob)
+                    if (ob0 + ob < OB) {
                         bacc[ob] = Op::mfma(ones, Zh[ob], bacc[ob]);
                         if (NP == 2) baccc[ob] = Op::mfma(ones, Zl[ob], baccc[ob]);
                     }
@@ -816,14 +822,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     float* part = a.partial + (long)blockIdx.x * a.net.nparams;
 #pragma unroll
     for (int i = 0; i < IBW; ++i) {
-        const int ib = wave + 4 * i;
+        const int ib = wave + NW * i;
         if (ib < IB) {
 #pragma unroll
-            for (int ob = 0; ob < WB; ++ob)
-                if (ob < OB) {
+            for (int ob = 0; ob < OBN; ++ob)
+                if (ob0 + ob < OB) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int in = 16 * ib + 4 * q + r, out = 16 * ob + c;
+                        const int in = 16 * ib + 4 * q + r, out = 16 * (ob0 + ob) + c;
                         if (in < real_in && out < real_out) {
                             const float v = NP == 2 ? acc[i][ob][r] + accc[i][ob][r] * INV_LS : acc[i][ob][r];
                             float* dst = part + a.net.w_off[l] + in * real_out + out;
@@ -835,9 +841,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
     if (wave == 0 && q == 0) {
 #pragma unroll
-        for (int ob = 0; ob < WB; ++ob)
-            if (ob < OB) {
-                const int out = 16 * ob + c;
+        for (int ob = 0; ob < OBN; ++ob)
+            if (ob0 + ob < OB) {
+                const int out = 16 * (ob0 + ob) + c;
                 if (out < real_out) {
                     const float v = NP == 2 ? bacc[ob][0] + baccc[ob][0] * INV_LS : bacc[ob][0];
                     float* dst = part + a.net.b_off[l] + out;

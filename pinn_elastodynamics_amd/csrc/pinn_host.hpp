@@ -252,7 +252,7 @@ struct Host {
             w.ntiles = nt;
             w.first_pass = pass == 0 ? 1 : 0;
             tic();
-            hipLaunchKernelGGL((wgrad_kernel<Op, SPLIT, WIDTH, NB, NS>), dim3(NCHUNK, c.net.nl + 1), dim3(256), 0, c.stream, w);
+            hipLaunchKernelGGL((wgrad_kernel<Op, SPLIT, WIDTH, NB, NS>), dim3(NCHUNK, c.net.nl + 1), dim3(64 * WgradCfg<WIDTH>::NW), 0, c.stream, w);
             if ((rc = (int)hipGetLastError())) return rc;
             toc(2);
         }
