@@ -74,6 +74,33 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
 }
+#ifndef PINN_SPLIT_PACKED_MUL
+#define PINN_SPLIT_PACKED_MUL 0
+#endif
+#if defined(__AMDGCN__) && !defined(PINN_GENERIC_SPLIT)
+// fp16 on the GPU: the same arithmetic pinned to  v_cvt_pk_f16_f32 ; v_fma_mixlo_f16 ; v_fma_mixhi_f16  (the mixed-precision
+// FMA reads the fp16 hi part directly and writes the rounded fp16 low part into its half of the destination).  Left to
+// itself the compiler SLP-vectorises the two FMAs into v_pk_fma_f32 and pays two v_cvt_f32_f16 plus a second v_cvt_pk for
+// them; the split is 18 % of the fused kernel's time (tools/exp_run.py, PINN_EXP_NO_LO experiment).
+template <>
+__device__ __forceinline__ void split2<OpF16>(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const uint32_t h = pack2<OpF16>(a, b);
+    const float nls = -OpF16::LO_SCALE;
+#if PINN_SPLIT_PACKED_MUL
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 t = f32x2{a, b} * OpF16::LO_SCALE;
+    const float ta = t[0], tb = t[1];
+#else
+    const float ta = a * OpF16::LO_SCALE, tb = b * OpF16::LO_SCALE;
+#endif
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l)
+        : "v"(h), "s"(nls), "v"(ta), "v"(tb));
+    hi = h;
+    lo = l;
+}
+#endif
 template <class Op>
 __device__ __forceinline__ float cvt16(uint16_t bits) {
     return (float)__builtin_bit_cast(typename Op::T, bits);

@@ -520,21 +520,29 @@ struct Fused {
             u32x4 B[NS][1][KS][NP];
             first_mb<0>(a, x, xin, B);
             park_state<0>(x, 1, B);
-            for (int l = 1; l < NL; ++l) {
-                u32x4 Bn[NS][1][KS][NP];
-                {
-                    const int frag0 = FI::fwd_mid(l, 0, 0);
-                    u32x4 A0[KS][NP];
-                    load_afrags<KS>(x, frag0, A0);
-                    fwd_mb<0>(x, frag0, (l - 1) * WIDTH * 4, A0, B, Bn);
-                }
-                if (l + 1 < NL) park_state<0>(x, l + 1, Bn);      // S_NL stays in registers
+            // two layers per loop trip, ping-ponging between B and B2: a one-buffer loop has to copy the 64 fragment registers
+            // back at the end of every layer (48 v_mov per layer in the ISA)
+            u32x4 B2[NS][1][KS][NP];
+            auto layer = [&](int l, const u32x4 (&in)[NS][1][KS][NP], u32x4 (&out)[NS][1][KS][NP]) {
+                const int frag0 = FI::fwd_mid(l, 0, 0);
+                u32x4 A0[KS][NP];
+                load_afrags<KS>(x, frag0, A0);
+                fwd_mb<0>(x, frag0, (l - 1) * WIDTH * 4, A0, in, out);
+                if (l + 1 < NL) park_state<0>(x, l + 1, out);      // S_NL stays in registers
+            };
+            int l = 1;
+            for (; l + 1 < NL; l += 2) {
+                layer(l, B, B2);
+                layer(l + 1, B2, B);
+            }
+            if (l < NL) {
+                layer(l, B, B2);
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
                     for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-                        for (int pp = 0; pp < NP; ++pp) B[s][0][kk][pp] = Bn[s][0][kk][pp];
+                        for (int pp = 0; pp < NP; ++pp) B[s][0][kk][pp] = B2[s][0][kk][pp];
             }
             fused_stamp(a, x.tracer, 1);
             // ---- output layer + residual head (net_f_sig INF:221-265)

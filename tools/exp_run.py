@@ -15,13 +15,20 @@ tw = np.ones(7) / n
 m = 4096
 ss_o, g_o, _ = po.wave2d_loss_grad(flat, layers, X[:m, 0], X[:m, 1], X[:m, 2], [0, 0, 0], [30, 30, 20], True, term_weights=np.ones(7) / m)
 names = sys.argv[1:] or sorted(os.path.basename(os.path.dirname(p)) for p in glob.glob(os.path.join(ROOT, 'build/exp/*/libpinn_hip.so')))
+engs = {}
 for name in names:
     eng = HipEngine(layers, precision='f16x3', device=dev, max_points=1 << 18, lib_path=os.path.join(ROOT, 'build/exp', name, 'libpinn_hip.so'))
     ss, g = eng.wave_loss_grad(theta, *(v[:m].contiguous() for v in xs), [0, 0, 0], [30, 30, 20], True, np.ones(7) / m)
     err = float(np.linalg.norm(g.cpu().numpy() - g_o) / np.linalg.norm(g_o))
     for _ in range(2):
         eng.wave_loss_grad(theta, *xs, [0, 0, 0], [30, 30, 20], True, tw)
-    ts = []
-    for _ in range(5):
-        ts.append(eng.wave_loss_grad_profile(theta, *xs, [0, 0, 0], [30, 30, 20], True, tw)['chain'])
-    print(f'{name:28s} fused launch ms: min {min(ts):.3f} med {sorted(ts)[2]:.3f}   grad err vs oracle {err:.1e}', flush=True)
+    engs[name] = (eng, err, [])
+for rnd in range(4):                        # interleaved rounds: box-to-box and clock drift hit every variant alike
+    for name in names:
+        eng, err, ts = engs[name]
+        for _ in range(6):
+            ts.append(eng.wave_loss_grad_profile(theta, *xs, [0, 0, 0], [30, 30, 20], True, tw)['chain'])
+for name in names:
+    eng, err, ts = engs[name]
+    ts = sorted(ts)
+    print(f'{name:28s} fused launch ms: min {ts[0]:.3f} q1 {ts[len(ts)//4]:.3f} med {ts[len(ts)//2]:.3f}   grad err vs oracle {err:.1e}', flush=True)
