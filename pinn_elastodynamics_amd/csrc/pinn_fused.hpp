@@ -27,6 +27,11 @@
 #pragma once
 #include "pinn_device.hpp"
 
+// 4 = production.  8 = experiment (every wave forwards a tile): parity-correct but 9.0 ms vs 6.0 ms per 2 M points, see DESIGN.md section 6
+#ifndef PINN_FUSED_TILES
+#define PINN_FUSED_TILES 4
+#endif
+
 namespace pinn {
 
 typedef short v4i16 __attribute__((ext_vector_type(4)));
@@ -42,12 +47,12 @@ struct FusedArgs {
     const float* y;
     const float* t;
     long n;
-    long nsteps;               // workgroup steps = ceil(n / 64)
+    long nsteps;               // workgroup steps = ceil(n / (16 * TILES))
     float sx[3], ox[3];
     float c1, c2, G, rho;
     float tw[8];
-    u32x4* scratch;            // [gridDim.x * 4 chain waves][NL-1][4 streams][KS][NP][64 lanes]
-    float* loss_part;          // [gridDim.x * 4][8]
+    u32x4* scratch;            // [gridDim.x * TILES][SCRATCH_BYTES]: per-tile images of the parked states
+    float* loss_part;          // [gridDim.x * TILES][8]
     float* partial;            // [gridDim.x][nparams]
     unsigned long long* dbg;   // optional phase timestamps (s_memtime) of workgroup 0, chain wave 0 / weight-gradient wave 0; nullptr = off
 };
@@ -81,7 +86,15 @@ struct Fused {
     static constexpr int WAVE_B = TENSOR_Z_B + 2 * SBUF_B;
     static constexpr int LDS_B = 4 * WAVE_B;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
-    static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * SBUF_B);   // per chain wave
+    // 16-point tiles per workgroup step.  8: every wave (both roles) runs the forward of one tile, then the chain waves take the
+    // eight tiles through the reverse in two rounds (their own from registers, then the tile a weight-gradient wave forwarded,
+    // from the scratch image).  4: the weight-gradient waves idle during the forward.
+    static constexpr int TILES = PINN_FUSED_TILES;
+    static constexpr bool T8 = TILES == 8;
+    static_assert(TILES == 4 || TILES == 8, "4 or 8 tiles per workgroup step");
+    // per-tile scratch: parked states S_1..S_{NL-1} (and S_NL plus the head's adjoint Z_NL for forwarded tiles)
+    static constexpr unsigned ZL_OFF = (unsigned)(NL * SBUF_B);
+    static constexpr unsigned SCRATCH_BYTES = T8 ? ZL_OFF + 4096u : (unsigned)((NL - 1) * SBUF_B);
 
     struct Acc {                       // persistent across the whole launch, all statically indexed
         f32x4 mid[NL - 1][IBW][OBW];
@@ -89,6 +102,41 @@ struct Fused {
         f32x4 last;                    // Wbar_NL block (in-block = quad, out-block 0) if quad < WB
         float bias[NL + 1];
     };
+
+    // T8: while a weight-gradient wave runs the forward of a tile its 120+ accumulator registers are parked in a per-wave slot of
+    // the workspace with wide stores (left to the register allocator they become ~500 dword spills reloaded one by one: measured
+    // 59 k cycles per step)
+    static constexpr int ACC_VEC = (NL - 1) * IBW * OBW + 2 + (NL + 1 + 3) / 4;      // f32x4 per lane
+    static constexpr unsigned ACC_BYTES = (unsigned)(ACC_VEC * 1024);               // per weight-gradient wave
+    template <bool SAVE>
+    static __device__ __forceinline__ void acc_move(__amdgpu_buffer_rsrc_t slot, unsigned lane16, Acc& A) {
+        int i = 0;
+        auto mv = [&](f32x4& v) {
+            if (SAVE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slot, lane16, i * 1024, 0);
+            else v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(slot, lane16, i * 1024, 0));
+            ++i;
+        };
+#pragma unroll
+        for (int l = 0; l < NL - 1; ++l)
+#pragma unroll
+            for (int a = 0; a < IBW; ++a)
+#pragma unroll
+                for (int o = 0; o < OBW; ++o) mv(A.mid[l][a][o]);
+        mv(A.first);
+        mv(A.last);
+#pragma unroll
+        for (int g = 0; g < (NL + 1 + 3) / 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = 4 * g + r <= NL ? A.bias[4 * g + r <= NL ? 4 * g + r : 0] : 0.0f;
+            mv(v);
+            if (!SAVE) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (4 * g + r <= NL) A.bias[4 * g + r] = v[r];
+            }
+        }
+    }
 
     // ---------------------------------------------------------------------------------------------
     // weight-gradient role
@@ -223,8 +271,65 @@ struct Fused {
 #pragma unroll
         for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
         const char* lanebase = lds + (q >> 1) * WAVE_B + (8 * (q & 1) + (c >> 2)) * ROWB + 8 * (c & 3);
+        Ctx x;
+        float lsum[8];
+        __amdgpu_buffer_rsrc_t accslot;
+        if constexpr (T8) {
+            x.init(a, const_cast<char*>(lds), quad, (q << 4) | c, c, q);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lsum[i] = 0.0f;
+            accslot = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(reinterpret_cast<char*>(a.scratch) + (long)gridDim.x * TILES * SCRATCH_BYTES + ((long)blockIdx.x * 4 + quad) * ACC_BYTES), 0,
+                (int)ACC_BYTES, 0x00020000);
+            acc_move<true>(accslot, x.lane16, A);
+        }
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
-            WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0, lanebase, A, quad);
+            if constexpr (T8) {
+                // forward + residual head of tile 4 + quad; everything the reverse needs goes to the tile's scratch image
+                const long tile = step * TILES + 4 + quad;
+                x.set_tile(a, (long)blockIdx.x * TILES + 4 + quad);
+                float xin[3];
+                const long p = tile * 16 + c;
+                const bool valid = p < a.n;
+                const long pidx = valid ? p : a.n - 1;
+                xin[0] = a.x[pidx] * a.sx[0] + a.ox[0];
+                xin[1] = a.y[pidx] * a.sx[1] + a.ox[1];
+                xin[2] = a.t[pidx] * a.sx[2] + a.ox[2];
+                u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
+                const bool tr = blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x;
+                fused_stamp(a, tr, 100);
+                forward_tile(a, x, xin, valid, lsum, B, ZL);
+                fused_stamp(a, tr, 101);
+                park_state<0>(x, NL, B);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const u32x4 v = {ZL[s][0][0][0][0], ZL[s][0][0][0][1], ZL[s][0][0][NP - 1][0], ZL[s][0][0][NP - 1][1]};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, x.scr, x.lane16, ZL_OFF + s * 1024, 0);
+                }
+                acc_move<false>(accslot, x.lane16, A);
+            }
+            const bool tracer = blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x;
+            WgDown<NL>::run(a, tracer, lanebase, A, quad);
+            if constexpr (T8) {
+                fused_stamp(a, tracer, 102);
+                WgDown<NL>::run(a, tracer, lanebase, A, quad);      // round 2: the tiles forwarded above
+                fused_stamp(a, tracer, 103);
+                acc_move<true>(accslot, x.lane16, A);
+                fused_stamp(a, tracer, 104);
+            }
+        }
+        if constexpr (T8) {
+            acc_move<false>(accslot, x.lane16, A);
+            const long gwave = (long)blockIdx.x * TILES + 4 + quad;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = lsum[i];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                if (q == 0 && c == 0) a.loss_part[gwave * 8 + i] = v;
+            }
         }
         // ---- write this workgroup's partial gradient
         float* part = a.partial + (long)blockIdx.x * a.net.nparams;
@@ -272,6 +377,20 @@ struct Fused {
         char* tenZ;                                // wave's Z tensor (uniform); S buffers follow at +TENSOR_Z_B (+SBUF_B)
         int c, q;
         bool tracer;                               // workgroup 0, chain wave 0, lane 0
+        __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile) {
+            scr = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES, 0x00020000);
+        }
+        __device__ __forceinline__ void init(const FusedArgs& a, char* lds, int slot, int lane, int c_, int q_) {
+            frags = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.frags, 0, (int)a.frags_bytes, 0x00020000);
+            bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.bias_mid, 0, (NL - 1) * WIDTH * 4, 0x00020000);
+            w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * 16, 0x00020000);
+            lane16 = (unsigned)lane * 16u;
+            tenZ = lds + slot * WAVE_B;
+            rowoff = (unsigned)(c_ * ROWB + 8 * q_);
+            c = c_;
+            q = q_;
+            tracer = false;
+        }
         __device__ __forceinline__ char* rowZ() const { return tenZ + rowoff; }
         __device__ __forceinline__ char* rowS(int L) const { return tenZ + TENSOR_Z_B + (L & 1) * SBUF_B + rowoff; }
     };
@@ -408,7 +527,7 @@ struct Fused {
 
     // parked state S_l: asynchronous LDS-DMA of the scratch image into the parity buffer of layer l (no registers involved;
     // completion is covered by the vmcnt(0) of the next workgroup barrier)
-    static __device__ __forceinline__ void dma_state(const Ctx& x, int l /*1..NL-1*/) {
+    static __device__ __forceinline__ void dma_state(const Ctx& x, int l /*1..NL-1; NL for a forwarded tile*/) {
         char* dst = x.tenZ + TENSOR_Z_B + (l & 1) * SBUF_B;
 #pragma unroll
         for (int i = 0; i < SBUF_B / 1024; ++i)
@@ -489,19 +608,147 @@ struct Fused {
         }
     };
 
+    // forward (same arithmetic as chain_kernel) + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
+    // parks S_1..S_{NL-1} in the tile's scratch image, returns S_NL (fragments) and the head's adjoint Z_NL, adds the loss sums
+    static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], bool valid, float (&lsum)[8],
+                                                        u32x4 (&B)[NS][1][KS][NP], u32x4 (&ZL)[NS][1][1][NP]) {
+        const int c = x.c, q = x.q;
+        first_mb<0>(a, x, xin, B);
+        park_state<0>(x, 1, B);
+        // two layers per loop trip, ping-ponging between B and B2: a one-buffer loop has to copy the 64 fragment registers
+        // back at the end of every layer (48 v_mov per layer in the ISA)
+        u32x4 B2[NS][1][KS][NP];
+        auto layer = [&](int l, const u32x4 (&in)[NS][1][KS][NP], u32x4 (&out)[NS][1][KS][NP]) {
+            const int frag0 = FI::fwd_mid(l, 0, 0);
+            u32x4 A0[KS][NP];
+            load_afrags<KS>(x, frag0, A0);
+            fwd_mb<0>(x, frag0, (l - 1) * WIDTH * 4, A0, in, out);
+            if (l + 1 < NL) park_state<0>(x, l + 1, out);      // S_NL is handled by the caller
+        };
+        int l = 1;
+        for (; l + 1 < NL; l += 2) {
+            layer(l, B, B2);
+            layer(l + 1, B2, B);
+        }
+        if (l < NL) {
+            layer(l, B, B2);
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                    for (int pp = 0; pp < NP; ++pp) B[s][0][kk][pp] = B2[s][0][kk][pp];
+        }
+        fused_stamp(a, x.tracer, 1);
+        f32x4 yacc[NS], yaccc[NS];
+        {
+            u32x4 A0[KS][NP];
+            load_afrags<KS>(x, FI::fwd_last(NL, 0), A0);
+            gemm_pre<KS>(A0, B, yacc, yaccc);
+        }
+        const f32x4 bl = *reinterpret_cast<const f32x4*>(a.pw.bias_last + 4 * q);
+        float Y[NS][8];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float own = comb(yacc[s], yaccc[s], r) + (s == 0 ? bl[r] : 0.0f);
+                const float oth = __shfl_xor(own, 16);
+                Y[s][r] = (q & 1) ? oth : own;
+                Y[s][4 + r] = (q & 1) ? own : oth;
+            }
+        const float vm = valid ? 1.0f : 0.0f;
+        const float e11 = Y[1][0], e22 = Y[2][1], e12 = Y[2][0] + Y[1][1];
+        float f[7];
+        f[0] = Y[1][4] + Y[2][6] - a.rho * Y[3][2];
+        f[1] = Y[2][5] + Y[1][6] - a.rho * Y[3][3];
+        f[2] = Y[3][0] - Y[0][2];
+        f[3] = Y[3][1] - Y[0][3];
+        f[4] = Y[0][4] - (a.c1 * e11 + a.c2 * e22);
+        f[5] = Y[0][5] - (a.c2 * e11 + a.c1 * e22);
+        f[6] = Y[0][6] - a.G * e12;
+        float g[7];
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            if (q == 0) lsum[i] += vm * f[i] * f[i];
+            g[i] = 2.0f * a.tw[i] * f[i] * vm;
+        }
+        float adj[NS][8];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int o = 0; o < 8; ++o) adj[s][o] = 0.0f;
+        adj[0][2] = -g[2];
+        adj[0][3] = -g[3];
+        adj[0][4] = g[4];
+        adj[0][5] = g[5];
+        adj[0][6] = g[6];
+        adj[1][0] = -a.c1 * g[4] - a.c2 * g[5];
+        adj[1][1] = -a.G * g[6];
+        adj[1][4] = g[0];
+        adj[1][6] = g[1];
+        adj[2][0] = -a.G * g[6];
+        adj[2][1] = -a.c2 * g[4] - a.c1 * g[5];
+        adj[2][5] = g[1];
+        adj[2][6] = g[0];
+        adj[3][0] = g[2];
+        adj[3][1] = g[3];
+        adj[3][2] = -a.rho * g[0];
+        adj[3][3] = -a.rho * g[1];
+        float vals[NS][1][4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vals[s][0][r] = q < 2 ? ((q & 1) ? adj[s][4 + r] : adj[s][r]) : 0.0f;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int pp = 0; pp < NP; ++pp) ZL[s][0][0][pp] = u32x4{0u, 0u, 0u, 0u};
+        CH::template emit<1, 0>(ZL, vals, nullptr, 16, c, q);
+    }
+
+    // reverse of one tile through all weight layers, in step with the weight-gradient waves.  FROM_SCRATCH: the tile was forwarded
+    // by a weight-gradient wave, so S_NL comes from the scratch image by LDS-DMA (B is not used); otherwise B holds S_NL.
+    template <bool FROM_SCRATCH>
+    static __device__ __forceinline__ void reverse_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&B)[NS][1][KS][NP],
+                                                        const u32x4 (&ZL)[NS][1][1][NP]) {
+        // ---- top weight layer NL: hand Z_NL (16 outputs) and S_NL over, then reverse into the hidden chain
+        fused_stamp(a, x.tracer, 2);
+        __syncthreads();
+        fused_stamp(a, x.tracer, 3);
+        put_tensor<1, 1, NP>(x.rowZ(), ZL);
+        if constexpr (FROM_SCRATCH) dma_state(x, NL);
+        else put_tensor<KS, WB, 1>(x.rowS(NL), B);
+        __syncthreads();
+        fused_stamp(a, x.tracer, 4);
+        u32x4 Zn[NS][1][KS][NP];
+        {
+            const int frag0 = FI::bwd_last(NL, 0);
+            u32x4 A0[1][NP];
+            load_afrags<1>(x, frag0, A0);
+            dma_state(x, NL - 1);
+            __builtin_amdgcn_sched_barrier(0);
+            bwd_mb<0, 1>(x, frag0, x.rowS(NL), A0, ZL, Zn);
+            pin<KS>(Zn);
+        }
+        fused_stamp(a, x.tracer, 5);
+        Down<NL - 1>::run(a, x, xin, Zn);
+    }
+
+    static __device__ __forceinline__ void load_inputs(const FusedArgs& a, long tile, int c, float (&xin)[3], bool& valid) {
+        const long p = tile * 16 + c;
+        valid = p < a.n;
+        const long pidx = valid ? p : a.n - 1;
+        xin[0] = a.x[pidx] * a.sx[0] + a.ox[0];
+        xin[1] = a.y[pidx] * a.sx[1] + a.ox[1];
+        xin[2] = a.t[pidx] * a.sx[2] + a.ox[2];
+    }
+
     static __device__ __forceinline__ void chain_role(const FusedArgs& a, char* lds, int wave, int lane, int c, int q) {
-        const long gwave = (long)blockIdx.x * 4 + wave;
+        const long gwave = (long)blockIdx.x * TILES + wave;
         Ctx x;
-        x.frags = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.frags, 0, (int)a.frags_bytes, 0x00020000);
-        x.scr = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gwave * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES,
-                                                  0x00020000);
-        x.bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.bias_mid, 0, (NL - 1) * WIDTH * 4, 0x00020000);
-        x.w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * 16, 0x00020000);
-        x.lane16 = (unsigned)lane * 16u;
-        x.tenZ = lds + wave * WAVE_B;
-        x.rowoff = (unsigned)(c * ROWB + 8 * q);
-        x.c = c;
-        x.q = q;
+        x.init(a, lds, wave, lane, c, q);
+        x.set_tile(a, gwave);
         x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0;
         float lsum[8];
 #pragma unroll
@@ -509,131 +756,34 @@ struct Fused {
 
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
             float xin[3];
-            const long p = (step * 4 + wave) * 16 + c;
-            const bool valid = p < a.n;
-            const long pidx = valid ? p : a.n - 1;
-            xin[0] = a.x[pidx] * a.sx[0] + a.ox[0];
-            xin[1] = a.y[pidx] * a.sx[1] + a.ox[1];
-            xin[2] = a.t[pidx] * a.sx[2] + a.ox[2];
+            bool valid;
+            load_inputs(a, step * TILES + wave, c, xin, valid);
+            x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0 && step == 2 * (long)gridDim.x;      // a steady-state step
             fused_stamp(a, x.tracer, 0);
-            // ---- forward (same arithmetic as chain_kernel), state parked in fragment order
-            u32x4 B[NS][1][KS][NP];
-            first_mb<0>(a, x, xin, B);
-            park_state<0>(x, 1, B);
-            // two layers per loop trip, ping-ponging between B and B2: a one-buffer loop has to copy the 64 fragment registers
-            // back at the end of every layer (48 v_mov per layer in the ISA)
-            u32x4 B2[NS][1][KS][NP];
-            auto layer = [&](int l, const u32x4 (&in)[NS][1][KS][NP], u32x4 (&out)[NS][1][KS][NP]) {
-                const int frag0 = FI::fwd_mid(l, 0, 0);
-                u32x4 A0[KS][NP];
-                load_afrags<KS>(x, frag0, A0);
-                fwd_mb<0>(x, frag0, (l - 1) * WIDTH * 4, A0, in, out);
-                if (l + 1 < NL) park_state<0>(x, l + 1, out);      // S_NL stays in registers
-            };
-            int l = 1;
-            for (; l + 1 < NL; l += 2) {
-                layer(l, B, B2);
-                layer(l + 1, B2, B);
-            }
-            if (l < NL) {
-                layer(l, B, B2);
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-#pragma unroll
-                    for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                        for (int pp = 0; pp < NP; ++pp) B[s][0][kk][pp] = B2[s][0][kk][pp];
-            }
-            fused_stamp(a, x.tracer, 1);
-            // ---- output layer + residual head (net_f_sig INF:221-265)
-            f32x4 yacc[NS], yaccc[NS];
             {
-                u32x4 A0[KS][NP];
-                load_afrags<KS>(x, FI::fwd_last(NL, 0), A0);
-                gemm_pre<KS>(A0, B, yacc, yaccc);
+                u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
+                if constexpr (T8) __builtin_amdgcn_s_setprio(0);       // both waves of a SIMD run a forward: no favourite
+                forward_tile(a, x, xin, valid, lsum, B, ZL);
+                __builtin_amdgcn_s_setprio(2);                         // reverse: the chain wave is the critical path of its SIMD
+                reverse_tile<false>(a, x, xin, B, ZL);
             }
-            const f32x4 bl = *reinterpret_cast<const f32x4*>(a.pw.bias_last + 4 * q);
-            float Y[NS][8];
+            if constexpr (T8) {
+                // ---- round 2: the tile forwarded by weight-gradient wave `wave`
+                Ctx x2 = x;
+                x2.set_tile(a, gwave + 4);
+                x2.tracer = false;
+                load_inputs(a, step * TILES + 4 + wave, c, xin, valid);
+                // (that wave's stores -- S_NL image, Z_NL -- completed before the first barrier of round 1)
+                u32x4 ZL[NS][1][1][NP];
 #pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float own = comb(yacc[s], yaccc[s], r) + (s == 0 ? bl[r] : 0.0f);
-                    const float oth = __shfl_xor(own, 16);
-                    Y[s][r] = (q & 1) ? oth : own;
-                    Y[s][4 + r] = (q & 1) ? own : oth;
+                for (int s = 0; s < NS; ++s) {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(x2.scr, x2.lane16, ZL_OFF + s * 1024, 0);
+                    ZL[s][0][0][0] = u32x4{v[0], v[1], 0u, 0u};
+                    if (NP == 2) ZL[s][0][0][NP - 1] = u32x4{v[2], v[3], 0u, 0u};
                 }
-            const float vm = valid ? 1.0f : 0.0f;
-            const float e11 = Y[1][0], e22 = Y[2][1], e12 = Y[2][0] + Y[1][1];
-            float f[7];
-            f[0] = Y[1][4] + Y[2][6] - a.rho * Y[3][2];
-            f[1] = Y[2][5] + Y[1][6] - a.rho * Y[3][3];
-            f[2] = Y[3][0] - Y[0][2];
-            f[3] = Y[3][1] - Y[0][3];
-            f[4] = Y[0][4] - (a.c1 * e11 + a.c2 * e22);
-            f[5] = Y[0][5] - (a.c2 * e11 + a.c1 * e22);
-            f[6] = Y[0][6] - a.G * e12;
-            float g[7];
-#pragma unroll
-            for (int i = 0; i < 7; ++i) {
-                if (q == 0) lsum[i] += vm * f[i] * f[i];
-                g[i] = 2.0f * a.tw[i] * f[i] * vm;
+                u32x4 Bdummy[NS][1][KS][NP];
+                reverse_tile<true>(a, x2, xin, Bdummy, ZL);
             }
-            float adj[NS][8];
-#pragma unroll
-            for (int s = 0; s < NS; ++s)
-#pragma unroll
-                for (int o = 0; o < 8; ++o) adj[s][o] = 0.0f;
-            adj[0][2] = -g[2];
-            adj[0][3] = -g[3];
-            adj[0][4] = g[4];
-            adj[0][5] = g[5];
-            adj[0][6] = g[6];
-            adj[1][0] = -a.c1 * g[4] - a.c2 * g[5];
-            adj[1][1] = -a.G * g[6];
-            adj[1][4] = g[0];
-            adj[1][6] = g[1];
-            adj[2][0] = -a.G * g[6];
-            adj[2][1] = -a.c2 * g[4] - a.c1 * g[5];
-            adj[2][5] = g[1];
-            adj[2][6] = g[0];
-            adj[3][0] = g[2];
-            adj[3][1] = g[3];
-            adj[3][2] = -a.rho * g[0];
-            adj[3][3] = -a.rho * g[1];
-            u32x4 ZL[NS][1][1][NP];
-            {
-                float vals[NS][1][4];
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vals[s][0][r] = q < 2 ? ((q & 1) ? adj[s][4 + r] : adj[s][r]) : 0.0f;
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-#pragma unroll
-                    for (int pp = 0; pp < NP; ++pp) ZL[s][0][0][pp] = u32x4{0u, 0u, 0u, 0u};
-                CH::template emit<1, 0>(ZL, vals, nullptr, 16, c, q);
-            }
-            // ---- top weight layer NL: hand Z_NL (16 outputs) and S_NL over, then reverse into the hidden chain
-            fused_stamp(a, x.tracer, 2);
-            __syncthreads();
-            fused_stamp(a, x.tracer, 3);
-            put_tensor<1, 1, NP>(x.rowZ(), ZL);
-            put_tensor<KS, WB, 1>(x.rowS(NL), B);         // B still holds S_NL
-            __syncthreads();
-            fused_stamp(a, x.tracer, 4);
-            u32x4 Zn[NS][1][KS][NP];
-            {
-                const int frag0 = FI::bwd_last(NL, 0);
-                u32x4 A0[1][NP];
-                load_afrags<1>(x, frag0, A0);
-                dma_state(x, NL - 1);
-                __builtin_amdgcn_sched_barrier(0);
-                bwd_mb<0, 1>(x, frag0, x.rowS(NL), A0, ZL, Zn);
-                pin<KS>(Zn);
-            }
-            fused_stamp(a, x.tracer, 5);
-            Down<NL - 1>::run(a, x, xin, Zn);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -653,7 +803,6 @@ struct Fused {
         if (wave8 >= 4) {
             wgrad_role(a, lds, wave8 - 4, c, q);
         } else {
-            __builtin_amdgcn_s_setprio(2);          // the chain wave is the critical path of its SIMD: issue it first
             chain_role(a, lds, wave8, lane, c, q);
         }
     }

@@ -287,7 +287,7 @@ struct Host {
             a.y = c.y;
             a.t = c.t;
             a.n = c.n;
-            a.nsteps = (c.n + 63) / 64;
+            a.nsteps = (c.n + 16 * F::TILES - 1) / (16 * F::TILES);
             for (int k = 0; k < 3; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
             a.c1 = c.c1;
             a.c2 = c.c2;
@@ -310,7 +310,7 @@ struct Host {
                 hipEventDestroy(ev[0]);
                 hipEventDestroy(ev[1]);
             }
-            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * 4, 7, c.loss_out, 0);
+            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * F::TILES, 7, c.loss_out, 0);
             if ((rc = (int)hipGetLastError())) return rc;
             hipLaunchKernelGGL((reduce_grad_kernel<0>), dim3((c.net.nparams + 63) / 64), dim3(256), 0, c.stream, (const float*)a.partial,
                                grid, c.net.nparams, twmax, c.grad_out, c.accumulate);
@@ -327,11 +327,13 @@ struct Host {
             Plan p;
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
-            const size_t per_wg = (size_t)4 * (c.net.nl - 1) * ((4 * 16 * (WIDTH * 2 + 8) + 1023) / 1024 * 1024);
+            constexpr int TILES = Fused<Op, SPLIT, WIDTH, 4>::TILES;
+            const size_t per_wg = c.net.nl == 4 ? (size_t)TILES * Fused<Op, SPLIT, WIDTH, 4>::SCRATCH_BYTES + 4 * (size_t)Fused<Op, SPLIT, WIDTH, 4>::ACC_BYTES
+                                                 : (size_t)TILES * Fused<Op, SPLIT, WIDTH, 8>::SCRATCH_BYTES + 4 * (size_t)Fused<Op, SPLIT, WIDTH, 8>::ACC_BYTES;
             if (c.ws_bytes < p.fixed_end + per_wg) return 0;
             long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
             if (grid > FUSED_GRID) grid = FUSED_GRID;
-            const long nsteps = (c.n + 63) / 64;
+            const long nsteps = (c.n + 16 * TILES - 1) / (16 * TILES);
             if (grid > nsteps) grid = nsteps;
             *out = c.net.nl == 4 ? fused_launch<4>(c, p, (int)grid) : fused_launch<8>(c, p, (int)grid);
             return 1;

@@ -32,6 +32,8 @@ for i, L in enumerate(range(NL, -1, -1)):
     prev_end = c[2] if i == 0 else c[5 + 3 * (i - 1)]
     print(f'  L={L}: wait@A {a-prev_end:6d}  put+wait@B {b-a:6d}  bwd {e-b if L>0 else 0:6d}')
 print(f'  step total ~ {c[4+3*NL]-c[0]}')
+print(f'wgrad wave forward: start {t[100]-c[0]:+d} after chain start, duration {t[101]-t[100]}')
+print('wgrad stamps rel. chain start: fwd start %d, fwd end %d, round2 start %d, round2 end %d, saved %d; chain step end %d' % tuple(int(v - c[0]) for v in (t[100], t[101], t[102], t[103], t[104], c[4 + 3 * NL])))
 print('wgrad wave:')
 for i, L in enumerate(range(NL, -1, -1)):
     a, b, e = w[3 * i], w[1 + 3 * i], w[2 + 3 * i]
