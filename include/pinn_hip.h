@@ -41,7 +41,7 @@ enum {
     PINN_ERR_LAYERS = -2,      /* unsupported layer list (see pinn_supported_width) */
     PINN_ERR_PRECISION = -3,   /* unknown precision_mode */
     PINN_ERR_WORKSPACE = -4,   /* workspace smaller than pinn_min_workspace_bytes() or misaligned */
-    PINN_ERR_SIZE = -5         /* n <= 0 */
+    PINN_ERR_SIZE = -5         /* n < 0 (n == 0 is a valid empty batch: zero sums, zero / untouched gradient) */
 };
 
 /* Padded hidden width the kernels use for a real hidden width h (0 if unsupported). */

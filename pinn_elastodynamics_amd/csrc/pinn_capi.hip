@@ -98,17 +98,27 @@ const char* pinn_error_string(int code) {
         case PINN_ERR_LAYERS: return "unsupported layer list (need {3, H x k, n_out<=8}, H<=160, <=16 weight layers, and a compiled variant)";
         case PINN_ERR_PRECISION: return "unknown precision_mode";
         case PINN_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
-        case PINN_ERR_SIZE: return "n must be positive";
+        case PINN_ERR_SIZE: return "n must not be negative";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
+}
+
+// An empty point set contributes nothing: zero sums, and a zero gradient unless the call accumulates.  (The reference would
+// produce NaN means there; a data-parallel rank that gets no rows of a small set must be able to make the same call sequence.)
+static int empty_batch(const Call& c, int nterms) {
+    hipStream_t st = static_cast<hipStream_t>(c.stream);
+    int rc = (int)hipMemsetAsync(c.loss_out, 0, (size_t)nterms * sizeof(float), st);
+    if (!rc && !c.accumulate) rc = (int)hipMemsetAsync(c.grad_out, 0, (size_t)c.net.nparams * sizeof(float), st);
+    return rc;
 }
 
 static int prepare(const float* params, const int* layers, int n_layers, const float* x, const float* y, const float* t, int64_t n,
                    const double lb[3], const double ub[3], int normalize, int precision_mode, void* ws, size_t ws_bytes, void* stream,
                    Call& c, const Impl*& impl) {
-    if (!params || !x || !y || !t || !ws) return PINN_ERR_NULL;
+    if (!params || !ws) return PINN_ERR_NULL;
+    if (n < 0) return PINN_ERR_SIZE;
+    if (n > 0 && (!x || !y || !t)) return PINN_ERR_NULL;          // n == 0 is a valid empty batch (see empty_batch)
     if (normalize && (!lb || !ub)) return PINN_ERR_NULL;
-    if (n <= 0) return PINN_ERR_SIZE;
     if (precision_mode < 0 || precision_mode > 3) return PINN_ERR_PRECISION;
     int width = 0;
     const int rc = decode_net(layers, n_layers, c.net, width);
@@ -185,6 +195,7 @@ static int wave2d_loss_grad_impl(const float* params_flat, const int* layers, in
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     c.prof_ms = prof_ms;
+    if (n == 0) return empty_batch(c, 7);
     return impl->wave_loss_grad(c);
 }
 
@@ -219,6 +230,7 @@ int pinn_data_loss_grad(const float* params_flat, const int* layers, int n_layer
     c.loss_out = loss_terms_out;
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
+    if (n == 0) return empty_batch(c, c.net.nout);
     return impl->data_loss_grad(c);
 }
 
@@ -231,6 +243,7 @@ int pinn_wave2d_fields(const float* params_flat, const int* layers, int n_layers
     if (rc) return rc;
     if (!fields_out) return PINN_ERR_NULL;
     c.fields_out = fields_out;
+    if (n == 0) return 0;
     return impl->fields(c);
 }
 
@@ -243,6 +256,7 @@ int pinn_net_streams(const float* params_flat, const int* layers, int n_layers, 
     if (rc) return rc;
     if (!streams_out) return PINN_ERR_NULL;
     c.fields_out = streams_out;
+    if (n == 0) return 0;
     return impl->streams(c);
 }
 
@@ -254,7 +268,7 @@ int pinn_plate2d_loss_grad(const float* params_flat, const int* layers, int n_la
     const Impl* impl = nullptr;
     int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
     if (rc) return rc;
-    if (!frozen_streams || !term_weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
+    if ((n > 0 && !frozen_streams) || !term_weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
     if (c.net.nout != 5) return PINN_ERR_LAYERS;
     c.c1 = (float)(E / (1.0 - mu * mu));               // plane stress, PLATE:416-418
     c.c2 = (float)(E * mu / (1.0 - mu * mu));
@@ -265,6 +279,7 @@ int pinn_plate2d_loss_grad(const float* params_flat, const int* layers, int n_la
     c.loss_out = loss_terms_out;
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
+    if (n == 0) return empty_batch(c, 5);
     return impl->plate_loss_grad(c);
 }
 
@@ -277,7 +292,7 @@ int pinn_plate2d_traction_loss_grad(const float* params_flat, const int* layers,
     const Impl* impl = nullptr;
     int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
     if (rc) return rc;
-    if (!frozen_and_normals || !weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
+    if ((n > 0 && !frozen_and_normals) || !weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
     if (c.net.nout != 5) return PINN_ERR_LAYERS;
     c.tw[0] = weights[0];
     c.tw[1] = weights[1];
@@ -285,6 +300,7 @@ int pinn_plate2d_traction_loss_grad(const float* params_flat, const int* layers,
     c.loss_out = loss_terms_out;
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
+    if (n == 0) return empty_batch(c, 2);
     return impl->traction_loss_grad(c);
 }
 
@@ -303,6 +319,7 @@ int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_lay
     c.loss_out = loss_terms_out;
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
+    if (n == 0) return empty_batch(c, c.net.nout);
     return impl->stream_loss_grad(c);
 }
 

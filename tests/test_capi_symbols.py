@@ -54,8 +54,8 @@ def test_argument_errors_return_codes_without_touching_the_gpu(lib):
         lib.wave2d_loss_grad(0, layers, 0, 0, 0, 10, [0, 0, 0], [1, 1, 1], True, 2.5, 0.25, 1.0, True, [1] * 7, 0, 0, False, "f16x3", 0, 0)
     buf = (ctypes.c_float * 64)()
     p = ctypes.addressof(buf)
-    with pytest.raises(PinnLibError, match="positive"):
-        lib.wave2d_loss_grad(p, layers, p, p, p, 0, [0, 0, 0], [1, 1, 1], True, 2.5, 0.25, 1.0, True, [1] * 7, p, p, False, "f16x3", p, 64)
+    with pytest.raises(PinnLibError, match="negative"):
+        lib.wave2d_loss_grad(p, layers, p, p, p, -1, [0, 0, 0], [1, 1, 1], True, 2.5, 0.25, 1.0, True, [1] * 7, p, p, False, "f16x3", p, 64)
     with pytest.raises(PinnLibError, match="layer"):
         lib.wave2d_loss_grad(p, [3, 32, 48, 7], p, p, p, 10, [0, 0, 0], [1, 1, 1], True, 2.5, 0.25, 1.0, True, [1] * 7, p, p, False,
                              "f16x3", p, 64)

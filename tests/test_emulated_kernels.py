@@ -181,3 +181,34 @@ def test_emulated_plate_entry_points(emu, lN, lD, n):
     emu.stream_loss_grad(pD.ctypes.data, lD, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, tg32.ctypes.data, w, loss.ctypes.data,
                          gradD.ctypes.data, False, prec, ws.ctypes.data, wsb)
     assert rel(loss[:5], ((w / w.max()) * s3).sum(0)) < 2e-6 and rel(gradD, g3) < 2e-6
+
+
+def test_empty_and_ragged_batches_emulated(emu):
+    """n = 0 is a valid empty batch (zero sums; gradient zeroed, or left alone when accumulating); sizes around the 16-point tile
+    and the 64-point workgroup step go through both paths."""
+    layers = [3] + 4 * [32] + [7]
+    rng = np.random.default_rng(0)
+    Ws, bs = po.xavier_init(layers, rng)
+    flat = po.pack_params(Ws, bs)
+    p32 = flat.astype(np.float32)
+    wsb = emu.workspace_bytes(layers, 256, "f16x3")
+    ws = aligned(wsb)
+    for accumulate in (False, True):
+        loss = np.full(8, np.nan, np.float32)
+        grad = np.full(p32.size, 3.0, np.float32)
+        emu.wave2d_loss_grad(p32.ctypes.data, layers, 0, 0, 0, 0, LB, UB, True, 2.5, 0.25, 1.0, True, np.ones(7), loss.ctypes.data, grad.ctypes.data,
+                             accumulate, "f16x3", ws.ctypes.data, wsb)
+        assert np.all(loss[:7] == 0) and np.all(grad == (3.0 if accumulate else 0.0))
+    for fused, tol in ((1, 2e-4), (0, 2e-6)):
+        emu.set_fused(fused)
+        for n in (1, 15, 17, 63, 65):
+            X = po.collocation_points(n, LB, UB, rng)
+            x, y, t = (np.ascontiguousarray(X[:, k], dtype=np.float32) for k in range(3))
+            tw = np.ones(7) / n
+            ss, g, _ = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, True, term_weights=tw)
+            loss = np.full(8, np.nan, np.float32)
+            grad = np.full(p32.size, np.nan, np.float32)
+            emu.wave2d_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, True, 2.5, 0.25, 1.0, True, tw,
+                                 loss.ctypes.data, grad.ctypes.data, False, "f16x3", ws.ctypes.data, wsb)
+            assert rel(loss[:7], ss) < 2e-6 and rel(grad, g) < tol, (fused, n)
+    emu.set_fused(1)

@@ -233,6 +233,29 @@ def test_sixteen_million_points_additivity(dev):
     assert rel(l_sum.cpu().numpy(), l_all.cpu().numpy()) < 1e-5 and rel(g_sum.cpu().numpy(), g_all.cpu().numpy()) < 1e-4
 
 
+def test_empty_and_ragged_batches(dev):
+    """Empty sets are a no-op (zero sums, gradient zeroed or untouched when accumulating); ragged sizes around the 16-point tile and
+    the 64-point workgroup step match the oracle."""
+    layers = [3] + 8 * [64] + [7]
+    Ws, bs, rng = make_net(layers, 12)
+    flat = po.pack_params(Ws, bs)
+    theta = to_dev(flat, dev)
+    eng = engine(layers, "f16x3", dev, 4096)
+    empty = torch.empty(0, dtype=torch.float32, device=dev)
+    g = torch.full((flat.size,), 3.0, dtype=torch.float32, device=dev)
+    l, _ = eng.wave_loss_grad(theta, empty, empty, empty, LB, UB, True, np.ones(7), grad_out=g, accumulate=True)
+    assert torch.all(l == 0) and torch.all(g == 3.0)
+    l, g = eng.wave_loss_grad(theta, empty, empty, empty, LB, UB, True, np.ones(7))
+    assert torch.all(l == 0) and torch.all(g == 0)
+    assert eng.fields(theta, empty, empty, empty, LB, UB, True).shape == (4, 7, 0)
+    for n in (1, 15, 17, 63, 65, 1025):
+        X = po.collocation_points(n, LB, UB, rng)
+        tw = np.ones(7) / n
+        ss, gr, _ = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, True, term_weights=tw)
+        l, g = eng.wave_loss_grad(theta, *(to_dev(X[:, k], dev) for k in range(3)), LB, UB, True, tw)
+        assert rel(l.cpu().numpy(), ss) < 2e-5 and rel(g.cpu().numpy(), gr) < 5e-4, n       # parked fp16 state: ~5e-4/sqrt(n)
+
+
 def test_error_paths(dev):
     from pinn_elastodynamics_amd.capi import PinnLib, PinnLibError
     lib = PinnLib()
