@@ -241,7 +241,7 @@ int pinn_wave2d_fields(const float* params_flat, const int* layers, int n_layers
     const Impl* impl = nullptr;
     int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
     if (rc) return rc;
-    if (!fields_out) return PINN_ERR_NULL;
+    if (n > 0 && !fields_out) return PINN_ERR_NULL;
     c.fields_out = fields_out;
     if (n == 0) return 0;
     return impl->fields(c);
@@ -254,7 +254,7 @@ int pinn_net_streams(const float* params_flat, const int* layers, int n_layers, 
     const Impl* impl = nullptr;
     int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
     if (rc) return rc;
-    if (!streams_out) return PINN_ERR_NULL;
+    if (n > 0 && !streams_out) return PINN_ERR_NULL;
     c.fields_out = streams_out;
     if (n == 0) return 0;
     return impl->streams(c);
