@@ -185,6 +185,7 @@ def main():
                 out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
+        torch.distributed.barrier()          # rank 0 is still profiling its kernel: leave together
         torch.distributed.destroy_process_group()
 
 

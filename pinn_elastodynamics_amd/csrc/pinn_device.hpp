@@ -315,6 +315,7 @@ struct Chain {
                 }
                 Bn[s][nb][MB >> 1][0][(MB & 1) * 2 + 0] = h0;
                 Bn[s][nb][MB >> 1][0][(MB & 1) * 2 + 1] = h1;
+#ifndef PINN_EXP_NO_PANEL_STORE
                 if (panel) {
                     uint16_t* p = panel + ((long)(s * NP) * rows + 16 * MB + 4 * q) * TP + 16 * nb + c;
                     p[0 * TP] = (uint16_t)(h0 & 0xffffu);
@@ -329,6 +330,7 @@ struct Chain {
                         pl[3 * TP] = (uint16_t)(l1 >> 16);
                     }
                 }
+#endif
             }
         }
     }
