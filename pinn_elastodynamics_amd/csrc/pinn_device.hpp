@@ -74,25 +74,16 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
     hi = __builtin_bit_cast(uint32_t, h);
     lo = __builtin_bit_cast(uint32_t, l);
 }
-#ifndef PINN_SPLIT_PACKED_MUL
-#define PINN_SPLIT_PACKED_MUL 0
-#endif
 #if defined(__AMDGCN__) && !defined(PINN_GENERIC_SPLIT)
 // fp16 on the GPU: the same arithmetic pinned to  v_cvt_pk_f16_f32 ; v_fma_mixlo_f16 ; v_fma_mixhi_f16  (the mixed-precision
 // FMA reads the fp16 hi part directly and writes the rounded fp16 low part into its half of the destination).  Left to
 // itself the compiler SLP-vectorises the two FMAs into v_pk_fma_f32 and pays two v_cvt_f32_f16 plus a second v_cvt_pk for
-// them; the split is 18 % of the fused kernel's time (tools/exp_run.py, PINN_EXP_NO_LO experiment).
+// them; the split is 18 % of the fused kernel's time (measured by deleting it).
 template <>
 __device__ __forceinline__ void split2<OpF16>(float a, float b, uint32_t& hi, uint32_t& lo) {
     const uint32_t h = pack2<OpF16>(a, b);
     const float nls = -OpF16::LO_SCALE;
-#if PINN_SPLIT_PACKED_MUL
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const f32x2 t = f32x2{a, b} * OpF16::LO_SCALE;
-    const float ta = t[0], tb = t[1];
-#else
-    const float ta = a * OpF16::LO_SCALE, tb = b * OpF16::LO_SCALE;
-#endif
+    const float ta = a * OpF16::LO_SCALE, tb = b * OpF16::LO_SCALE;      // (a packed v_pk_mul_f32 here measured +4 %)
     uint32_t l;
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
         : "=&v"(l)
@@ -315,7 +306,6 @@ struct Chain {
                 }
                 Bn[s][nb][MB >> 1][0][(MB & 1) * 2 + 0] = h0;
                 Bn[s][nb][MB >> 1][0][(MB & 1) * 2 + 1] = h1;
-#ifndef PINN_EXP_NO_PANEL_STORE
                 if (panel) {
                     uint16_t* p = panel + ((long)(s * NP) * rows + 16 * MB + 4 * q) * TP + 16 * nb + c;
                     p[0 * TP] = (uint16_t)(h0 & 0xffffu);
@@ -330,7 +320,6 @@ struct Chain {
                         pl[3 * TP] = (uint16_t)(l1 >> 16);
                     }
                 }
-#endif
             }
         }
     }

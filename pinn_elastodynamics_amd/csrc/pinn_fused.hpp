@@ -27,11 +27,6 @@
 #pragma once
 #include "pinn_device.hpp"
 
-// 4 = production.  8 = experiment (every wave forwards a tile): parity-correct but 9.0 ms vs 6.0 ms per 2 M points, see DESIGN.md section 6
-#ifndef PINN_FUSED_TILES
-#define PINN_FUSED_TILES 4
-#endif
-
 namespace pinn {
 
 typedef short v4i16 __attribute__((ext_vector_type(4)));
@@ -86,15 +81,8 @@ struct Fused {
     static constexpr int WAVE_B = TENSOR_Z_B + 2 * SBUF_B;
     static constexpr int LDS_B = 4 * WAVE_B;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
-    // 16-point tiles per workgroup step.  8: every wave (both roles) runs the forward of one tile, then the chain waves take the
-    // eight tiles through the reverse in two rounds (their own from registers, then the tile a weight-gradient wave forwarded,
-    // from the scratch image).  4: the weight-gradient waves idle during the forward.
-    static constexpr int TILES = PINN_FUSED_TILES;
-    static constexpr bool T8 = TILES == 8;
-    static_assert(TILES == 4 || TILES == 8, "4 or 8 tiles per workgroup step");
-    // per-tile scratch: parked states S_1..S_{NL-1} (and S_NL plus the head's adjoint Z_NL for forwarded tiles)
-    static constexpr unsigned ZL_OFF = (unsigned)(NL * SBUF_B);
-    static constexpr unsigned SCRATCH_BYTES = T8 ? ZL_OFF + 4096u : (unsigned)((NL - 1) * SBUF_B);
+    static constexpr int TILES = 4;                                           // 16-point tiles per workgroup step (one per chain wave)
+    static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * SBUF_B);   // per tile: parked states S_1..S_{NL-1}
 
     struct Acc {                       // persistent across the whole launch, all statically indexed
         f32x4 mid[NL - 1][IBW][OBW];
@@ -102,41 +90,6 @@ struct Fused {
         f32x4 last;                    // Wbar_NL block (in-block = quad, out-block 0) if quad < WB
         float bias[NL + 1];
     };
-
-    // T8: while a weight-gradient wave runs the forward of a tile its 120+ accumulator registers are parked in a per-wave slot of
-    // the workspace with wide stores (left to the register allocator they become ~500 dword spills reloaded one by one: measured
-    // 59 k cycles per step)
-    static constexpr int ACC_VEC = (NL - 1) * IBW * OBW + 2 + (NL + 1 + 3) / 4;      // f32x4 per lane
-    static constexpr unsigned ACC_BYTES = (unsigned)(ACC_VEC * 1024);               // per weight-gradient wave
-    template <bool SAVE>
-    static __device__ __forceinline__ void acc_move(__amdgpu_buffer_rsrc_t slot, unsigned lane16, Acc& A) {
-        int i = 0;
-        auto mv = [&](f32x4& v) {
-            if (SAVE) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slot, lane16, i * 1024, 0);
-            else v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(slot, lane16, i * 1024, 0));
-            ++i;
-        };
-#pragma unroll
-        for (int l = 0; l < NL - 1; ++l)
-#pragma unroll
-            for (int a = 0; a < IBW; ++a)
-#pragma unroll
-                for (int o = 0; o < OBW; ++o) mv(A.mid[l][a][o]);
-        mv(A.first);
-        mv(A.last);
-#pragma unroll
-        for (int g = 0; g < (NL + 1 + 3) / 4; ++g) {
-            f32x4 v;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = 4 * g + r <= NL ? A.bias[4 * g + r <= NL ? 4 * g + r : 0] : 0.0f;
-            mv(v);
-            if (!SAVE) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (4 * g + r <= NL) A.bias[4 * g + r] = v[r];
-            }
-        }
-    }
 
     // ---------------------------------------------------------------------------------------------
     // weight-gradient role
@@ -271,65 +224,8 @@ struct Fused {
 #pragma unroll
         for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
         const char* lanebase = lds + (q >> 1) * WAVE_B + (8 * (q & 1) + (c >> 2)) * ROWB + 8 * (c & 3);
-        Ctx x;
-        float lsum[8];
-        __amdgpu_buffer_rsrc_t accslot;
-        if constexpr (T8) {
-            x.init(a, const_cast<char*>(lds), quad, (q << 4) | c, c, q);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) lsum[i] = 0.0f;
-            accslot = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)(reinterpret_cast<char*>(a.scratch) + (long)gridDim.x * TILES * SCRATCH_BYTES + ((long)blockIdx.x * 4 + quad) * ACC_BYTES), 0,
-                (int)ACC_BYTES, 0x00020000);
-            acc_move<true>(accslot, x.lane16, A);
-        }
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
-            if constexpr (T8) {
-                // forward + residual head of tile 4 + quad; everything the reverse needs goes to the tile's scratch image
-                const long tile = step * TILES + 4 + quad;
-                x.set_tile(a, (long)blockIdx.x * TILES + 4 + quad);
-                float xin[3];
-                const long p = tile * 16 + c;
-                const bool valid = p < a.n;
-                const long pidx = valid ? p : a.n - 1;
-                xin[0] = a.x[pidx] * a.sx[0] + a.ox[0];
-                xin[1] = a.y[pidx] * a.sx[1] + a.ox[1];
-                xin[2] = a.t[pidx] * a.sx[2] + a.ox[2];
-                u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
-                const bool tr = blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x;
-                fused_stamp(a, tr, 100);
-                forward_tile(a, x, xin, valid, lsum, B, ZL);
-                fused_stamp(a, tr, 101);
-                park_state<0>(x, NL, B);
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const u32x4 v = {ZL[s][0][0][0][0], ZL[s][0][0][0][1], ZL[s][0][0][NP - 1][0], ZL[s][0][0][NP - 1][1]};
-                    __builtin_amdgcn_raw_buffer_store_b128(v, x.scr, x.lane16, ZL_OFF + s * 1024, 0);
-                }
-                acc_move<false>(accslot, x.lane16, A);
-            }
-            const bool tracer = blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x;
-            WgDown<NL>::run(a, tracer, lanebase, A, quad);
-            if constexpr (T8) {
-                fused_stamp(a, tracer, 102);
-                WgDown<NL>::run(a, tracer, lanebase, A, quad);      // round 2: the tiles forwarded above
-                fused_stamp(a, tracer, 103);
-                acc_move<true>(accslot, x.lane16, A);
-                fused_stamp(a, tracer, 104);
-            }
-        }
-        if constexpr (T8) {
-            acc_move<false>(accslot, x.lane16, A);
-            const long gwave = (long)blockIdx.x * TILES + 4 + quad;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float v = lsum[i];
-                v += __shfl_xor(v, 1);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 8);
-                if (q == 0 && c == 0) a.loss_part[gwave * 8 + i] = v;
-            }
+            WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, lanebase, A, quad);
         }
         // ---- write this workgroup's partial gradient
         float* part = a.partial + (long)blockIdx.x * a.net.nparams;
@@ -527,7 +423,7 @@ struct Fused {
 
     // parked state S_l: asynchronous LDS-DMA of the scratch image into the parity buffer of layer l (no registers involved;
     // completion is covered by the vmcnt(0) of the next workgroup barrier)
-    static __device__ __forceinline__ void dma_state(const Ctx& x, int l /*1..NL-1; NL for a forwarded tile*/) {
+    static __device__ __forceinline__ void dma_state(const Ctx& x, int l /*1..NL-1*/) {
         char* dst = x.tenZ + TENSOR_Z_B + (l & 1) * SBUF_B;
 #pragma unroll
         for (int i = 0; i < SBUF_B / 1024; ++i)
@@ -707,9 +603,7 @@ struct Fused {
         CH::template emit<1, 0>(ZL, vals, nullptr, 16, c, q);
     }
 
-    // reverse of one tile through all weight layers, in step with the weight-gradient waves.  FROM_SCRATCH: the tile was forwarded
-    // by a weight-gradient wave, so S_NL comes from the scratch image by LDS-DMA (B is not used); otherwise B holds S_NL.
-    template <bool FROM_SCRATCH>
+    // reverse of one tile through all weight layers, in step with the weight-gradient waves; B holds S_NL
     static __device__ __forceinline__ void reverse_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&B)[NS][1][KS][NP],
                                                         const u32x4 (&ZL)[NS][1][1][NP]) {
         // ---- top weight layer NL: hand Z_NL (16 outputs) and S_NL over, then reverse into the hidden chain
@@ -717,8 +611,7 @@ struct Fused {
         __syncthreads();
         fused_stamp(a, x.tracer, 3);
         put_tensor<1, 1, NP>(x.rowZ(), ZL);
-        if constexpr (FROM_SCRATCH) dma_state(x, NL);
-        else put_tensor<KS, WB, 1>(x.rowS(NL), B);
+        put_tensor<KS, WB, 1>(x.rowS(NL), B);
         __syncthreads();
         fused_stamp(a, x.tracer, 4);
         u32x4 Zn[NS][1][KS][NP];
@@ -762,27 +655,8 @@ struct Fused {
             fused_stamp(a, x.tracer, 0);
             {
                 u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
-                if constexpr (T8) __builtin_amdgcn_s_setprio(0);       // both waves of a SIMD run a forward: no favourite
                 forward_tile(a, x, xin, valid, lsum, B, ZL);
-                __builtin_amdgcn_s_setprio(2);                         // reverse: the chain wave is the critical path of its SIMD
-                reverse_tile<false>(a, x, xin, B, ZL);
-            }
-            if constexpr (T8) {
-                // ---- round 2: the tile forwarded by weight-gradient wave `wave`
-                Ctx x2 = x;
-                x2.set_tile(a, gwave + 4);
-                x2.tracer = false;
-                load_inputs(a, step * TILES + 4 + wave, c, xin, valid);
-                // (that wave's stores -- S_NL image, Z_NL -- completed before the first barrier of round 1)
-                u32x4 ZL[NS][1][1][NP];
-#pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(x2.scr, x2.lane16, ZL_OFF + s * 1024, 0);
-                    ZL[s][0][0][0] = u32x4{v[0], v[1], 0u, 0u};
-                    if (NP == 2) ZL[s][0][0][NP - 1] = u32x4{v[2], v[3], 0u, 0u};
-                }
-                u32x4 Bdummy[NS][1][KS][NP];
-                reverse_tile<true>(a, x2, xin, Bdummy, ZL);
+                reverse_tile(a, x, xin, B, ZL);
             }
         }
 #pragma unroll
@@ -803,6 +677,7 @@ struct Fused {
         if (wave8 >= 4) {
             wgrad_role(a, lds, wave8 - 4, c, q);
         } else {
+            __builtin_amdgcn_s_setprio(2);          // the chain wave is the critical path of its SIMD: issue it first
             chain_role(a, lds, wave8, lane, c, q);
         }
     }

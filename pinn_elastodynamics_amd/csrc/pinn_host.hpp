@@ -328,8 +328,7 @@ struct Host {
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
             constexpr int TILES = Fused<Op, SPLIT, WIDTH, 4>::TILES;
-            const size_t per_wg = c.net.nl == 4 ? (size_t)TILES * Fused<Op, SPLIT, WIDTH, 4>::SCRATCH_BYTES + 4 * (size_t)Fused<Op, SPLIT, WIDTH, 4>::ACC_BYTES
-                                                 : (size_t)TILES * Fused<Op, SPLIT, WIDTH, 8>::SCRATCH_BYTES + 4 * (size_t)Fused<Op, SPLIT, WIDTH, 8>::ACC_BYTES;
+            const size_t per_wg = (size_t)TILES * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8>::SCRATCH_BYTES);
             if (c.ws_bytes < p.fixed_end + per_wg) return 0;
             long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
             if (grid > FUSED_GRID) grid = FUSED_GRID;
