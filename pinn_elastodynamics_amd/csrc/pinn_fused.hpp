@@ -46,6 +46,7 @@ struct FusedArgs {
     float sx[3], ox[3];
     float c1, c2, G, rho;
     float tw[8];
+    const float* targets;      // NS = 1 only: [nout][n] or nullptr (= 0)
     u32x4* scratch;            // [gridDim.x * TILES][SCRATCH_BYTES]: per-tile images of the parked states
     float* loss_part;          // [gridDim.x * TILES][8]
     float* partial;            // [gridDim.x][nparams]
@@ -56,9 +57,12 @@ __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int sl
     if (a.dbg != nullptr && who) a.dbg[slot] = __builtin_readcyclecounter();
 }
 
-template <class Op, int SPLIT, int WIDTH, int NL>
+// NS = 4: value + three tangent streams, residual head of net_f_sig (the collocation set).  NS = 1: value stream only, head
+// sum_o w_o (Y_o - target_o)^2 -- the side sets loss_IC / loss_SRC / loss_NB / loss_FIX (INF:111-118, CONF:145-146).
+template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4>
 struct Fused {
-    static constexpr int NS = 4, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1;
+    static constexpr int NS = NS_, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1;
+    static_assert(NS == 4 || NS == 1, "wave residual head (4 streams) or value-only data head (1 stream)");
     // weight fragments as stored by repack_kernel: [hi, lo, hi*LO_SCALE] when split; the fused kernel accumulates
     //   acc = (hi*LS).x_hi + hi.x_lo + lo.x_hi = LS * (W.x)   in ONE accumulator per stream (x_lo, lo carry the 2^11 scale)
     static constexpr int NPS = NP;                     // stored parts per weight fragment: [hi, lo] when split
@@ -66,7 +70,7 @@ struct Fused {
     static_assert(NL >= 2, "fused kernel needs at least two hidden layers");
     static constexpr int IBW = WB / 2, OBW = WB / 2;          // weight-gradient wave (i,o) owns IBW x OBW blocks of every mid Wbar
     static constexpr float INV_LS = 1.0f / Op::LO_SCALE;
-    typedef Chain<Op, SPLIT, WIDTH, 1, NS, HEAD_WAVE> CH;
+    typedef Chain<Op, SPLIT, WIDTH, 1, NS, NS == 4 ? HEAD_WAVE : HEAD_DATA> CH;
     typedef FragIndex<WIDTH> FI;
     // LDS: per chain wave [Z tensor | S tensor]; tensor = NS*NP panels of [16 points][ROWB bytes]
     static constexpr int ROWB = WIDTH * 2 + 8;
@@ -124,7 +128,7 @@ struct Fused {
         // of group g, so LDS latency hides behind matrix work; the fence after each group bounds how far the compiler may hoist
         struct Frags { u32x4 Ah[NA], Bh[NBK], Bl[NBK]; };
         auto fetch = [&](int g, Frags& f) {
-            const int j = g >> 2, st = g & 3;
+            const int j = g / NS, st = g % NS;
 #pragma unroll
             for (int a = 0; a < NA; ++a) f.Ah[a] = get_frag(sbase, 2 * j * WAVE_B + st * PANEL_B + 32 * a);
 #pragma unroll
@@ -145,7 +149,7 @@ struct Fused {
                     acc[a][b] = Op::mfma(cur.Ah[a], cur.Bh[b], acc[a][b]);
                     if (NP == 2) cc[a][b] = Op::mfma(cur.Ah[a], cur.Bl[b], cc[a][b]);
                 }
-            if ((g & 3) == 0) {                   // bias gradient = ones^T . Z (value stream)
+            if (g % NS == 0) {                    // bias gradient = ones^T . Z (value stream)
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
                     bm[b] = Op::mfma(ones, cur.Bh[b], bm[b]);
@@ -506,7 +510,7 @@ struct Fused {
 
     // forward (same arithmetic as chain_kernel) + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
     // parks S_1..S_{NL-1} in the tile's scratch image, returns S_NL (fragments) and the head's adjoint Z_NL, adds the loss sums
-    static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], bool valid, float (&lsum)[8],
+    static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], bool valid, long pidx, float (&lsum)[8],
                                                         u32x4 (&B)[NS][1][KS][NP], u32x4 (&ZL)[NS][1][1][NP]) {
         const int c = x.c, q = x.q;
         first_mb<0>(a, x, xin, B);
@@ -554,43 +558,53 @@ struct Fused {
                 Y[s][4 + r] = (q & 1) ? own : oth;
             }
         const float vm = valid ? 1.0f : 0.0f;
-        const float e11 = Y[1][0], e22 = Y[2][1], e12 = Y[2][0] + Y[1][1];
-        float f[7];
-        f[0] = Y[1][4] + Y[2][6] - a.rho * Y[3][2];
-        f[1] = Y[2][5] + Y[1][6] - a.rho * Y[3][3];
-        f[2] = Y[3][0] - Y[0][2];
-        f[3] = Y[3][1] - Y[0][3];
-        f[4] = Y[0][4] - (a.c1 * e11 + a.c2 * e22);
-        f[5] = Y[0][5] - (a.c2 * e11 + a.c1 * e22);
-        f[6] = Y[0][6] - a.G * e12;
-        float g[7];
-#pragma unroll
-        for (int i = 0; i < 7; ++i) {
-            if (q == 0) lsum[i] += vm * f[i] * f[i];
-            g[i] = 2.0f * a.tw[i] * f[i] * vm;
-        }
         float adj[NS][8];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int o = 0; o < 8; ++o) adj[s][o] = 0.0f;
-        adj[0][2] = -g[2];
-        adj[0][3] = -g[3];
-        adj[0][4] = g[4];
-        adj[0][5] = g[5];
-        adj[0][6] = g[6];
-        adj[1][0] = -a.c1 * g[4] - a.c2 * g[5];
-        adj[1][1] = -a.G * g[6];
-        adj[1][4] = g[0];
-        adj[1][6] = g[1];
-        adj[2][0] = -a.G * g[6];
-        adj[2][1] = -a.c2 * g[4] - a.c1 * g[5];
-        adj[2][5] = g[1];
-        adj[2][6] = g[0];
-        adj[3][0] = g[2];
-        adj[3][1] = g[3];
-        adj[3][2] = -a.rho * g[0];
-        adj[3][3] = -a.rho * g[1];
+        if constexpr (NS == 4) {
+            const float e11 = Y[1][0], e22 = Y[2][1], e12 = Y[2][0] + Y[1][1];
+            float f[7];
+            f[0] = Y[1][4] + Y[2][6] - a.rho * Y[3][2];
+            f[1] = Y[2][5] + Y[1][6] - a.rho * Y[3][3];
+            f[2] = Y[3][0] - Y[0][2];
+            f[3] = Y[3][1] - Y[0][3];
+            f[4] = Y[0][4] - (a.c1 * e11 + a.c2 * e22);
+            f[5] = Y[0][5] - (a.c2 * e11 + a.c1 * e22);
+            f[6] = Y[0][6] - a.G * e12;
+            float g[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                if (q == 0) lsum[i] += vm * f[i] * f[i];
+                g[i] = 2.0f * a.tw[i] * f[i] * vm;
+            }
+            adj[0][2] = -g[2];
+            adj[0][3] = -g[3];
+            adj[0][4] = g[4];
+            adj[0][5] = g[5];
+            adj[0][6] = g[6];
+            adj[1][0] = -a.c1 * g[4] - a.c2 * g[5];
+            adj[1][1] = -a.G * g[6];
+            adj[1][4] = g[0];
+            adj[1][6] = g[1];
+            adj[2][0] = -a.G * g[6];
+            adj[2][1] = -a.c2 * g[4] - a.c1 * g[5];
+            adj[2][5] = g[1];
+            adj[2][6] = g[0];
+            adj[3][0] = g[2];
+            adj[3][1] = g[3];
+            adj[3][2] = -a.rho * g[0];
+            adj[3][3] = -a.rho * g[1];
+        } else {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                float d = 0.0f;
+                if (o < a.net.nout) d = Y[0][o] - (a.targets ? a.targets[(long)o * a.n + pidx] : 0.0f);
+                if (q == 0) lsum[o] += vm * d * d;
+                adj[0][o] = 2.0f * a.tw[o] * d * vm;
+            }
+        }
         float vals[NS][1][4];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -628,10 +642,10 @@ struct Fused {
         Down<NL - 1>::run(a, x, xin, Zn);
     }
 
-    static __device__ __forceinline__ void load_inputs(const FusedArgs& a, long tile, int c, float (&xin)[3], bool& valid) {
+    static __device__ __forceinline__ void load_inputs(const FusedArgs& a, long tile, int c, float (&xin)[3], bool& valid, long& pidx) {
         const long p = tile * 16 + c;
         valid = p < a.n;
-        const long pidx = valid ? p : a.n - 1;
+        pidx = valid ? p : a.n - 1;
         xin[0] = a.x[pidx] * a.sx[0] + a.ox[0];
         xin[1] = a.y[pidx] * a.sx[1] + a.ox[1];
         xin[2] = a.t[pidx] * a.sx[2] + a.ox[2];
@@ -650,12 +664,13 @@ struct Fused {
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
             float xin[3];
             bool valid;
-            load_inputs(a, step * TILES + wave, c, xin, valid);
+            long pidx;
+            load_inputs(a, step * TILES + wave, c, xin, valid, pidx);
             x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0 && step == 2 * (long)gridDim.x;      // a steady-state step
             fused_stamp(a, x.tracer, 0);
             {
                 u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
-                forward_tile(a, x, xin, valid, lsum, B, ZL);
+                forward_tile(a, x, xin, valid, pidx, lsum, B, ZL);
                 reverse_tile(a, x, xin, B, ZL);
             }
         }
@@ -683,9 +698,9 @@ struct Fused {
     }
 };
 
-template <class Op, int SPLIT, int WIDTH, int NL>
+template <class Op, int SPLIT, int WIDTH, int NL, int NS>
 __global__ __launch_bounds__(512) void fused_wave_kernel(const FusedArgs a) {
-    Fused<Op, SPLIT, WIDTH, NL>::run(a);
+    Fused<Op, SPLIT, WIDTH, NL, NS>::run(a);
 }
 
 }  // namespace pinn

@@ -270,10 +270,10 @@ struct Host {
     }
 
     // fused path (pinn_fused.hpp): padded width <= 64 and a compiled depth; needs the per-wave state scratch in the workspace
-    template <int NL>
-    static int fused_launch(const Call& c, const Plan& p, int grid) {
+    template <int NL, int NS>
+    static int fused_launch(const Call& c, const Plan& p, int grid, int nterms) {
         if constexpr (WIDTH <= 64) {
-            typedef Fused<Op, SPLIT, WIDTH, NL> F;
+            typedef Fused<Op, SPLIT, WIDTH, NL, NS> F;
             int rc = repack(c, p);
             if (rc) return rc;
             float twmax = 0.0f;
@@ -294,13 +294,14 @@ struct Host {
             a.G = c.G;
             a.rho = c.rho;
             for (int i = 0; i < 8; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
+            a.targets = c.targets;
             a.scratch = reinterpret_cast<u32x4*>(b + p.panels);
             a.loss_part = reinterpret_cast<float*>(b + p.loss_part);
             a.partial = reinterpret_cast<float*>(b + p.partial);
             a.dbg = c.dbg_stamps;
             hipEvent_t ev[2] = {nullptr, nullptr};
             if (c.prof_ms) { hipEventCreate(&ev[0]); hipEventCreate(&ev[1]); hipEventRecord(ev[0], c.stream); }
-            hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL>), dim3(grid), dim3(512), 0, c.stream, a);
+            hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL, NS>), dim3(grid), dim3(512), 0, c.stream, a);
             if ((rc = (int)hipGetLastError())) return rc;
             if (c.prof_ms) {
                 hipEventRecord(ev[1], c.stream);
@@ -310,7 +311,7 @@ struct Host {
                 hipEventDestroy(ev[0]);
                 hipEventDestroy(ev[1]);
             }
-            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * F::TILES, 7, c.loss_out, 0);
+            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * F::TILES, nterms, c.loss_out, 0);
             if ((rc = (int)hipGetLastError())) return rc;
             hipLaunchKernelGGL((reduce_grad_kernel<0>), dim3((c.net.nparams + 63) / 64), dim3(256), 0, c.stream, (const float*)a.partial,
                                grid, c.net.nparams, twmax, c.grad_out, c.accumulate);
@@ -321,20 +322,21 @@ struct Host {
     }
 
     // returns 1 if the fused path ran (rc in *out), 0 if it does not apply
-    static int try_fused(const Call& c, int* out) {
+    template <int NS>
+    static int try_fused(const Call& c, int* out, int nterms) {
         if constexpr (WIDTH <= 64) {
             if (c.net.nl != 4 && c.net.nl != 8) return 0;
             Plan p;
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
-            constexpr int TILES = Fused<Op, SPLIT, WIDTH, 4>::TILES;
-            const size_t per_wg = (size_t)TILES * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8>::SCRATCH_BYTES);
+            constexpr int TILES = Fused<Op, SPLIT, WIDTH, 4, NS>::TILES;
+            const size_t per_wg = (size_t)TILES * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NS>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NS>::SCRATCH_BYTES);
             if (c.ws_bytes < p.fixed_end + per_wg) return 0;
             long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
             if (grid > FUSED_GRID) grid = FUSED_GRID;
             const long nsteps = (c.n + 16 * TILES - 1) / (16 * TILES);
             if (grid > nsteps) grid = nsteps;
-            *out = c.net.nl == 4 ? fused_launch<4>(c, p, (int)grid) : fused_launch<8>(c, p, (int)grid);
+            *out = c.net.nl == 4 ? fused_launch<4, NS>(c, p, (int)grid, nterms) : fused_launch<8, NS>(c, p, (int)grid, nterms);
             return 1;
         } else {
             return 0;
@@ -343,10 +345,14 @@ struct Host {
 
     static int wave_loss_grad(const Call& c) {
         int rc = 0;
-        if (c.use_fused && try_fused(c, &rc)) return rc;
+        if (c.use_fused && try_fused<4>(c, &rc, 7)) return rc;
         return loss_grad<4, HEAD_WAVE>(c, 7);
     }
-    static int data_loss_grad(const Call& c) { return loss_grad<1, HEAD_DATA>(c, c.net.nout); }
+    static int data_loss_grad(const Call& c) {
+        int rc = 0;
+        if (c.use_fused && try_fused<1>(c, &rc, c.net.nout)) return rc;
+        return loss_grad<1, HEAD_DATA>(c, c.net.nout);
+    }
 
     template <int NS>
     static int fields_ns(const Call& c) {

@@ -212,3 +212,27 @@ def test_empty_and_ragged_batches_emulated(emu):
                                  loss.ctypes.data, grad.ctypes.data, False, "f16x3", ws.ctypes.data, wsb)
             assert rel(loss[:7], ss) < 2e-6 and rel(grad, g) < tol, (fused, n)
     emu.set_fused(1)
+
+
+@pytest.mark.parametrize("layers,n,fused", [([3] + 4 * [32] + [7], 150, 1), ([3] + 8 * [64] + [7], 90, 1), ([3] + 8 * [64] + [7], 90, 0)])
+def test_data_terms_fused_and_two_kernel_emulated(emu, layers, n, fused):
+    """value-only side sets (loss_IC / loss_SRC / ...) through the fused kernel's 1-stream instantiation and the two-kernel path"""
+    emu.set_fused(fused)
+    rng = np.random.default_rng(8)
+    Ws, bs = po.xavier_init(layers, rng)
+    bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
+    X = -15 + 30 * rng.random((n, 3))
+    flat = po.pack_params(Ws, bs)
+    p32 = flat.astype(np.float32)
+    x, y, t = (X[:, k].astype(np.float32).copy() for k in range(3))
+    wsb = emu.workspace_bytes(layers, n, "f16x3")
+    ws = aligned(wsb)
+    for tgt, ow in ((rng.standard_normal((n, 7)), np.array([1, 1, 0, 0, 0, 2, 0.5]) / n), (None, np.array([1, 1, 1, 1, 0, 0, 0.0]) / n)):
+        ss, g, _ = po.data_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, False, tgt, ow)
+        tg = None if tgt is None else np.ascontiguousarray(tgt.T.astype(np.float32))
+        loss = np.full(8, np.nan, np.float32)
+        grad = np.full(p32.size, np.nan, np.float32)
+        emu.data_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, False, 0 if tg is None else tg.ctypes.data, ow,
+                           loss.ctypes.data, grad.ctypes.data, False, "f16x3", ws.ctypes.data, wsb)
+        assert rel(loss[:7], ss) < 2e-6 and rel(grad, g) < (2e-4 if fused else 2e-6)
+    emu.set_fused(1)
