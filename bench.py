@@ -72,7 +72,15 @@ def cpu_baseline(sample_pts=32768, reps=3):
     for _ in range(reps):
         m.flat_grad(X)
     dt = (time.perf_counter() - t0) / reps
-    return {"value": sample_pts / dt, "unit": "collocation-points/s", "cores": torch.get_num_threads(), "kind": "port",
+    # second leg: the same numbers by the minimal algorithm (one forward with three tangents + one reverse pass) on the CPU
+    from oracle.tf1_shaped import MinimalWave
+    mm = MinimalWave(Ws, bs, LB, UB, True, dtype=torch.float32)
+    mm.flat_grad(X[:2048])
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        mm.flat_grad(X)
+    dt_min = (time.perf_counter() - t1) / reps
+    return {"value": sample_pts / dt, "minimal_algorithm_value": sample_pts / dt_min, "unit": "collocation-points/s", "cores": torch.get_num_threads(), "kind": "port",
             "host_cpus": os.cpu_count(),
             "sample": f"{reps}x loss+grad of the 8x64 net on {sample_pts} points, fp32, TF1-graph-shaped torch-CPU restatement "
                       f"(oracle/tf1_shaped.py), {dt:.2f} s per pass"}

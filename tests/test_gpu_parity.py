@@ -263,3 +263,21 @@ def test_error_paths(dev):
     with pytest.raises(PinnLibError):
         lib.wave2d_loss_grad(0, layers, 0, 0, 0, 10, LB, UB, True, 2.5, 0.25, 1.0, True, np.ones(7), 0, 0, False, "f16x3", 0, 0)
     assert lib.workspace_bytes([3, 500, 500, 7], 100, "f16x3") == 0      # unsupported width
+
+
+def test_c_abi_from_plain_cpp(dev, tmp_path):
+    """examples/c_abi_demo.cpp: a host program with no Python / PyTorch drives the library (hipMalloc'd buffers, 20 Adam steps)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "c_abi_demo")
+    libdir = os.path.join(root, "pinn_elastodynamics_amd", "lib")
+    subprocess.run([hipcc, "-O2", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "c_abi_demo.cpp"), "-L" + libdir, "-lpinn_hip",
+                    "-Wl,-rpath," + libdir, "-o", exe], check=True, capture_output=True, timeout=600)
+    r = subprocess.run([exe, "50000"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [l for l in r.stdout.splitlines() if l.startswith("step")]
+    l0, l20 = float(lines[0].split()[3]), float(lines[1].split()[3])
+    assert np.isfinite(l0) and 0 < l20 < l0 and "abi 1 ok" in r.stdout
