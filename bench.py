@@ -102,11 +102,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    backend = os.environ.get("PINN_BENCH_BACKEND", "nccl")        # "gloo": dry run of the multi-process path on a 1-GPU box
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=dev)
+        else:
+            torch.distributed.init_process_group(backend)
 
     from pinn_elastodynamics_amd.elastic_wave import DeepHPM
     from pinn_elastodynamics_amd.hip_engine import HipEngine
@@ -140,8 +146,8 @@ def main():
         "value": value, "unit": "collocation-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": "2D elastic wave (infinite), 8x64 tanh MLP, 2M collocation pts per GPU + IC 10201 + SRC 70400, "
-                               "Adam (TF1 rule) step incl. gradient all-reduce",
+        "config": {"workload": f"2D elastic wave (infinite), 8x64 tanh MLP, {args.points_per_gpu} collocation pts per GPU + IC 10201 + SRC 70400, "
+                               "Adam (TF1 rule) step incl. gradient all-reduce (BASELINE configs[1]; x8 GPUs = configs[3])",
                    "collocation_points_global": n_global, "precision_mode": args.precision,
                    "parallelism": f"dp{world}", "final_loss": losses[4][-1]},
     }
