@@ -92,6 +92,31 @@ __device__ __forceinline__ void split2<OpF16>(float a, float b, uint32_t& hi, ui
     lo = l;
 }
 #endif
+// fp16 operands read straight out of a packed dword by the mixed-precision FMA (HALF = 0 / 1 selects the low / high half):
+//   fma<HALF>(w, b, c) = float(half(w)) * b + c        one_minus_sq<HALF>(w) = 1 - float(half(w))^2
+// Only the gfx950 build of the fp16 operand type has it; everything else converts first.
+template <class Op>
+struct MixF16 { static constexpr bool value = false; };
+#if defined(__AMDGCN__) && !defined(PINN_GENERIC_SPLIT)
+template <>
+struct MixF16<OpF16> {
+    static constexpr bool value = true;
+    template <int HALF>
+    static __device__ __forceinline__ float fma(uint32_t w, float b, float c) {
+        float d;
+        if (HALF) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(b), "v"(c));
+        else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(w), "v"(b), "v"(c));
+        return d;
+    }
+    template <int HALF>
+    static __device__ __forceinline__ float one_minus_sq(uint32_t w) {
+        float d;
+        if (HALF) asm("v_fma_mix_f32 %0, -%1, %1, 1.0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(w));
+        else asm("v_fma_mix_f32 %0, -%1, %1, 1.0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(w));
+        return d;
+    }
+};
+#endif
 template <class Op>
 __device__ __forceinline__ float cvt16(uint16_t bits) {
     return (float)__builtin_bit_cast(typename Op::T, bits);

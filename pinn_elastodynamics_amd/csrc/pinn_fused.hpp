@@ -404,21 +404,43 @@ struct Fused {
         if constexpr (MB + 1 < WB) load_afrags<KSB>(x, frag0 + (MB + 1) * KSB, An);
         f32x4 acc[NS], accc[NS];
         gemm_pre<KSB>(Af, Zf, acc, accc);
-        float st[NS][1][4], vals[NS][1][4];
-        state_from_lds<MB>(rowS, st);
-        // reverse of (h = tanh z, hdot_k = (1-h^2) zdot_k)
+        float vals[NS][1][4];
+        // reverse of (h = tanh z, hdot_k = (1-h^2) zdot_k); state of this block from the wave's own LDS rows
+        if constexpr (MixF16<Op>::value) {
+            // fp16 state consumed in place by mixed-precision FMAs (no v_cvt_f32_f16: 64 per layer otherwise)
+            u32x2 sp[NS];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float h = st[0][0][r];
-            const float sd = 1.0f - h * h;
-            float dot = 0.0f;
+            for (int s = 0; s < NS; ++s) sp[s] = *reinterpret_cast<const u32x2*>(rowS + s * PANEL_B + 32 * MB);
 #pragma unroll
-            for (int s = 1; s < NS; ++s) {
-                const float hdb = comb(acc[s], accc[s], r);
-                dot += hdb * st[s][0][r];
-                vals[s][0][r] = sd * hdb;
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t hw = sp[0][r >> 1];
+                const float sd = (r & 1) ? MixF16<Op>::template one_minus_sq<1>(hw) : MixF16<Op>::template one_minus_sq<0>(hw);
+                float dot = 0.0f;
+#pragma unroll
+                for (int s = 1; s < NS; ++s) {
+                    const float hdb = comb(acc[s], accc[s], r);
+                    dot = (r & 1) ? MixF16<Op>::template fma<1>(sp[s][r >> 1], hdb, dot) : MixF16<Op>::template fma<0>(sp[s][r >> 1], hdb, dot);
+                    vals[s][0][r] = sd * hdb;
+                }
+                const float hd = (r & 1) ? MixF16<Op>::template fma<1>(hw, dot, 0.0f) : MixF16<Op>::template fma<0>(hw, dot, 0.0f);
+                vals[0][0][r] = sd * comb(acc[0], accc[0], r) - 2.0f * hd;
             }
-            vals[0][0][r] = sd * comb(acc[0], accc[0], r) - 2.0f * h * dot;
+        } else {
+            float st[NS][1][4];
+            state_from_lds<MB>(rowS, st);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float h = st[0][0][r];
+                const float sd = 1.0f - h * h;
+                float dot = 0.0f;
+#pragma unroll
+                for (int s = 1; s < NS; ++s) {
+                    const float hdb = comb(acc[s], accc[s], r);
+                    dot += hdb * st[s][0][r];
+                    vals[s][0][r] = sd * hdb;
+                }
+                vals[0][0][r] = sd * comb(acc[0], accc[0], r) - 2.0f * h * dot;
+            }
         }
         CH::template emit<KS, MB>(Zn, vals, nullptr, WIDTH, x.c, x.q);
         __builtin_amdgcn_sched_barrier(0);
