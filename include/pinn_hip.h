@@ -32,7 +32,11 @@ enum {
     PINN_PREC_BF16 = 0,   /* bf16 operands, one MFMA per product (BASELINE config "bf16-MFMA/fp32-accum") */
     PINN_PREC_F16X3 = 1,  /* fp16 hi + scaled-lo split, three MFMAs per product: fp32-class accuracy */
     PINN_PREC_F16 = 2,    /* fp16 operands, one MFMA per product */
-    PINN_PREC_BF16X3 = 3  /* bf16 hi/lo split, three MFMAs per product (16-bit significand) */
+    PINN_PREC_BF16X3 = 3, /* bf16 hi/lo split, three MFMAs per product (16-bit significand) */
+    /* OR this into precision_mode when the PREVIOUS call on the same workspace used the same params_flat contents, layers and
+     * mode: the packed MFMA weight fragments are still in the workspace and the repack launch is skipped (the reference feeds
+     * one set of variables to every loss term of a step, INF:297-305; a step makes 3-4 calls). */
+    PINN_FLAG_WEIGHTS_PACKED = 0x100
 };
 
 enum {

@@ -9,6 +9,9 @@ import ctypes as C
 import os
 
 PREC = {"bf16": 0, "f16x3": 1, "f16": 2, "bf16x3": 3}
+FLAG_WEIGHTS_PACKED = 0x100
+for _k in list(PREC):                      # "<mode>+packed": the workspace still holds this call's packed weights (PINN_FLAG_WEIGHTS_PACKED)
+    PREC[_k + "+packed"] = PREC[_k] | FLAG_WEIGHTS_PACKED
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "lib", "libpinn_hip.so")

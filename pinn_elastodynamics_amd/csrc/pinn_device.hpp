@@ -927,6 +927,48 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* partial, 
     }
 }
 
+// Fused-path epilogue: reduce_grad_kernel's blocks plus ONE extra block (the last) that does reduce_loss_kernel's job, so that
+// a call ends with one launch instead of two (the small configurations are bound by the chain of short launches).
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void reduce_grad_loss_kernel(const float* partial, int nchunks, int nparams, float scale, float* grad,
+                                                               int accumulate, const float* loss_part, long nwaves, int nterms,
+                                                               float* loss_terms) {
+    if (blockIdx.x + 1 == gridDim.x) {
+        const int term = threadIdx.x >> 5, sub = threadIdx.x & 31;
+        double s = 0.0;
+        if (term < nterms)
+            for (long w = sub; w < nwaves; w += 32) s += (double)loss_part[w * 8 + term];
+        float v = (float)s;
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        if (sub == 0 && term < nterms) loss_terms[term] = v;
+        return;
+    }
+    __shared__ float sub[4][64];
+    const int pl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long p = (long)blockIdx.x * 64 + pl;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (p < nparams) {
+        int cidx = sl;
+        for (; cidx + 12 < nchunks; cidx += 16) {
+            s0 += partial[(long)cidx * nparams + p];
+            s1 += partial[(long)(cidx + 4) * nparams + p];
+            s2 += partial[(long)(cidx + 8) * nparams + p];
+            s3 += partial[(long)(cidx + 12) * nparams + p];
+        }
+        for (; cidx < nchunks; cidx += 4) s0 += partial[(long)cidx * nparams + p];
+    }
+    sub[sl][pl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && p < nparams) {
+        const float s = (sub[0][pl] + sub[1][pl]) + (sub[2][pl] + sub[3][pl]);
+        grad[p] = (accumulate ? grad[p] : 0.0f) + scale * s;
+    }
+}
+
 // loss_terms[i] (+)= sum over waves of loss_part[w][i]   (one block of 256 threads: 32 lanes per term, nterms <= 8)
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void reduce_loss_kernel(const float* loss_part, long nwaves, int nterms, float* loss_terms,

@@ -39,6 +39,7 @@ struct Call {
     // optional per-kernel timing (host pointer, 4 floats: repack, chain, wgrad, reductions) -- makes the call synchronous
     float* prof_ms;
     unsigned long long* dbg_stamps;   // optional device buffer for the fused kernel's phase timestamps (128 x u64)
+    int weights_packed;        // skip the repack: the workspace already holds the packed form of `params` (same net / precision mode)
     int use_fused;             // 1: prefer the fused kernel where it applies (default), 0: force the two-kernel path
 };
 
@@ -142,6 +143,7 @@ struct Host {
     }
 
     static int repack(const Call& c, const Plan& p) {
+        if (c.weights_packed) return 0;      // PINN_FLAG_WEIGHTS_PACKED: the previous call on this workspace left them in place
         char* b = static_cast<char*>(c.ws);
         RepackArgs ra;
         ra.net = c.net;
@@ -311,10 +313,8 @@ struct Host {
                 hipEventDestroy(ev[0]);
                 hipEventDestroy(ev[1]);
             }
-            hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * F::TILES, nterms, c.loss_out, 0);
-            if ((rc = (int)hipGetLastError())) return rc;
-            hipLaunchKernelGGL((reduce_grad_kernel<0>), dim3((c.net.nparams + 63) / 64), dim3(256), 0, c.stream, (const float*)a.partial,
-                               grid, c.net.nparams, twmax, c.grad_out, c.accumulate);
+            hipLaunchKernelGGL((reduce_grad_loss_kernel<0>), dim3((c.net.nparams + 63) / 64 + 1), dim3(256), 0, c.stream, (const float*)a.partial, grid,
+                               c.net.nparams, twmax, c.grad_out, c.accumulate, (const float*)a.loss_part, (long)grid * F::TILES, nterms, c.loss_out);
             return (int)hipGetLastError();
         } else {
             return PINN_ERR_LAYERS;

@@ -278,7 +278,7 @@ class DeepHPM:
             for o in cols:
                 ow[o] = lay[name] / n
             eng.data_loss_grad(self.theta, x, y, t, self.lb, self.ub, self.normalize, tg, ow,
-                               grad_out=grad, accumulate=wrote, loss_out=buf[P + 8 * k:P + 8 * k + 8])
+                               grad_out=grad, accumulate=wrote, loss_out=buf[P + 8 * k:P + 8 * k + 8], packed=wrote)
             wrote = True
         if not wrote:
             grad.zero_()

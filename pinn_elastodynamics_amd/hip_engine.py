@@ -45,6 +45,10 @@ class HipEngine:
         self._ws_ptr = (self.ws.data_ptr() + 255) // 256 * 256
 
     # ------------------------------------------------------------------------------------------
+    def _mode(self, packed: bool) -> str:
+        """packed=True: the previous call of this engine used the same parameter values, skip the repack launch."""
+        return self.precision + "+packed" if packed else self.precision
+
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
 
@@ -55,7 +59,7 @@ class HipEngine:
             assert t.numel() == n, f"expected {n} elements, got {t.numel()}"
 
     def wave_loss_grad(self, params, x, y, t, lb, ub, normalize, term_weights, E=2.5, mu=0.25, rho=1.0, plane_strain=True,
-                       grad_out: Optional[torch.Tensor] = None, accumulate: bool = False, loss_out: Optional[torch.Tensor] = None):
+                       grad_out: Optional[torch.Tensor] = None, accumulate: bool = False, loss_out: Optional[torch.Tensor] = None, packed: bool = False):
         """Returns (sumsq[7] device tensor, grad_flat).  grad = d/dparams sum_i term_weights[i]*sumsq[i]."""
         n = x.numel()
         for v in (x, y, t):
@@ -68,7 +72,7 @@ class HipEngine:
             loss_out = torch.empty(8, dtype=torch.float32, device=self.device)
         self.lib.wave2d_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize,
                                   E, mu, rho, plane_strain, term_weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate,
-                                  self.precision, self._ws_ptr, self.ws_bytes, self._stream())
+                                  self._mode(packed), self._ws_ptr, self.ws_bytes, self._stream())
         return loss_out[:7], grad_out
 
     def wave_loss_grad_profile(self, params, x, y, t, lb, ub, normalize, term_weights, E=2.5, mu=0.25, rho=1.0, plane_strain=True):
@@ -82,7 +86,7 @@ class HipEngine:
         return dict(zip(("repack", "chain", "wgrad", "reduce"), ms))
 
     def data_loss_grad(self, params, x, y, t, lb, ub, normalize, targets, out_weights,
-                       grad_out: Optional[torch.Tensor] = None, accumulate: bool = False, loss_out: Optional[torch.Tensor] = None):
+                       grad_out: Optional[torch.Tensor] = None, accumulate: bool = False, loss_out: Optional[torch.Tensor] = None, packed: bool = False):
         """Value-only terms.  targets: [n_out, n] device tensor or None.  Returns (sumsq[n_out], grad)."""
         n = x.numel()
         nout = self.layers[-1]
@@ -99,7 +103,7 @@ class HipEngine:
         if loss_out is None:
             loss_out = torch.empty(8, dtype=torch.float32, device=self.device)
         self.lib.data_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize,
-                                tptr, out_weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate, self.precision,
+                                tptr, out_weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate, self._mode(packed),
                                 self._ws_ptr, self.ws_bytes, self._stream())
         return loss_out[:nout], grad_out
 
@@ -146,14 +150,14 @@ class HipEngine:
                                    self.precision, self._ws_ptr, self.ws_bytes, self._stream())
         return loss_out[:5], grad_out
 
-    def traction_loss_grad(self, params, x, y, t, lb, ub, normalize, aux, weights, grad_out=None, accumulate=False, loss_out=None):
+    def traction_loss_grad(self, params, x, y, t, lb, ub, normalize, aux, weights, grad_out=None, accumulate=False, loss_out=None, packed=False):
         """aux: [12, n] = D values, P values, nx, ny.  Returns ((sum tx^2, sum ty^2), grad)."""
         n = x.numel()
         self._chk(aux, 12 * n)
         grad_out, accumulate, loss_out = self._outs(grad_out, accumulate, loss_out)
         self.lib.plate2d_traction_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub,
                                             normalize, aux.data_ptr(), weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate,
-                                            self.precision, self._ws_ptr, self.ws_bytes, self._stream())
+                                            self._mode(packed), self._ws_ptr, self.ws_bytes, self._stream())
         return loss_out[:2], grad_out
 
     def stream_loss_grad(self, params, x, y, t, lb, ub, normalize, targets, weights, grad_out=None, accumulate=False, loss_out=None):

@@ -234,7 +234,7 @@ class PINN:
         if x.numel():
             w = [10.0 / self.n_hole] * 2
             eng.traction_loss_grad(self.theta["uv"], x, y, t, self.lb, self.ub, False, self._aux_hole, w,
-                                   grad_out=grad, accumulate=wrote, loss_out=buf[P + 8:P + 16])
+                                   grad_out=grad, accumulate=wrote, loss_out=buf[P + 8:P + 16], packed=wrote)
             wrote = True
         if not wrote:
             grad.zero_()

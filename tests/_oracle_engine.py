@@ -19,7 +19,7 @@ class OracleEngine:
         return t.detach().cpu().numpy().astype(np.float64)
 
     def wave_loss_grad(self, params, x, y, t, lb, ub, normalize, term_weights, E=2.5, mu=0.25, rho=1.0, plane_strain=True,
-                       grad_out=None, accumulate=False, loss_out=None):
+                       grad_out=None, accumulate=False, loss_out=None, packed=False):
         self.calls.append(("wave", x.numel()))
         ss, g, _ = po.wave2d_loss_grad(self._np(params), self.layers, self._np(x), self._np(y), self._np(t), lb, ub, normalize,
                                        E, mu, rho, plane_strain, np.asarray(term_weights, dtype=np.float64))
@@ -33,7 +33,7 @@ class OracleEngine:
         loss_out[:7].copy_(torch.from_numpy(ss.astype(np.float32)))
         return loss_out[:7], grad_out
 
-    def data_loss_grad(self, params, x, y, t, lb, ub, normalize, targets, out_weights, grad_out=None, accumulate=False, loss_out=None):
+    def data_loss_grad(self, params, x, y, t, lb, ub, normalize, targets, out_weights, grad_out=None, accumulate=False, loss_out=None, packed=False):
         self.calls.append(("data", x.numel()))
         nout = self.layers[-1]
         tg = None if targets is None else self._np(targets).T
@@ -69,18 +69,18 @@ class OracleEngine:
         return loss_out[:n], grad_out
 
     def plate_loss_grad(self, params, x, y, t, lb, ub, normalize, frozen, term_weights, E=20.0, mu=0.25, rho=1.0,
-                        grad_out=None, accumulate=False, loss_out=None):
+                        grad_out=None, accumulate=False, loss_out=None, packed=False):
         fr = self._np(frozen)
         ss, g, _ = pl.plate_loss_grad(self._np(params), self.layers, self._np(x), self._np(y), self._np(t), fr[0], fr[1], E, mu, rho,
                                       np.asarray(term_weights, dtype=np.float64))
         return self._put(g, ss, 5, grad_out, accumulate, loss_out)
 
-    def traction_loss_grad(self, params, x, y, t, lb, ub, normalize, aux, weights, grad_out=None, accumulate=False, loss_out=None):
+    def traction_loss_grad(self, params, x, y, t, lb, ub, normalize, aux, weights, grad_out=None, accumulate=False, loss_out=None, packed=False):
         a = self._np(aux)
         ss, g = pl.traction_loss_grad(self._np(params), self.layers, self._np(x), self._np(y), self._np(t), a[0:5], a[5:10], 0.1, float(weights[0]))
         return self._put(g, ss, 2, grad_out, accumulate, loss_out)
 
-    def stream_loss_grad(self, params, x, y, t, lb, ub, normalize, targets, weights, grad_out=None, accumulate=False, loss_out=None):
+    def stream_loss_grad(self, params, x, y, t, lb, ub, normalize, targets, weights, grad_out=None, accumulate=False, loss_out=None, packed=False):
         w = np.asarray(weights, dtype=np.float64)
         ss, g = pl.stream_loss_grad(self._np(params), self.layers, self._np(x), self._np(y), self._np(t),
                                     None if targets is None else self._np(targets), w)

@@ -236,3 +236,35 @@ def test_data_terms_fused_and_two_kernel_emulated(emu, layers, n, fused):
                            loss.ctypes.data, grad.ctypes.data, False, "f16x3", ws.ctypes.data, wsb)
         assert rel(loss[:7], ss) < 2e-6 and rel(grad, g) < (2e-4 if fused else 2e-6)
     emu.set_fused(1)
+
+
+def test_packed_weights_flag_emulated(emu):
+    """PINN_FLAG_WEIGHTS_PACKED: a second call on the same workspace with the same parameters may skip the repack and must give
+    the same numbers; with different parameters (flag misuse) it would reuse the OLD weights -- shown here as the documented hazard."""
+    layers = [3] + 4 * [32] + [7]
+    rng = np.random.default_rng(2)
+    Ws, bs = po.xavier_init(layers, rng)
+    flat = po.pack_params(Ws, bs)
+    p32 = flat.astype(np.float32)
+    n = 80
+    X = po.collocation_points(n, LB, UB, rng)
+    x, y, t = (np.ascontiguousarray(X[:, k], dtype=np.float32) for k in range(3))
+    wsb = emu.workspace_bytes(layers, n, "f16x3")
+    ws = aligned(wsb)
+    ow = np.array([1, 1, 1, 1, 0, 0, 0.0]) / n
+
+    def data(params, mode):
+        loss, grad = np.full(8, np.nan, np.float32), np.full(p32.size, np.nan, np.float32)
+        emu.data_loss_grad(params.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, True, 0, ow, loss.ctypes.data,
+                           grad.ctypes.data, False, mode, ws.ctypes.data, wsb)
+        return loss[:7].copy(), grad
+
+    l0, g0 = data(p32, "f16x3")
+    l1, g1 = data(p32, "f16x3+packed")
+    np.testing.assert_array_equal(l0, l1)
+    np.testing.assert_array_equal(g0, g1)
+    other = (p32 * 1.5).astype(np.float32)
+    l2, _ = data(other, "f16x3+packed")           # misuse: still the first parameters' fragments
+    np.testing.assert_array_equal(l0, l2)
+    l3, _ = data(other, "f16x3")
+    assert not np.allclose(l0, l3)

@@ -14,3 +14,26 @@ print(f'C1 step {dt*1e3:.3f} ms  -> {50000/dt:.3e} collocation points/s')
 st, en = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 st.record(); m.train(200, 1e-3, 1); en.record(); torch.cuda.synchronize()
 print(f'GPU-side span per step {st.elapsed_time(en)/200:.3f} ms')
+# ---- would a captured graph of the step be faster? (timing probe: Adam's step index is frozen inside the graph)
+P = m.n_params
+def step():
+    m._loss_and_grad(0, 50000)
+    eng.adam_step(m.theta, m.adam_m, m.adam_v, m._buf[:P], 1e-3, 100)
+s = torch.cuda.Stream()
+s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    for _ in range(3):
+        step()
+torch.cuda.current_stream().wait_stream(s)
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    step()
+torch.cuda.synchronize()
+for _ in range(20):
+    g.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(200):
+    g.replay()
+torch.cuda.synchronize()
+print(f'graph replay per step {(time.perf_counter() - t0) / 200 * 1e3:.3f} ms')
