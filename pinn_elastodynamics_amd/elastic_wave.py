@@ -253,11 +253,13 @@ class DeepHPM:
         n = hi - lo
         return lo + n * self.rank // self.world, lo + n * (self.rank + 1) // self.world
 
-    def _loss_and_grad(self, idx_start, idx_end):
+    def _loss_and_grad(self, idx_start, idx_end, sums_out=None):
         """Fills self._buf = [grad (P) | 8 floats per slot] with this rank's partial sums, then
-        all-reduces.  Returns nothing; everything stays on the device."""
+        all-reduces.  Returns nothing; everything stays on the device.  Slots of sets this rank does not hold stay at the zero
+        they were created with (every call overwrites the slots it owns).  Single process only: ``sums_out`` (a view of
+        8*len(_SLOTS) floats, zero where no set exists) receives the sums directly instead of the tail of the buffer."""
         P, lay, eng, buf = self.n_params, self.layout, self.engine, self._buf
-        buf[P:].zero_()
+        sums = buf[P:] if (sums_out is None or self.world > 1) else sums_out
         grad = buf[:P]
         n_blk = idx_end - idx_start
         s, e = self._shard(idx_start, idx_end)
@@ -266,7 +268,7 @@ class DeepHPM:
         if e > s:
             x, y, t = (a[s:e] for a in self._collo)
             eng.wave_loss_grad(self.theta, x, y, t, self.lb, self.ub, self.normalize, tw, self.E, self.mu, self.rho, True,
-                               grad_out=grad, accumulate=False, loss_out=buf[P:P + 8])
+                               grad_out=grad, accumulate=False, loss_out=sums[0:8])
             wrote = True
         for k, name in enumerate(_SLOTS[1:], start=1):
             if name not in self._sides or lay[name] == 0.0:
@@ -278,7 +280,7 @@ class DeepHPM:
             for o in cols:
                 ow[o] = lay[name] / n
             eng.data_loss_grad(self.theta, x, y, t, self.lb, self.ub, self.normalize, tg, ow,
-                               grad_out=grad, accumulate=wrote, loss_out=buf[P + 8 * k:P + 8 * k + 8], packed=wrote)
+                               grad_out=grad, accumulate=wrote, loss_out=sums[8 * k:8 * k + 8], packed=wrote)
             wrote = True
         if not wrote:
             grad.zero_()
@@ -315,10 +317,11 @@ class DeepHPM:
         for i in range(batch_num):
             idx_start = int(i * col_num / batch_num)
             idx_end = int((i + 1) * col_num / batch_num)
-            rec = torch.empty((iter, 8 * len(_SLOTS)), dtype=torch.float32, device=self.device)
+            rec = torch.zeros((iter, 8 * len(_SLOTS)), dtype=torch.float32, device=self.device)
             for it in range(iter):
-                self._loss_and_grad(idx_start, idx_end)
-                rec[it].copy_(self._buf[P:])
+                self._loss_and_grad(idx_start, idx_end, sums_out=rec[it])     # one launch less per step than copying afterwards
+                if self.world > 1:
+                    rec[it].copy_(self._buf[P:])
                 self.adam_t += 1
                 self.engine.adam_step(self.theta, self.adam_m, self.adam_v, self._buf[:P], learning_rate, self.adam_t)
                 if self.verbose and it % 10 == 0 and self.rank == 0:
