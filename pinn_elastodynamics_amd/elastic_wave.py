@@ -255,11 +255,14 @@ class DeepHPM:
 
     def _loss_and_grad(self, idx_start, idx_end, sums_out=None):
         """Fills self._buf = [grad (P) | 8 floats per slot] with this rank's partial sums, then
-        all-reduces.  Returns nothing; everything stays on the device.  Slots of sets this rank does not hold stay at the zero
-        they were created with (every call overwrites the slots it owns).  Single process only: ``sums_out`` (a view of
+        all-reduces.  Returns nothing; everything stays on the device.  Single process only: ``sums_out`` (a view of
         8*len(_SLOTS) floats, zero where no set exists) receives the sums directly instead of the tail of the buffer."""
         P, lay, eng, buf = self.n_params, self.layout, self.engine, self._buf
-        sums = buf[P:] if (sums_out is None or self.world > 1) else sums_out
+        if sums_out is None or self.world > 1:
+            sums = buf[P:]
+            sums.zero_()                    # slots of skipped sets must read zero (getloss toggles the NB weight)
+        else:
+            sums = sums_out
         grad = buf[:P]
         n_blk = idx_end - idx_start
         s, e = self._shard(idx_start, idx_end)

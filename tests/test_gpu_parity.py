@@ -306,3 +306,24 @@ def test_training_trajectory_matches_oracle_engine(dev, case, layers):
     th_g, th_r = m_gpu.theta.cpu().numpy(), m_ref.theta.numpy()
     assert rel(th_g, th_r) < 2e-3          # Adam's sign-like early steps amplify last-digit gradient differences
     assert out_gpu[4][-1] < out_gpu[4][0]
+
+
+def test_lbfgs_stage_on_device(dev):
+    """train_bfgs (INF:321-335): scipy L-BFGS-B on the host, loss and gradient from the kernels; the loss goes down, the callback
+    fires per evaluation and save_NN / load_NN round-trip the result."""
+    import tempfile
+    from pinn_elastodynamics_amd.elastic_wave import DeepHPM
+    rng = np.random.default_rng(6)
+    layers = [3] + 4 * [32] + [7]
+    Collo = po.collocation_points(5000, LB, UB, rng)
+    SRC = po.ricker_source_set(n_pt=20, n_time=30)
+    IC = po.ic_grid(num=15)
+    m = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, case="infinite", seed=3, verbose=False)
+    l0 = m.getloss()[0]
+    m.train_bfgs(batch_num=1, options=dict(maxiter=15, maxfun=20))
+    l1 = m.getloss()[0]
+    assert l1 < 0.7 * l0 and m.count >= 10 and len(m.loss_rec) == m.count
+    with tempfile.TemporaryDirectory() as d:
+        m.save_NN(d + "/uv.pickle")
+        m2 = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, ExistModel=1, modelDir=d + "/uv.pickle", case="infinite", verbose=False)
+    assert torch.equal(m.theta, m2.theta) and abs(m2.getloss()[0] - l1) < 1e-6 * max(1.0, l1)
