@@ -144,6 +144,26 @@ int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_lay
                           float* loss_terms_out, float* grad_flat_out, int accumulate,
                           int precision_mode, void* workspace, size_t ws_bytes, void* stream);
 
+/* Several value-only sets in ONE call (the reference evaluates loss_IC, loss_SRC, loss_NB / loss_FIX of a step from one set of
+ * variables, INF:111-119,297-305): same arithmetic as pinn_data_loss_grad per set, gradients summed, sums of set k written to
+ * sets[k].loss_terms_out[0..n_out).  For nets the fused kernel covers this is one launch instead of n_sets; otherwise the sets
+ * are processed one after the other.  n_sets <= PINN_MAX_SETS; empty sets (n == 0) are skipped and report zeros. */
+#define PINN_MAX_SETS 4
+typedef struct {
+    const float* x;
+    const float* y;
+    const float* t;
+    int64_t n;
+    const float* targets;      /* SoA [n_out][n] or NULL (= 0) */
+    float out_weights[8];
+    float* loss_terms_out;     /* device, >= n_out floats */
+} pinn_point_set;
+int pinn_data_loss_grad_multi(const float* params_flat, const int* layers, int n_layers,
+                              const pinn_point_set* sets, int n_sets,
+                              const double lb[3], const double ub[3], int normalize,
+                              float* grad_flat_out, int accumulate,
+                              int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
 /* Replaces tf.train.AdamOptimizer's update (INF:131-133; TF1 rule: epsilon outside the bias
  * correction).  step is 1-based.  All arrays are length n_params, updated in place. */
 int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_flat, int64_t n_params,

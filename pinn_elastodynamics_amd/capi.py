@@ -17,6 +17,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "lib", "libpinn_hip.so")
 
 
+class PointSet(C.Structure):
+    """pinn_point_set of include/pinn_hip.h"""
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("t", C.c_void_p), ("n", C.c_int64), ("targets", C.c_void_p),
+                ("out_weights", C.c_float * 8), ("loss_terms_out", C.c_void_p)]
+
+
 class PinnLibError(RuntimeError):
     pass
 
@@ -50,6 +56,8 @@ class PinnLib:
         L.pinn_wave2d_loss_grad_profile.restype = i32
         L.pinn_data_loss_grad.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, pf32, vp, vp, i32, i32, vp, sz, vp]
         L.pinn_data_loss_grad.restype = i32
+        L.pinn_data_loss_grad_multi.argtypes = [vp, pi32, i32, C.POINTER(PointSet), i32, pf64, pf64, i32, vp, i32, i32, vp, sz, vp]
+        L.pinn_data_loss_grad_multi.restype = i32
         L.pinn_wave2d_fields.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, i32, vp, sz, vp]
         L.pinn_wave2d_fields.restype = i32
         L.pinn_net_streams.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, i32, vp, sz, vp]
@@ -122,6 +130,17 @@ class PinnLib:
                                           int(bool(normalize)), targets, self._floats(out_weights, 8), loss_out, grad_out,
                                           int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream)
         self.check(rc, "pinn_data_loss_grad")
+
+    def data_loss_grad_multi(self, params, layers, sets, lb, ub, normalize, grad_out, accumulate, prec, ws, ws_bytes, stream=0):
+        """sets: list of (x, y, t, n, targets_or_0, out_weights, loss_out) with device pointers as integers."""
+        arr = (PointSet * len(sets))()
+        for k, (x, y, t, n, tg, ow, lo) in enumerate(sets):
+            arr[k].x, arr[k].y, arr[k].t, arr[k].n, arr[k].targets, arr[k].loss_terms_out = x or None, y or None, t or None, int(n), tg or None, lo
+            for i in range(8):
+                arr[k].out_weights[i] = float(ow[i]) if i < len(ow) else 0.0
+        rc = self.lib.pinn_data_loss_grad_multi(params, self._ints(layers), len(layers), arr, len(sets), self._d3(lb), self._d3(ub),
+                                                int(bool(normalize)), grad_out, int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_data_loss_grad_multi")
 
     def wave2d_fields(self, params, layers, x, y, t, n, lb, ub, normalize, fields_out, prec, ws, ws_bytes, stream=0):
         rc = self.lib.pinn_wave2d_fields(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),

@@ -128,6 +128,8 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     impl = find_impl(precision_mode, width);
     if (!impl) return PINN_ERR_LAYERS;
     c.params = params;
+    c.nsets = 0;
+    c.targets = nullptr;
     c.x = x;
     c.y = y;
     c.t = t;
@@ -233,6 +235,46 @@ int pinn_data_loss_grad(const float* params_flat, const int* layers, int n_layer
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, c.net.nout);
+    return impl->data_loss_grad(c);
+}
+
+int pinn_data_loss_grad_multi(const float* params_flat, const int* layers, int n_layers, const pinn_point_set* sets, int n_sets,
+                              const double lb[3], const double ub[3], int normalize, float* grad_flat_out, int accumulate, int precision_mode,
+                              void* workspace, size_t ws_bytes, void* stream) {
+    if (!sets || n_sets < 1 || n_sets > PINN_MAX_SETS || !grad_flat_out) return n_sets < 1 || n_sets > PINN_MAX_SETS ? PINN_ERR_SIZE : PINN_ERR_NULL;
+    int64_t nmax = 0, ntot = 0;
+    const pinn_point_set* first = nullptr;
+    for (int k = 0; k < n_sets; ++k) {
+        if (sets[k].n < 0) return PINN_ERR_SIZE;
+        if (!sets[k].loss_terms_out || (sets[k].n > 0 && (!sets[k].x || !sets[k].y || !sets[k].t))) return PINN_ERR_NULL;
+        if (sets[k].n > 0 && !first) first = &sets[k];
+        if (sets[k].n > nmax) nmax = sets[k].n;
+        ntot += sets[k].n;
+    }
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, first ? first->x : nullptr, first ? first->y : nullptr, first ? first->t : nullptr, nmax, lb, ub,
+                     normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+    if (rc) return rc;
+    c.grad_out = grad_flat_out;
+    c.accumulate = accumulate;
+    c.targets = nullptr;
+    c.nsets = n_sets;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    for (int k = 0; k < n_sets; ++k) {
+        c.sets[k].x = sets[k].x;
+        c.sets[k].y = sets[k].y;
+        c.sets[k].t = sets[k].t;
+        c.sets[k].targets = sets[k].targets;
+        c.sets[k].n = (long)sets[k].n;
+        for (int i = 0; i < 8; ++i) c.sets[k].tw[i] = i < c.net.nout ? sets[k].out_weights[i] : 0.0f;
+        c.sets[k].loss_out = sets[k].loss_terms_out;
+        if (sets[k].n == 0 && (rc = (int)hipMemsetAsync(sets[k].loss_terms_out, 0, (size_t)c.net.nout * sizeof(float), st))) return rc;
+    }
+    if (ntot == 0) {
+        if (!accumulate) return (int)hipMemsetAsync(grad_flat_out, 0, (size_t)c.net.nparams * sizeof(float), st);
+        return 0;
+    }
     return impl->data_loss_grad(c);
 }
 

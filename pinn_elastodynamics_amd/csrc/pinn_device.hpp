@@ -927,24 +927,28 @@ __global__ __launch_bounds__(256) void reduce_grad_kernel(const float* partial, 
     }
 }
 
-// Fused-path epilogue: reduce_grad_kernel's blocks plus ONE extra block (the last) that does reduce_loss_kernel's job, so that
-// a call ends with one launch instead of two (the small configurations are bound by the chain of short launches).
+// Fused-path epilogue: reduce_grad_kernel's blocks plus one extra block per point set (the last nsets blocks) that do
+// reduce_loss_kernel's job, so that a call ends with one launch instead of two (the small configurations are bound by the chain
+// of short launches).  loss_part is [wave][slots][8] (set k in slot k); set k's sums go to loss_out.p[k][0..nterms).
+struct LossOuts { float* p[4]; };
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void reduce_grad_loss_kernel(const float* partial, int nchunks, int nparams, float scale, float* grad,
-                                                               int accumulate, const float* loss_part, long nwaves, int nterms,
-                                                               float* loss_terms) {
-    if (blockIdx.x + 1 == gridDim.x) {
+                                                               int accumulate, const float* loss_part, long nwaves, int nterms, int nsets,
+                                                               int slots, LossOuts loss_out) {
+    const int grad_blocks = (int)gridDim.x - nsets;
+    if ((int)blockIdx.x >= grad_blocks) {
+        const int k = (int)blockIdx.x - grad_blocks;
         const int term = threadIdx.x >> 5, sub = threadIdx.x & 31;
         double s = 0.0;
         if (term < nterms)
-            for (long w = sub; w < nwaves; w += 32) s += (double)loss_part[w * 8 + term];
+            for (long w = sub; w < nwaves; w += 32) s += (double)loss_part[(w * slots + k) * 8 + term];
         float v = (float)s;
         v += __shfl_xor(v, 1);
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 8);
         v += __shfl_xor(v, 16);
-        if (sub == 0 && term < nterms) loss_terms[term] = v;
+        if (sub == 0 && term < nterms && loss_out.p[k] != nullptr) loss_out.p[k][term] = v;
         return;
     }
     __shared__ float sub[4][64];

@@ -34,6 +34,8 @@ typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
+constexpr int FUSED_MAX_SETS = 4;
+
 struct FusedArgs {
     NetDesc net;
     PackedWeights pw;
@@ -46,7 +48,17 @@ struct FusedArgs {
     float sx[3], ox[3];
     float c1, c2, G, rho;
     float tw[8];
-    const float* targets;      // NS = 1 only: [nout][n] or nullptr (= 0)
+    const float* targets;      // NS = 1 only: [nout][n] or nullptr (= 0)   (single-set form; the set table below supersedes it)
+    // NS = 1: up to FUSED_MAX_SETS value-only point sets in ONE launch (loss_IC, loss_SRC, loss_NB, loss_FIX of a step): set k owns
+    // the workgroup steps [set_step0[k], set_step0[k+1]) and has its own points, targets, output weights and loss slot
+    int nsets;
+    long set_step0[5];
+    const float* set_x[4];
+    const float* set_y[4];
+    const float* set_t[4];
+    const float* set_targets[4];
+    long set_n[4];
+    float set_tw[4][8];
     u32x4* scratch;            // [gridDim.x * TILES][SCRATCH_BYTES]: per-tile images of the parked states
     float* loss_part;          // [gridDim.x * TILES][8]
     float* partial;            // [gridDim.x][nparams]
@@ -532,7 +544,7 @@ struct Fused {
 
     // forward (same arithmetic as chain_kernel) + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
     // parks S_1..S_{NL-1} in the tile's scratch image, returns S_NL (fragments) and the head's adjoint Z_NL, adds the loss sums
-    static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], bool valid, long pidx, float (&lsum)[8],
+    static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], bool valid, long pidx, int set, float (&lsum)[8],
                                                         u32x4 (&B)[NS][1][KS][NP], u32x4 (&ZL)[NS][1][1][NP]) {
         const int c = x.c, q = x.q;
         first_mb<0>(a, x, xin, B);
@@ -622,9 +634,10 @@ struct Fused {
 #pragma unroll
             for (int o = 0; o < 8; ++o) {
                 float d = 0.0f;
-                if (o < a.net.nout) d = Y[0][o] - (a.targets ? a.targets[(long)o * a.n + pidx] : 0.0f);
+                const float* tg = a.set_targets[set];
+                if (o < a.net.nout) d = Y[0][o] - (tg ? tg[(long)o * a.set_n[set] + pidx] : 0.0f);
                 if (q == 0) lsum[o] += vm * d * d;
-                adj[0][o] = 2.0f * a.tw[o] * d * vm;
+                adj[0][o] = 2.0f * a.set_tw[set][o] * d * vm;
             }
         }
         float vals[NS][1][4];
@@ -664,13 +677,14 @@ struct Fused {
         Down<NL - 1>::run(a, x, xin, Zn);
     }
 
-    static __device__ __forceinline__ void load_inputs(const FusedArgs& a, long tile, int c, float (&xin)[3], bool& valid, long& pidx) {
+    static __device__ __forceinline__ void load_inputs(const FusedArgs& a, const float* px, const float* py, const float* pt, long n, long tile, int c,
+                                                       float (&xin)[3], bool& valid, long& pidx) {
         const long p = tile * 16 + c;
-        valid = p < a.n;
-        pidx = valid ? p : a.n - 1;
-        xin[0] = a.x[pidx] * a.sx[0] + a.ox[0];
-        xin[1] = a.y[pidx] * a.sx[1] + a.ox[1];
-        xin[2] = a.t[pidx] * a.sx[2] + a.ox[2];
+        valid = p < n;
+        pidx = valid ? p : n - 1;
+        xin[0] = px[pidx] * a.sx[0] + a.ox[0];
+        xin[1] = py[pidx] * a.sx[1] + a.ox[1];
+        xin[2] = pt[pidx] * a.sx[2] + a.ox[2];
     }
 
     static __device__ __forceinline__ void chain_role(const FusedArgs& a, char* lds, int wave, int lane, int c, int q) {
@@ -679,32 +693,52 @@ struct Fused {
         x.init(a, lds, wave, lane, c, q);
         x.set_tile(a, gwave);
         x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0;
-        float lsum[8];
+        constexpr int NSETS = NS == 1 ? FUSED_MAX_SETS : 1;
+        float lsum[NSETS][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lsum[i] = 0.0f;
+        for (int k = 0; k < NSETS; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) lsum[k][i] = 0.0f;
 
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
             float xin[3];
             bool valid;
             long pidx;
-            load_inputs(a, step * TILES + wave, c, xin, valid, pidx);
+            int set = 0;
+            if constexpr (NS == 1) {
+#pragma unroll
+                for (int k = 1; k < FUSED_MAX_SETS; ++k)
+                    if (k < a.nsets && step >= a.set_step0[k]) set = k;
+                load_inputs(a, a.set_x[set], a.set_y[set], a.set_t[set], a.set_n[set], (step - a.set_step0[set]) * TILES + wave, c, xin, valid, pidx);
+            } else {
+                load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + wave, c, xin, valid, pidx);
+            }
             x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0 && step == 2 * (long)gridDim.x;      // a steady-state step
             fused_stamp(a, x.tracer, 0);
             {
                 u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
-                forward_tile(a, x, xin, valid, pidx, lsum, B, ZL);
+                float ls[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ls[i] = 0.0f;
+                forward_tile(a, x, xin, valid, pidx, set, ls, B, ZL);
+#pragma unroll
+                for (int k = 0; k < NSETS; ++k)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) lsum[k][i] += (k == set) ? ls[i] : 0.0f;
                 reverse_tile(a, x, xin, B, ZL);
             }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float v = lsum[i];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
-            if (lane == 0) a.loss_part[gwave * 8 + i] = v;
-        }
+        for (int k = 0; k < NSETS; ++k)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float v = lsum[k][i];
+                v += __shfl_xor(v, 1);
+                v += __shfl_xor(v, 2);
+                v += __shfl_xor(v, 4);
+                v += __shfl_xor(v, 8);
+                if (lane == 0) a.loss_part[(gwave * NSETS + k) * 8 + i] = v;
+            }
     }
 
     static __device__ void run(const FusedArgs& a) {

@@ -12,6 +12,13 @@
 
 namespace pinn {
 
+struct DataSet {                // one value-only point set of pinn_data_loss_grad_multi
+    const float *x, *y, *t, *targets;
+    long n;
+    float tw[8];
+    float* loss_out;
+};
+
 struct Call {
     NetDesc net;
     const float* params;
@@ -31,6 +38,8 @@ struct Call {
     float tw[8];
     // data head
     const float* targets;
+    int nsets;                 // > 0: pinn_data_loss_grad_multi -- the value-only sets of this call (else the single set x, y, t, n, targets, tw)
+    DataSet sets[4];
     // fields head
     float* fields_out;
     // plate / traction / stream-target heads
@@ -272,14 +281,30 @@ struct Host {
     }
 
     // fused path (pinn_fused.hpp): padded width <= 64 and a compiled depth; needs the per-wave state scratch in the workspace
+    // The value-only sets of a call as a table (a single-set call becomes a table of one).
+    static int data_sets(const Call& c, DataSet (&sets)[4]) {
+        if (c.nsets > 0) {
+            int m = 0;
+            for (int k = 0; k < c.nsets; ++k)
+                if (c.sets[k].n > 0) sets[m++] = c.sets[k];
+            return m;
+        }
+        sets[0].x = c.x;
+        sets[0].y = c.y;
+        sets[0].t = c.t;
+        sets[0].targets = c.targets;
+        sets[0].n = c.n;
+        for (int i = 0; i < 8; ++i) sets[0].tw[i] = c.tw[i];
+        sets[0].loss_out = c.loss_out;
+        return 1;
+    }
+
     template <int NL, int NS>
-    static int fused_launch(const Call& c, const Plan& p, int grid, int nterms) {
+    static int fused_launch(const Call& c, const Plan& p, int grid, int nterms, long nsteps) {
         if constexpr (WIDTH <= 64) {
             typedef Fused<Op, SPLIT, WIDTH, NL, NS> F;
             int rc = repack(c, p);
             if (rc) return rc;
-            float twmax = 0.0f;
-            for (int i = 0; i < 8; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
             char* b = static_cast<char*>(c.ws);
             FusedArgs a;
             a.net = c.net;
@@ -289,14 +314,42 @@ struct Host {
             a.y = c.y;
             a.t = c.t;
             a.n = c.n;
-            a.nsteps = (c.n + 16 * F::TILES - 1) / (16 * F::TILES);
+            a.nsteps = nsteps;
             for (int k = 0; k < 3; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
             a.c1 = c.c1;
             a.c2 = c.c2;
             a.G = c.G;
             a.rho = c.rho;
-            for (int i = 0; i < 8; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
-            a.targets = c.targets;
+            a.targets = nullptr;
+            float twmax = 0.0f;
+            LossOuts lo = {{nullptr, nullptr, nullptr, nullptr}};
+            int nsets = 1;
+            if constexpr (NS == 1) {
+                DataSet sets[4];
+                nsets = data_sets(c, sets);
+                for (int k = 0; k < nsets; ++k)
+                    for (int i = 0; i < 8; ++i) { const float v = sets[k].tw[i] < 0 ? -sets[k].tw[i] : sets[k].tw[i]; if (v > twmax) twmax = v; }
+                long s0 = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const bool on = k < nsets;
+                    a.set_step0[k] = s0;
+                    a.set_x[k] = on ? sets[k].x : nullptr;
+                    a.set_y[k] = on ? sets[k].y : nullptr;
+                    a.set_t[k] = on ? sets[k].t : nullptr;
+                    a.set_targets[k] = on ? sets[k].targets : nullptr;
+                    a.set_n[k] = on ? sets[k].n : 0;
+                    for (int i = 0; i < 8; ++i) a.set_tw[k][i] = on && twmax > 0.0f ? sets[k].tw[i] / twmax : 0.0f;
+                    if (on) { s0 += (sets[k].n + 16 * F::TILES - 1) / (16 * F::TILES); lo.p[k] = sets[k].loss_out; }
+                }
+                a.set_step0[4] = s0;
+                a.nsets = nsets;
+                for (int i = 0; i < 8; ++i) a.tw[i] = 0.0f;
+            } else {
+                for (int i = 0; i < 8; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
+                for (int i = 0; i < 8; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
+                a.nsets = 1;
+                lo.p[0] = c.loss_out;
+            }
             a.scratch = reinterpret_cast<u32x4*>(b + p.panels);
             a.loss_part = reinterpret_cast<float*>(b + p.loss_part);
             a.partial = reinterpret_cast<float*>(b + p.partial);
@@ -313,8 +366,11 @@ struct Host {
                 hipEventDestroy(ev[0]);
                 hipEventDestroy(ev[1]);
             }
-            hipLaunchKernelGGL((reduce_grad_loss_kernel<0>), dim3((c.net.nparams + 63) / 64 + 1), dim3(256), 0, c.stream, (const float*)a.partial, grid,
-                               c.net.nparams, twmax, c.grad_out, c.accumulate, (const float*)a.loss_part, (long)grid * F::TILES, nterms, c.loss_out);
+            // loss partials are [wave][set][8] with set = FUSED_MAX_SETS slots for NS = 1 and one slot for NS = 4
+            constexpr int SLOTS = NS == 1 ? FUSED_MAX_SETS : 1;
+            hipLaunchKernelGGL((reduce_grad_loss_kernel<0>), dim3((c.net.nparams + 63) / 64 + nsets), dim3(256), 0, c.stream, (const float*)a.partial,
+                               grid, c.net.nparams, twmax, c.grad_out, c.accumulate, (const float*)a.loss_part, (long)grid * F::TILES, nterms, nsets,
+                               SLOTS, lo);
             return (int)hipGetLastError();
         } else {
             return PINN_ERR_LAYERS;
@@ -334,9 +390,17 @@ struct Host {
             if (c.ws_bytes < p.fixed_end + per_wg) return 0;
             long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
             if (grid > FUSED_GRID) grid = FUSED_GRID;
-            const long nsteps = (c.n + 16 * TILES - 1) / (16 * TILES);
+            long nsteps = 0;
+            if (NS == 1) {
+                DataSet sets[4];
+                const int m = data_sets(c, sets);
+                for (int k = 0; k < m; ++k) nsteps += (sets[k].n + 16 * TILES - 1) / (16 * TILES);
+            } else {
+                nsteps = (c.n + 16 * TILES - 1) / (16 * TILES);
+            }
+            if (nsteps == 0) return 0;
             if (grid > nsteps) grid = nsteps;
-            *out = c.net.nl == 4 ? fused_launch<4, NS>(c, p, (int)grid, nterms) : fused_launch<8, NS>(c, p, (int)grid, nterms);
+            *out = c.net.nl == 4 ? fused_launch<4, NS>(c, p, (int)grid, nterms, nsteps) : fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
             return 1;
         } else {
             return 0;
@@ -351,7 +415,26 @@ struct Host {
     static int data_loss_grad(const Call& c) {
         int rc = 0;
         if (c.use_fused && try_fused<1>(c, &rc, c.net.nout)) return rc;
-        return loss_grad<1, HEAD_DATA>(c, c.net.nout);
+        if (c.nsets == 0) return loss_grad<1, HEAD_DATA>(c, c.net.nout);
+        // several sets on the two-kernel path: one after the other, accumulating into the same gradient
+        bool first = true;
+        for (int k = 0; k < c.nsets; ++k) {
+            if (c.sets[k].n <= 0) continue;
+            Call s = c;
+            s.nsets = 0;
+            s.x = c.sets[k].x;
+            s.y = c.sets[k].y;
+            s.t = c.sets[k].t;
+            s.n = c.sets[k].n;
+            s.targets = c.sets[k].targets;
+            for (int i = 0; i < 8; ++i) s.tw[i] = c.sets[k].tw[i];
+            s.loss_out = c.sets[k].loss_out;
+            s.accumulate = c.accumulate || !first;
+            s.weights_packed = c.weights_packed || !first;
+            if ((rc = loss_grad<1, HEAD_DATA>(s, c.net.nout))) return rc;
+            first = false;
+        }
+        return 0;
     }
 
     template <int NS>

@@ -273,6 +273,7 @@ class DeepHPM:
             eng.wave_loss_grad(self.theta, x, y, t, self.lb, self.ub, self.normalize, tw, self.E, self.mu, self.rho, True,
                                grad_out=grad, accumulate=False, loss_out=sums[0:8])
             wrote = True
+        side = []
         for k, name in enumerate(_SLOTS[1:], start=1):
             if name not in self._sides or lay[name] == 0.0:
                 continue
@@ -282,8 +283,9 @@ class DeepHPM:
             ow = [0.0] * 7
             for o in cols:
                 ow[o] = lay[name] / n
-            eng.data_loss_grad(self.theta, x, y, t, self.lb, self.ub, self.normalize, tg, ow,
-                               grad_out=grad, accumulate=wrote, loss_out=sums[8 * k:8 * k + 8], packed=wrote)
+            side.append((x, y, t, tg, ow, sums[8 * k:8 * k + 8]))
+        for i in range(0, len(side), 4):           # all value-only sets of the step in one call (up to PINN_MAX_SETS per call)
+            eng.data_loss_grad_multi(self.theta, side[i:i + 4], self.lb, self.ub, self.normalize, grad_out=grad, accumulate=wrote, packed=wrote)
             wrote = True
         if not wrote:
             grad.zero_()

@@ -107,6 +107,22 @@ class HipEngine:
                                 self._ws_ptr, self.ws_bytes, self._stream())
         return loss_out[:nout], grad_out
 
+    def data_loss_grad_multi(self, params, sets, lb, ub, normalize, grad_out, accumulate=False, packed=False):
+        """Several value-only sets in one call.  sets: list of (x, y, t, targets_or_None, out_weights, loss_out[>=n_out]); the sums of
+        set k land in its loss_out, the gradients are summed into grad_out."""
+        self._chk(params, self.n_params)
+        rows = []
+        for x, y, t, tg, ow, lo in sets:
+            n = x.numel()
+            for v in (x, y, t):
+                self._chk(v, n)
+            if tg is not None:
+                self._chk(tg, self.layers[-1] * n)
+            rows.append((x.data_ptr(), y.data_ptr(), t.data_ptr(), n, 0 if tg is None else tg.data_ptr(), ow, lo.data_ptr()))
+        self.lib.data_loss_grad_multi(params.data_ptr(), self.layers, rows, lb, ub, normalize, grad_out.data_ptr(), accumulate, self._mode(packed),
+                                      self._ws_ptr, self.ws_bytes, self._stream())
+        return grad_out
+
     def fields(self, params, x, y, t, lb, ub, normalize):
         """Returns [4, n_out, n]: Y and its derivatives w.r.t. x, y, t."""
         n = x.numel()

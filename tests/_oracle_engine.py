@@ -86,6 +86,12 @@ class OracleEngine:
                                     None if targets is None else self._np(targets), w)
         return self._put(g, ((w / np.abs(w).max()) * ss).sum(0), self.layers[-1], grad_out, accumulate, loss_out)
 
+    def data_loss_grad_multi(self, params, sets, lb, ub, normalize, grad_out, accumulate=False, packed=False):
+        for x, y, t, tg, ow, lo in sets:
+            self.data_loss_grad(params, x, y, t, lb, ub, normalize, tg, ow, grad_out=grad_out, accumulate=accumulate, loss_out=lo)
+            accumulate = True
+        return grad_out
+
     def adam_step(self, params, m, v, grad, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
         th, mm, vv = po.adam_tf1_step(self._np(params), self._np(grad), self._np(m), self._np(v), step, lr, beta1, beta2, eps)
         params.copy_(torch.from_numpy(th.astype(np.float32)))

@@ -268,3 +268,44 @@ def test_packed_weights_flag_emulated(emu):
     np.testing.assert_array_equal(l0, l2)
     l3, _ = data(other, "f16x3")
     assert not np.allclose(l0, l3)
+
+
+@pytest.mark.parametrize("layers,fused", [([3] + 4 * [32] + [7], 1), ([3] + 2 * [48] + [7], 1)])
+def test_data_loss_grad_multi_emulated(emu, layers, fused):
+    """pinn_data_loss_grad_multi: three value-only sets (one of them empty, one with targets) in one call equal three single calls;
+    4x32 takes the fused kernel's set table (one launch), 2x48 the two-kernel loop."""
+    emu.set_fused(fused)
+    rng = np.random.default_rng(9)
+    Ws, bs = po.xavier_init(layers, rng)
+    bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
+    flat = po.pack_params(Ws, bs)
+    p32 = flat.astype(np.float32)
+    sizes = (70, 0, 130)
+    sets, refs, keep = [], [], []
+    g_ref = np.zeros_like(flat)
+    for k, n in enumerate(sizes):
+        X = -15 + 30 * rng.random((max(n, 1), 3))[:n]
+        tgt = rng.standard_normal((n, 7)) if k == 2 else None
+        ow = (np.array([1, 1, 0, 0, 0, 2, 0.5]) if k == 2 else np.array([1, 1, 1, 1, 0, 0, 0.0])) / max(n, 1)
+        x, y, t = (np.ascontiguousarray(X[:, j], dtype=np.float32) for j in range(3))
+        tg = None if tgt is None else np.ascontiguousarray(tgt.T.astype(np.float32))
+        lo = np.full(8, np.nan, np.float32)
+        keep.append((x, y, t, tg, lo))
+        sets.append((x.ctypes.data if n else 0, y.ctypes.data if n else 0, t.ctypes.data if n else 0, n, 0 if tg is None else tg.ctypes.data, ow, lo.ctypes.data))
+        if n:
+            ss, g, _ = po.data_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, False, tgt, ow)
+            g_ref += g
+            refs.append(ss)
+        else:
+            refs.append(np.zeros(7))
+    wsb = emu.workspace_bytes(layers, max(sizes), "f16x3")
+    ws = aligned(wsb)
+    grad = np.full(p32.size, np.nan, np.float32)
+    emu.data_loss_grad_multi(p32.ctypes.data, layers, sets, LB, UB, False, grad.ctypes.data, False, "f16x3", ws.ctypes.data, wsb)
+    for k in range(3):
+        if sizes[k]:
+            assert rel(keep[k][4][:7], refs[k]) < 2e-6, k
+        else:
+            assert np.all(keep[k][4][:7] == 0)
+    assert rel(grad, g_ref) < 2e-4
+    emu.set_fused(1)
