@@ -47,7 +47,7 @@ def main():
     elif a.case == "semi":
         c = ps.semi_infinite_case(MAX_T=a.max_t or 16.0, N_f=a.n_f, **kw)
         model = DeepHPM(c["Collo"], c["SRC"], c["IC"], c["UP"], c["uv_layers"], c["lb"], c["ub"], ExistModel=int(bool(a.load)), modelDir=a.load,
-                        case="semi", precision=a.precision, verbose=rank == 0)
+                        case="semi_infinite", precision=a.precision, verbose=rank == 0)
     else:
         c = ps.confined_case(MAX_T=a.max_t or 14.0, N_f=a.n_f, **kw)
         model = DeepHPMConfined(c["Collo"], c["SRC"], c["IC"], c["FIXED"], None, c["uv_layers"], None, None, c["lb"], c["ub"], uvDir=a.load,
