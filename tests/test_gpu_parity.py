@@ -327,3 +327,18 @@ def test_lbfgs_stage_on_device(dev):
         m.save_NN(d + "/uv.pickle")
         m2 = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, ExistModel=1, modelDir=d + "/uv.pickle", case="infinite", verbose=False)
     assert torch.equal(m.theta, m2.theta) and abs(m2.getloss()[0] - l1) < 1e-6 * max(1.0, l1)
+
+
+@pytest.mark.parametrize("args", [["elastic_wave.py", "--case", "infinite", "--iters", "5", "--n-f", "4000", "--bfgs-iters", "3", "--width", "32"],
+                                  ["elastic_wave.py", "--case", "semi", "--iters", "5", "--n-f", "4000", "--width", "48"],
+                                  ["elastic_wave.py", "--case", "confined", "--iters", "5", "--n-f", "4000", "--width", "64"],
+                                  ["plate_hole.py", "--pre-iters", "5", "--iters", "3", "--bfgs-iters", "3", "--n-collo", "3000", "--n-refine", "500"]])
+def test_example_drivers_run(dev, tmp_path, args):
+    """The drivers shaped like the reference's __main__ blocks run end to end (point sets -> model -> Adam / L-BFGS -> save -> predict)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "examples", args[0])] + args[1:], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "seconds ---" in r.stdout
