@@ -8,7 +8,7 @@ D=$ROOT/build/exp/$NAME
 mkdir -p $D
 echo 'PINN_VARIANT(F16, 3, 64)' > $D/variants.def
 CS=${CS:-$ROOT/pinn_elastodynamics_amd/csrc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$CS -Wno-unused-value -Rpass-analysis=kernel-resource-usage $*"
+FLAGS="--offload-arch=gfx950 ${OPT:--O3} -std=c++17 -fPIC -I$CS -Wno-unused-value -Rpass-analysis=kernel-resource-usage $*"
 /opt/rocm/bin/hipcc $FLAGS -DPINN_VARIANTS_DEF="\"$D/variants.def\"" -c $CS/pinn_capi.hip -o $D/capi.o > $D/build.log 2>&1 &
 /opt/rocm/bin/hipcc $FLAGS -DPINN_INST_OP=F16 -DPINN_INST_SPLIT=3 -DPINN_INST_WIDTH=64 -c $CS/pinn_inst.hip -o $D/inst.o > $D/inst.log 2>&1
 wait
