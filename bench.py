@@ -184,6 +184,9 @@ def main():
                            "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
                            "traffic": traffic, "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch,
                            "algorithmic_flop_per_point": flop_pt,
+                           # what the matrix pipe actually executes in this precision mode: 3 MFMAs per product in the forward and
+                           # reverse chain (8 of the 12 contraction units), 2 in the weight gradient (4 of 12); 1 in the unsplit modes
+                           "issued_mfma_tflops": tflops * ((8 * 3 + 4 * 2) / 12.0 if args.precision in ("f16x3", "bf16x3") else 1.0),
                            "note": "algorithmic flops: one product per contraction; the f16x3 mode issues 3 (forward/reverse chain) "
                                    "or 2 (weight gradient) MFMAs per product"}
         out["kernel_ms_per_step"] = acc
