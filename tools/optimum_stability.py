@@ -1,0 +1,24 @@
+"""Dev tool (GPU): start at the reference's trained infinite-domain weights and run L-BFGS in each precision mode: what happens to the loss
+and to the FEM error.  Evidence for the f16x3 default."""
+import sys, numpy as np, torch
+sys.path.insert(0, '.')
+from pinn_elastodynamics_amd import pointsets as ps
+from pinn_elastodynamics_amd.elastic_wave import DeepHPM
+g = 'tests/golden'
+c = ps.infinite_case(N_f=60000, N_ext=5000, seed=5)
+fem = np.load(f'{g}/fem_inf20s.npz')['fem'].astype(np.float64)
+for prec in ('f16x3', 'bf16'):
+    m = DeepHPM(c['Collo'], c['SRC'], c['IC'], c['UP'], c['uv_layers'], c['lb'], c['ub'], ExistModel=1, modelDir=f'{g}/weights_inf20s.npz', case='infinite',
+                precision=prec, verbose=False)
+    def fem_err():
+        u, v = m.predict(fem[:, 0:1], fem[:, 1:2], fem[:, 2:3])[:2]
+        return ps.relative_l2(u, fem[:, 3]), ps.relative_l2(v, fem[:, 4])
+    l0 = m.getloss(); e0 = fem_err()
+    res = m.train_bfgs(batch_num=1, options=dict(maxiter=60, maxfun=80))
+    l1 = m.getloss(); e1 = fem_err()
+    # evaluate the result with the accurate mode as referee
+    ref = DeepHPM(c['Collo'], c['SRC'], c['IC'], c['UP'], c['uv_layers'], c['lb'], c['ub'], case='infinite', precision='f16x3', verbose=False)
+    ref.theta.copy_(m.theta)
+    lr = ref.getloss()
+    print(f'{prec:6s}: loss {l0[0]:.4e} -> {l1[0]:.4e} (as seen by this mode), referee f16x3 sees {lr[0]:.4e}; f_uv {l0[1]:.3e}->{lr[1]:.3e} f_s {l0[2]:.3e}->{lr[2]:.3e}; '
+          f'FEM rel-L2 u {e0[0]:.3f}->{e1[0]:.3f} v {e0[1]:.3f}->{e1[1]:.3f}; L-BFGS evals {m.count}', flush=True)
