@@ -180,3 +180,19 @@ def test_plate_full_size_properties(dev):
     ss, g, _ = pl.plate_loss_grad(fN, lN, C[:m, 0], C[:m, 1], C[:m, 2], Dst, Pst, term_weights=np.full(5, 10.0 / m))
     l_s, g_s = eN.plate_loss_grad(thN, *(v[:m].contiguous() for v in xs), LB, UB, False, frozen[:, :, :, :m].contiguous(), [10.0 / m] * 5)
     assert rel(l_s.cpu().numpy(), ss) < 5e-5 and rel(g_s.cpu().numpy(), g) < 5e-5
+
+
+def test_plate_training_at_the_reference_optimum_is_stable(dev, golden_dir):
+    """The reference's three trained plate nets (uv 8x70, distance and particular 4x20) on fresh point sets: the composite residual
+    and the hole traction are at the reference's level, and 15 L-BFGS iterations of the main stage do not degrade the loss."""
+    from pinn_elastodynamics_amd import pointsets as ps
+    from pinn_elastodynamics_amd.plate_hole import PINN
+    c = ps.plate_case(seed=9, n_collo=12000, n_refine=6000)
+    paths = {k: f"{golden_dir}/weights_plate_{k}.npz" for k in ("uv", "dist", "part")}
+    m = PINN(c["Collo"], c["HOLE"], c["IC"], c["LF"], c["RT"], c["UP"], c["LW"], c["DIST"], c["uv_layers"], c["dist_layers"], c["part_layers"],
+             c["lb"], c["ub"], partDir=paths["part"], distDir=paths["dist"], uvDir=paths["uv"], verbose=False)
+    l0 = m.getloss()
+    assert l0["loss_f_uv"] < 1e-4 and l0["loss_f_s"] < 1e-4 and l0["loss_HOLE"] < 1e-4 and l0["loss_DIST"] < 1e-3 and l0["loss_PART"] < 1e-3
+    m.train_bfgs(options=dict(maxiter=15, maxfun=20))
+    l1 = m.getloss()
+    assert l1["loss"] <= l0["loss"] * 1.0001
