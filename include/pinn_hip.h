@@ -37,6 +37,7 @@ enum {
      * mode: the packed MFMA weight fragments are still in the workspace and the repack launch is skipped (the reference feeds
      * one set of variables to every loss term of a step, INF:297-305; a step makes 3-4 calls). */
     PINN_FLAG_WEIGHTS_PACKED = 0x100
+    /* PINN_ADJOINT_SHIFT(k), k = 0..24, may be OR'ed in as well: see below */
 };
 
 enum {
@@ -143,6 +144,14 @@ int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_lay
                           const float* targets, const float* weights,
                           float* loss_terms_out, float* grad_flat_out, int accumulate,
                           int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
+/* The 16-bit operand modes run the reverse pass on adjoints  2 w_i f_i / max|w|  (fp16: |x| < 65504).  A residual that is
+ * orders of magnitude above its trained size -- the first trial points of an L-BFGS line search far from the optimum, a stiff
+ * material -- can overflow that range; the sums of squares stay finite but the gradient comes back non-finite.  OR
+ * PINN_ADJOINT_SHIFT(k) into precision_mode to run the reverse pass on adjoints scaled by 2^-k (the gradient is scaled back
+ * by 2^k in the reduction, so the result is the same number); k > 0 costs accuracy only for adjoint elements that drop below
+ * fp16's normal range.  The host classes raise k when a gradient comes back non-finite and lower it again as the loss falls. */
+#define PINN_ADJOINT_SHIFT(k) (((k) & 0x1f) << 16)
 
 /* Several value-only sets in ONE call (the reference evaluates loss_IC, loss_SRC, loss_NB / loss_FIX of a step from one set of
  * variables, INF:111-119,297-305): same arithmetic as pinn_data_loss_grad per set, gradients summed, sums of set k written to

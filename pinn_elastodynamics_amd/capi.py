@@ -10,6 +10,16 @@ import os
 
 PREC = {"bf16": 0, "f16x3": 1, "f16": 2, "bf16x3": 3}
 FLAG_WEIGHTS_PACKED = 0x100
+def adjoint_shift(k: int) -> int:
+    """PINN_ADJOINT_SHIFT(k) of include/pinn_hip.h"""
+    return (int(k) & 0x1f) << 16
+
+
+def mode_bits(prec) -> int:
+    """precision name (optionally "+packed") or ready-made integer -> the precision_mode argument"""
+    return PREC[prec] if isinstance(prec, str) else int(prec)
+
+
 for _k in list(PREC):                      # "<mode>+packed": the workspace still holds this call's packed weights (PINN_FLAG_WEIGHTS_PACKED)
     PREC[_k + "+packed"] = PREC[_k] | FLAG_WEIGHTS_PACKED
 
@@ -100,16 +110,16 @@ class PinnLib:
         return self.lib.pinn_supported_width(int(h))
 
     def workspace_bytes(self, layers, n, prec) -> int:
-        return int(self.lib.pinn_workspace_bytes(self._ints(layers), len(layers), int(n), PREC[prec]))
+        return int(self.lib.pinn_workspace_bytes(self._ints(layers), len(layers), int(n), mode_bits(prec)))
 
     def min_workspace_bytes(self, layers, prec) -> int:
-        return int(self.lib.pinn_min_workspace_bytes(self._ints(layers), len(layers), PREC[prec]))
+        return int(self.lib.pinn_min_workspace_bytes(self._ints(layers), len(layers), mode_bits(prec)))
 
     def wave2d_loss_grad(self, params, layers, x, y, t, n, lb, ub, normalize, E, mu, rho, plane_strain, term_weights,
                          loss_out, grad_out, accumulate, prec, ws, ws_bytes, stream=0):
         rc = self.lib.pinn_wave2d_loss_grad(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
                                             int(bool(normalize)), float(E), float(mu), float(rho), int(bool(plane_strain)),
-                                            self._floats(term_weights, 7), loss_out, grad_out, int(bool(accumulate)), PREC[prec],
+                                            self._floats(term_weights, 7), loss_out, grad_out, int(bool(accumulate)), mode_bits(prec),
                                             ws, int(ws_bytes), stream)
         self.check(rc, "pinn_wave2d_loss_grad")
 
@@ -120,7 +130,7 @@ class PinnLib:
         rc = self.lib.pinn_wave2d_loss_grad_profile(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb),
                                                     self._d3(ub), int(bool(normalize)), float(E), float(mu), float(rho),
                                                     int(bool(plane_strain)), self._floats(term_weights, 7), loss_out, grad_out,
-                                                    int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream, ms)
+                                                    int(bool(accumulate)), mode_bits(prec), ws, int(ws_bytes), stream, ms)
         self.check(rc, "pinn_wave2d_loss_grad_profile")
         return [float(v) for v in ms]
 
@@ -128,7 +138,7 @@ class PinnLib:
                        accumulate, prec, ws, ws_bytes, stream=0):
         rc = self.lib.pinn_data_loss_grad(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
                                           int(bool(normalize)), targets, self._floats(out_weights, 8), loss_out, grad_out,
-                                          int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream)
+                                          int(bool(accumulate)), mode_bits(prec), ws, int(ws_bytes), stream)
         self.check(rc, "pinn_data_loss_grad")
 
     def data_loss_grad_multi(self, params, layers, sets, lb, ub, normalize, grad_out, accumulate, prec, ws, ws_bytes, stream=0):
@@ -139,24 +149,24 @@ class PinnLib:
             for i in range(8):
                 arr[k].out_weights[i] = float(ow[i]) if i < len(ow) else 0.0
         rc = self.lib.pinn_data_loss_grad_multi(params, self._ints(layers), len(layers), arr, len(sets), self._d3(lb), self._d3(ub),
-                                                int(bool(normalize)), grad_out, int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream)
+                                                int(bool(normalize)), grad_out, int(bool(accumulate)), mode_bits(prec), ws, int(ws_bytes), stream)
         self.check(rc, "pinn_data_loss_grad_multi")
 
     def wave2d_fields(self, params, layers, x, y, t, n, lb, ub, normalize, fields_out, prec, ws, ws_bytes, stream=0):
         rc = self.lib.pinn_wave2d_fields(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
-                                         int(bool(normalize)), fields_out, PREC[prec], ws, int(ws_bytes), stream)
+                                         int(bool(normalize)), fields_out, mode_bits(prec), ws, int(ws_bytes), stream)
         self.check(rc, "pinn_wave2d_fields")
 
     def net_streams(self, params, layers, x, y, t, n, lb, ub, normalize, streams_out, prec, ws, ws_bytes, stream=0):
         rc = self.lib.pinn_net_streams(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
-                                       int(bool(normalize)), streams_out, PREC[prec], ws, int(ws_bytes), stream)
+                                       int(bool(normalize)), streams_out, mode_bits(prec), ws, int(ws_bytes), stream)
         self.check(rc, "pinn_net_streams")
 
     def plate2d_loss_grad(self, params, layers, x, y, t, n, lb, ub, normalize, frozen, E, mu, rho, term_weights, loss_out, grad_out,
                           accumulate, prec, ws, ws_bytes, stream=0):
         rc = self.lib.pinn_plate2d_loss_grad(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
                                              int(bool(normalize)), frozen, float(E), float(mu), float(rho),
-                                             self._floats(term_weights, 5), loss_out, grad_out, int(bool(accumulate)), PREC[prec],
+                                             self._floats(term_weights, 5), loss_out, grad_out, int(bool(accumulate)), mode_bits(prec),
                                              ws, int(ws_bytes), stream)
         self.check(rc, "pinn_plate2d_loss_grad")
 
@@ -164,7 +174,7 @@ class PinnLib:
                                    prec, ws, ws_bytes, stream=0):
         rc = self.lib.pinn_plate2d_traction_loss_grad(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb),
                                                       self._d3(ub), int(bool(normalize)), aux, self._floats(weights, 2), loss_out,
-                                                      grad_out, int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream)
+                                                      grad_out, int(bool(accumulate)), mode_bits(prec), ws, int(ws_bytes), stream)
         self.check(rc, "pinn_plate2d_traction_loss_grad")
 
     def stream_loss_grad(self, params, layers, x, y, t, n, lb, ub, normalize, targets, weights, loss_out, grad_out, accumulate, prec,
@@ -172,7 +182,7 @@ class PinnLib:
         w = [float(v) for row in weights for v in row]
         rc = self.lib.pinn_stream_loss_grad(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
                                             int(bool(normalize)), targets, (C.c_float * len(w))(*w), loss_out, grad_out,
-                                            int(bool(accumulate)), PREC[prec], ws, int(ws_bytes), stream)
+                                            int(bool(accumulate)), mode_bits(prec), ws, int(ws_bytes), stream)
         self.check(rc, "pinn_stream_loss_grad")
 
     def adam_step(self, params, m, v, grad, n_params, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, stream=0):

@@ -120,7 +120,8 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     if (n > 0 && (!x || !y || !t)) return PINN_ERR_NULL;          // n == 0 is a valid empty batch (see empty_batch)
     if (normalize && (!lb || !ub)) return PINN_ERR_NULL;
     c.weights_packed = (precision_mode & PINN_FLAG_WEIGHTS_PACKED) ? 1 : 0;
-    precision_mode &= ~PINN_FLAG_WEIGHTS_PACKED;
+    c.adj_shift = (precision_mode >> 16) & 0x1f;
+    precision_mode &= ~(PINN_FLAG_WEIGHTS_PACKED | (0x1f << 16));
     if (precision_mode < 0 || precision_mode > 3) return PINN_ERR_PRECISION;
     int width = 0;
     const int rc = decode_net(layers, n_layers, c.net, width);

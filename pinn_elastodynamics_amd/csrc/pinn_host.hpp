@@ -48,6 +48,7 @@ struct Call {
     // optional per-kernel timing (host pointer, 4 floats: repack, chain, wgrad, reductions) -- makes the call synchronous
     float* prof_ms;
     unsigned long long* dbg_stamps;   // optional device buffer for the fused kernel's phase timestamps (128 x u64)
+    int adj_shift;             // PINN_ADJOINT_SHIFT(k): adjoint seeds scaled by 2^-k inside the kernels, the gradient by 2^k at the reduction
     int weights_packed;        // skip the repack: the workspace already holds the packed form of `params` (same net / precision mode)
     int use_fused;             // 1: prefer the fused kernel where it applies (default), 0: force the two-kernel path
 };
@@ -225,6 +226,7 @@ struct Host {
         toc(0);
         float twmax = 0.0f;
         for (int i = 0; i < 8; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
+        if (HEAD != HEAD_STREAMS) twmax *= (float)(1u << c.adj_shift);      // the weights are only ever used normalised: folds the shift in
         ChainArgs a;
         fill_common(c, p, a);
         for (int i = 0; i < 8; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
@@ -329,6 +331,7 @@ struct Host {
                 nsets = data_sets(c, sets);
                 for (int k = 0; k < nsets; ++k)
                     for (int i = 0; i < 8; ++i) { const float v = sets[k].tw[i] < 0 ? -sets[k].tw[i] : sets[k].tw[i]; if (v > twmax) twmax = v; }
+                twmax *= (float)(1u << c.adj_shift);
                 long s0 = 0;
                 for (int k = 0; k < 4; ++k) {
                     const bool on = k < nsets;
@@ -346,6 +349,7 @@ struct Host {
                 for (int i = 0; i < 8; ++i) a.tw[i] = 0.0f;
             } else {
                 for (int i = 0; i < 8; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
+                twmax *= (float)(1u << c.adj_shift);
                 for (int i = 0; i < 8; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
                 a.nsets = 1;
                 lo.p[0] = c.loss_out;

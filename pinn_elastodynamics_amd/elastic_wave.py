@@ -79,6 +79,35 @@ def unpack_params(flat, layers):
     return Ws, bs
 
 
+def evaluate_with_finite_gradient(engine, evaluate, n_params, state):
+    """Run ``evaluate()`` (it fills and returns the device buffer [grad | sums]) and bring the result to the host.  The 16-bit
+    reverse pass can overflow when residuals are orders of magnitude above their trained size (include/pinn_hip.h,
+    PINN_ADJOINT_SHIFT); the sums of squares are still right then, only the gradient is non-finite.  In that case the adjoint
+    shift of the engine is raised by 4 (x1/16) and the evaluation repeated; once the loss has fallen 256-fold below where the shift
+    was raised, it is lowered again.  ``state`` is a dict the caller keeps between evaluations.  Deterministic in every rank of a
+    data-parallel job (all ranks see the same reduced buffer)."""
+    for _ in range(7):
+        host = evaluate().detach().cpu().numpy()
+        if np.isfinite(host[:n_params]).all():
+            return host
+        if engine.adjoint_shift >= 24:
+            break
+        engine.adjoint_shift = min(engine.adjoint_shift + 4, 24)
+        state["raised_at"] = None                    # filled with the loss of the next successful evaluation
+    raise FloatingPointError("non-finite gradient even with the reverse pass scaled by 2^-24")
+
+
+def relax_adjoint_shift(engine, loss, state):
+    """Companion of evaluate_with_finite_gradient: call with the loss of every successful evaluation."""
+    if engine.adjoint_shift == 0:
+        return
+    if state.get("raised_at") is None:
+        state["raised_at"] = loss
+    elif loss < state["raised_at"] / 256.0:
+        engine.adjoint_shift -= 4
+        state["raised_at"] = loss
+
+
 class DeepHPM:
     """Drop-in for the reference's model class on the wave cases (INF:21-376)."""
 
@@ -86,6 +115,7 @@ class DeepHPM:
                  FIX=None, precision="f16x3", engine=None, seed=1111, process_group=None, verbose=True,
                  E=2.5, mu=0.25, rho=1.0):
         self.count = 0                      # callback counter (INF:26)
+        self._shift_state = {}              # adjoint-shift bookkeeping of evaluate_with_finite_gradient
         self.loss_rec = []                  # SEMI:39
         self.case = case
         self.layout = LOSS_LAYOUT[case]
@@ -323,6 +353,15 @@ class DeepHPM:
             idx_start = int(i * col_num / batch_num)
             idx_end = int((i + 1) * col_num / batch_num)
             rec = torch.zeros((iter, 8 * len(_SLOTS)), dtype=torch.float32, device=self.device)
+
+            def probe():
+                self._loss_and_grad(idx_start, idx_end)
+                return self._buf
+
+            if iter > 0 and getattr(self.engine, "needs_finite_probe", False) and not self._shift_state.get("probed"):
+                # once per model: a synchronous evaluation settles the adjoint shift (Adam's steps are small, it rarely moves after)
+                evaluate_with_finite_gradient(self.engine, probe, P, self._shift_state)
+                self._shift_state["probed"] = True
             for it in range(iter):
                 self._loss_and_grad(idx_start, idx_end, sums_out=rec[it])     # one launch less per step than copying afterwards
                 if self.world > 1:
@@ -333,6 +372,9 @@ class DeepHPM:
                     tm = self._terms_from_sums(rec[it].detach().cpu().numpy().reshape(len(_SLOTS), 8), idx_end - idx_start)
                     print('It: %d, Loss: %.3e' % (it, tm["loss"]))
             sums = rec.detach().cpu().numpy().reshape(iter, len(_SLOTS), 8)
+            if iter > 0 and not bool(torch.isfinite(self.theta).all()):
+                raise FloatingPointError("parameters became non-finite during train(): residuals outgrew the 16-bit reverse pass; "
+                                         "lower the learning rate or raise engine.adjoint_shift")
             for it in range(iter):
                 tm = self._terms_from_sums(sums[it], idx_end - idx_start)
                 loss_f_uv.append(tm["loss_f_uv"])
@@ -357,11 +399,15 @@ class DeepHPM:
             idx_start = int(i * col_num / batch_num)
             idx_end = int((i + 1) * col_num / batch_num)
 
+            def evaluate():
+                self._loss_and_grad(idx_start, idx_end)
+                return self._buf
+
             def fun(theta64):
                 self.theta.copy_(torch.from_numpy(theta64.astype(np.float32)).to(self.device))
-                self._loss_and_grad(idx_start, idx_end)
-                host = self._buf.detach().cpu().numpy()
+                host = evaluate_with_finite_gradient(self.engine, evaluate, P, self._shift_state)
                 tm = self._terms_from_sums(host[P:].reshape(len(_SLOTS), 8), idx_end - idx_start)
+                relax_adjoint_shift(self.engine, tm["loss"], self._shift_state)
                 self.callback(tm["loss"])
                 return tm["loss"], host[:P].astype(np.float64)
 

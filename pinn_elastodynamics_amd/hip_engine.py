@@ -9,7 +9,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from .capi import DEFAULT_LIB, PinnLib, PinnLibError
+from .capi import DEFAULT_LIB, FLAG_WEIGHTS_PACKED, PREC, PinnLib, PinnLibError, adjoint_shift
 
 
 def param_count(layers: Sequence[int]) -> int:
@@ -32,6 +32,8 @@ class HipEngine:
         self.precision = precision
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.n_params = param_count(self.layers)
+        self.adjoint_shift = 0
+        self.needs_finite_probe = True        # 16-bit reverse pass: the model classes check the first gradient (PINN_ADJOINT_SHIFT)
         if self.lib.supported_width(self.layers[1]) == 0:
             raise PinnLibError(f"hidden width {self.layers[1]} is not supported by the compiled kernels")
         want = workspace_bytes if workspace_bytes is not None else self.lib.workspace_bytes(self.layers, max_points, precision)
@@ -45,9 +47,11 @@ class HipEngine:
         self._ws_ptr = (self.ws.data_ptr() + 255) // 256 * 256
 
     # ------------------------------------------------------------------------------------------
-    def _mode(self, packed: bool) -> str:
-        """packed=True: the previous call of this engine used the same parameter values, skip the repack launch."""
-        return self.precision + "+packed" if packed else self.precision
+    def _mode(self, packed: bool) -> int:
+        """precision_mode argument of the loss / gradient calls: the precision, PINN_FLAG_WEIGHTS_PACKED when the previous call of this
+        engine used the same parameter values (skip the repack launch), and the current adjoint shift (``self.adjoint_shift``, see
+        PINN_ADJOINT_SHIFT in include/pinn_hip.h; the model classes adapt it when a gradient comes back non-finite)."""
+        return PREC[self.precision] | (FLAG_WEIGHTS_PACKED if packed else 0) | adjoint_shift(self.adjoint_shift)
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream
@@ -163,7 +167,7 @@ class HipEngine:
         grad_out, accumulate, loss_out = self._outs(grad_out, accumulate, loss_out)
         self.lib.plate2d_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize,
                                    frozen.data_ptr(), E, mu, rho, term_weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate,
-                                   self.precision, self._ws_ptr, self.ws_bytes, self._stream())
+                                   self._mode(False), self._ws_ptr, self.ws_bytes, self._stream())
         return loss_out[:5], grad_out
 
     def traction_loss_grad(self, params, x, y, t, lb, ub, normalize, aux, weights, grad_out=None, accumulate=False, loss_out=None, packed=False):

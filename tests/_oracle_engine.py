@@ -13,6 +13,7 @@ class OracleEngine:
         self.device = torch.device("cpu")
         self.n_params = po.param_count(self.layers)
         self.calls = []
+        self.adjoint_shift = 0
 
     @staticmethod
     def _np(t):

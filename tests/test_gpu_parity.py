@@ -367,3 +367,36 @@ def test_training_at_the_reference_optimum_is_stable(dev, golden_dir):
     loss1 = m.getloss()[0]
     assert loss1 <= loss0 * 1.0001
     assert fem_err() < max(1.1 * e0, 0.2)
+
+
+def test_adjoint_shift_keeps_the_gradient_and_rescues_overflow(dev):
+    """PINN_ADJOINT_SHIFT(k): same sums and (to rounding) the same gradient for moderate k; with residuals inflated until the 16-bit
+    reverse pass overflows, the unshifted gradient is non-finite while the sums stay finite, and a shift brings back the oracle's
+    gradient -- the mechanism the L-BFGS driver relies on at wild line-search points."""
+    layers = [3] + 8 * [64] + [7]
+    Ws, bs, rng = make_net(layers, 15)
+    n = 20000
+    X = po.collocation_points(n, LB, UB, rng)
+    xs = [to_dev(X[:, k], dev) for k in range(3)]
+    eng = engine(layers, "f16x3", dev, n)
+    flat = po.pack_params(Ws, bs)
+    theta = to_dev(flat, dev)
+    tw = np.ones(7) / n
+    l0, g0 = (v.clone() for v in eng.wave_loss_grad(theta, *xs, LB, UB, True, tw))
+    eng.adjoint_shift = 6
+    l6, g6 = (v.clone() for v in eng.wave_loss_grad(theta, *xs, LB, UB, True, tw))
+    assert torch.equal(l0, l6) and rel(g6.cpu().numpy(), g0.cpu().numpy()) < 2e-5
+    # inflate the last layer: outputs (and residuals) x 3000
+    big = [w.copy() for w in Ws]
+    big[-1] = big[-1] * 3000.0
+    flat_b = po.pack_params(big, bs)
+    theta_b = to_dev(flat_b, dev)
+    m = 4000
+    ss, g, _ = po.wave2d_loss_grad(flat_b, layers, X[:m, 0], X[:m, 1], X[:m, 2], LB, UB, True, term_weights=np.ones(7) / m)
+    xm = [v[:m].contiguous() for v in xs]
+    eng.adjoint_shift = 0
+    lb_, gb = eng.wave_loss_grad(theta_b, *xm, LB, UB, True, np.ones(7) / m)
+    assert torch.isfinite(lb_).all() and rel(lb_.cpu().numpy(), ss) < 1e-4 and not bool(torch.isfinite(gb).all())
+    eng.adjoint_shift = 12
+    ls, gs = eng.wave_loss_grad(theta_b, *xm, LB, UB, True, np.ones(7) / m)
+    assert bool(torch.isfinite(gs).all()) and rel(gs.cpu().numpy(), g) < 1e-3

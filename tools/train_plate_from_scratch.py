@@ -1,0 +1,63 @@
+"""Dev tool (GPU): the plate script's whole schedule from fresh weights (PLATE:953-972) under a wall-clock budget, with the error against
+the committed FEM sample (tests/golden/fem_plate.npz, 500 points of each of the frames t = 1.25, 2.5, 3.75, 7.5) printed as training
+proceeds.  The reference's own trained nets reach u 0.5-1.3 %, v 1.7-2.8 %, s11 0.3-0.7 %, s22 4.5-7 %, s12 2-2.5 % on this sample.
+
+    python tools/train_plate_from_scratch.py [budget_seconds] [n_collo] [n_refine]
+"""
+import sys, time, numpy as np, torch, scipy.optimize
+sys.path.insert(0, '.')
+from pinn_elastodynamics_amd import pointsets as ps
+from pinn_elastodynamics_amd.plate_hole import PINN
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+n_collo = int(sys.argv[2]) if len(sys.argv) > 2 else 70000
+n_refine = int(sys.argv[3]) if len(sys.argv) > 3 else 40000
+c = ps.plate_case(n_collo=n_collo, n_refine=n_refine)
+fem = np.load('tests/golden/fem_plate.npz')['fem'].astype(np.float64)
+m = PINN(c['Collo'], c['HOLE'], c['IC'], c['LF'], c['RT'], c['UP'], c['LW'], c['DIST'], c['uv_layers'], c['dist_layers'], c['part_layers'], c['lb'], c['ub'],
+         verbose=False)
+t0 = time.time()
+m.train_bfgs_dist()
+m.train_bfgs_part()
+l = m.getloss()
+print(f'[{time.time()-t0:6.1f} s] pre-training done: loss_DIST {l["loss_DIST"]:.3e} loss_PART {l["loss_PART"]:.3e}  ({m.count} evaluations)', flush=True)
+
+def fem_err():
+    p = m.predict(fem[:, 0:1], fem[:, 1:2], fem[:, 2:3])
+    return [ps.relative_l2(p[j], fem[:, 3 + j]) for j in range(5)]
+
+P = m.theta['uv'].numel()
+state = dict(it=0, evals=0, best=None, t_last=time.time())
+class Budget(Exception):
+    pass
+def fun(th):
+    m.theta['uv'].copy_(torch.from_numpy(th.astype(np.float32)).to(m.device))
+    m._loss_and_grad()
+    host = m._buf.detach().cpu().numpy()
+    state['evals'] += 1
+    return m._terms(host[P:])['loss'], host[:P].astype(np.float64)
+def cb(xk):
+    state['it'] += 1
+    state['best'] = xk.copy()
+    if time.time() - state['t_last'] > 30.0:
+        state['t_last'] = time.time()
+        m.theta['uv'].copy_(torch.from_numpy(xk.astype(np.float32)).to(m.device))
+        m._loss_and_grad()
+        tm = m._terms(m._buf[P:].detach().cpu().numpy())
+        e = fem_err()
+        print(f'[{time.time()-t0:6.1f} s] it {state["it"]:6d} evals {state["evals"]:6d} loss {tm["loss"]:.3e} f_uv {tm["loss_f_uv"]:.2e} f_s {tm["loss_f_s"]:.2e} hole {tm["loss_HOLE"]:.2e}'
+              f' | FEM rel-L2 u {e[0]:.3f} v {e[1]:.3f} s11 {e[2]:.3f} s22 {e[3]:.3f} s12 {e[4]:.3f}', flush=True)
+    if time.time() - t0 > budget:
+        raise Budget()
+x0 = m.theta['uv'].detach().cpu().numpy().astype(np.float64)
+try:
+    scipy.optimize.minimize(fun, x0, jac=True, method='L-BFGS-B', callback=cb,
+                            options=dict(maxiter=70000, maxfun=70000, maxcor=50, maxls=50, ftol=1e-5 * np.finfo(float).eps))
+except Budget:
+    pass
+if state['best'] is not None:
+    m.theta['uv'].copy_(torch.from_numpy(state['best'].astype(np.float32)).to(m.device))
+e = fem_err()
+l = m.getloss()
+print(f'[{time.time()-t0:6.1f} s] final: it {state["it"]} evals {state["evals"]} loss {l["loss"]:.3e} | FEM rel-L2 u {e[0]:.3f} v {e[1]:.3f} s11 {e[2]:.3f} s22 {e[3]:.3f} s12 {e[4]:.3f}')
+m.save_NN('gpurun_out/plate_uv_scratch.npz', TYPE='UV')
