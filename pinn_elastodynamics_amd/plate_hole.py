@@ -17,7 +17,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .elastic_wave import _col, evaluate_with_finite_gradient, pack_params, relax_adjoint_shift, unpack_params, xavier_init
+from .elastic_wave import _col, evaluate_with_finite_gradient, lbfgs_on_device, pack_params, relax_adjoint_shift, unpack_params, xavier_init
 
 _EPS = float(np.finfo(float).eps)
 BFGS_OPTIONS = {   # PLATE:220-247
@@ -280,7 +280,8 @@ class PINN:
         self.theta[key].copy_(torch.from_numpy(res.x.astype(np.float32)).to(self.device))
         return res
 
-    def train_bfgs(self, options: Optional[dict] = None):          # PLATE:508-526
+    def train_bfgs(self, options: Optional[dict] = None, backend: str = "scipy"):          # PLATE:508-526
+        """backend="torch": the optimizer runs on the device too (elastic_wave.lbfgs_on_device)."""
         P = self.theta["uv"].numel()
 
         def evaluate():
@@ -295,7 +296,15 @@ class PINN:
             self.callback(loss)
             return loss, host[:P].astype(np.float64)
 
-        return self._bfgs("uv", fun, dict(BFGS_OPTIONS["uv"], **(options or {})))
+        opts = dict(BFGS_OPTIONS["uv"], **(options or {}))
+        if backend == "torch":
+            def loss_and_grad():
+                host = evaluate_with_finite_gradient(self.eng["uv"], evaluate, 0, self._shift_state, device_check=P)
+                loss = self._terms(host)["loss"]
+                relax_adjoint_shift(self.eng["uv"], loss, self._shift_state)
+                return loss, self._buf[:P]
+            return lbfgs_on_device(self.theta["uv"], loss_and_grad, opts, self.callback)
+        return self._bfgs("uv", fun, opts)
 
     def _pretrain_loss_grad(self, key, sets):
         """sum over sets of mean-square terms (PLATE:194-215); returns (loss, grad) on the host."""

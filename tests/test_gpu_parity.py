@@ -308,7 +308,8 @@ def test_training_trajectory_matches_oracle_engine(dev, case, layers):
     assert out_gpu[4][-1] < out_gpu[4][0]
 
 
-def test_lbfgs_stage_on_device(dev):
+@pytest.mark.parametrize("backend", ["scipy", "torch"])
+def test_lbfgs_stage_on_device(dev, backend):
     """train_bfgs (INF:321-335): scipy L-BFGS-B on the host, loss and gradient from the kernels; the loss goes down, the callback
     fires per evaluation and save_NN / load_NN round-trip the result."""
     import tempfile
@@ -320,7 +321,7 @@ def test_lbfgs_stage_on_device(dev):
     IC = po.ic_grid(num=15)
     m = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, case="infinite", seed=3, verbose=False)
     l0 = m.getloss()[0]
-    m.train_bfgs(batch_num=1, options=dict(maxiter=15, maxfun=20))
+    m.train_bfgs(batch_num=1, options=dict(maxiter=15, maxfun=20), backend=backend)      # "torch": optimizer on the device too
     l1 = m.getloss()[0]
     assert l1 < 0.7 * l0 and m.count >= 10 and len(m.loss_rec) == m.count
     with tempfile.TemporaryDirectory() as d:

@@ -126,3 +126,18 @@ def test_data_parallel_two_ranks_matches_single(tmp_path):
     np.testing.assert_allclose(z["theta0"], z["theta1"], rtol=0, atol=0)              # ranks stay bit-identical
     np.testing.assert_allclose(z["theta0"], m.theta.numpy(), rtol=2e-5, atol=2e-7)
     np.testing.assert_allclose(z["loss"], np.array(losses[4]), rtol=1e-4)
+
+
+def test_device_lbfgs_backend_matches_scipy_objective():
+    """train_bfgs(backend="torch"): torch.optim.LBFGS on the flat parameter tensor drives the same loss / gradient; it reaches a
+    loss comparable to scipy's L-BFGS-B in the same number of iterations and fires the callback per evaluation."""
+    Collo, SRC, IC, UP = small_sets(n=200)
+    losses = {}
+    for backend in ("scipy", "torch"):
+        m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), verbose=False, seed=11)
+        l0 = m.getloss()[0]
+        m.train_bfgs(1, options=dict(maxiter=25, maxfun=40), backend=backend)
+        losses[backend] = (l0, m.getloss()[0], m.count)
+    for backend, (l0, l1, count) in losses.items():
+        assert l1 < 0.5 * l0 and count >= 10, backend
+    assert losses["torch"][1] < 3.0 * losses["scipy"][1]

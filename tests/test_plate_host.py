@@ -148,3 +148,10 @@ def test_plate_data_parallel_two_ranks(tmp_path):
     np.testing.assert_array_equal(z["theta0"], z["theta1"])                      # ranks stay bit-identical
     np.testing.assert_allclose(z["loss"], np.array(hist[3]), rtol=1e-4)
     np.testing.assert_allclose(z["theta0"], m.theta["uv"].numpy(), rtol=5e-3, atol=5e-5)      # L-BFGS amplifies summation-order noise
+
+
+def test_plate_device_lbfgs_backend():
+    m, _ = make_model(6)
+    l0 = m.getloss()["loss"]
+    m.train_bfgs(options=dict(maxiter=12, maxfun=20), backend="torch")
+    assert m.getloss()["loss"] < 0.8 * l0

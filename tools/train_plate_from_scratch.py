@@ -2,7 +2,7 @@
 the committed FEM sample (tests/golden/fem_plate.npz, 500 points of each of the frames t = 1.25, 2.5, 3.75, 7.5) printed as training
 proceeds.  The reference's own trained nets reach u 0.5-1.3 %, v 1.7-2.8 %, s11 0.3-0.7 %, s22 4.5-7 %, s12 2-2.5 % on this sample.
 
-    python tools/train_plate_from_scratch.py [budget_seconds] [n_collo] [n_refine]
+    python tools/train_plate_from_scratch.py [budget_seconds] [n_collo] [n_refine] [scipy|torch]
 """
 import sys, time, numpy as np, torch, scipy.optimize
 sys.path.insert(0, '.')
@@ -11,6 +11,7 @@ from pinn_elastodynamics_amd.elastic_wave import evaluate_with_finite_gradient, 
 from pinn_elastodynamics_amd.plate_hole import PINN
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 600.0
+backend = sys.argv[4] if len(sys.argv) > 4 else 'scipy'          # 'torch': optimizer on the device too
 n_collo = int(sys.argv[2]) if len(sys.argv) > 2 else 70000
 n_refine = int(sys.argv[3]) if len(sys.argv) > 3 else 40000
 c = ps.plate_case(n_collo=n_collo, n_refine=n_refine)
@@ -55,10 +56,34 @@ def cb(xk):
     if time.time() - t0 > budget:
         raise Budget()
 x0 = m.theta['uv'].detach().cpu().numpy().astype(np.float64)
-try:
+if backend == 'torch':
+    from pinn_elastodynamics_amd.elastic_wave import lbfgs_on_device
+    def loss_and_grad():
+        def evaluate():
+            m._loss_and_grad()
+            return m._buf
+        host = evaluate_with_finite_gradient(m.eng['uv'], evaluate, 0, m._shift_state, device_check=P)
+        loss = m._terms(host)['loss']
+        relax_adjoint_shift(m.eng['uv'], loss, m._shift_state)
+        state['evals'] += 1
+        if time.time() - state['t_last'] > 30.0:
+            state['t_last'] = time.time()
+            e = fem_err()
+            tm = m._terms(host)
+            print(f'[{time.time()-t0:6.1f} s] evals {state["evals"]:6d} loss {tm["loss"]:.3e} f_uv {tm["loss_f_uv"]:.2e} f_s {tm["loss_f_s"]:.2e} hole {tm["loss_HOLE"]:.2e}'
+                  f' | FEM rel-L2 u {e[0]:.3f} v {e[1]:.3f} s11 {e[2]:.3f} s22 {e[3]:.3f} s12 {e[4]:.3f} (at a line-search point)', flush=True)
+        if time.time() - t0 > budget:
+            raise Budget()
+        return loss, m._buf[:P]
+    try:
+        lbfgs_on_device(m.theta['uv'], loss_and_grad, dict(maxiter=70000, maxfun=70000, maxcor=50))
+    except Budget:
+        pass
+else:
+  try:
     scipy.optimize.minimize(fun, x0, jac=True, method='L-BFGS-B', callback=cb,
                             options=dict(maxiter=70000, maxfun=70000, maxcor=50, maxls=50, ftol=1e-5 * np.finfo(float).eps))
-except Budget:
+  except Budget:
     pass
 if state['best'] is not None:
     m.theta['uv'].copy_(torch.from_numpy(state['best'].astype(np.float32)).to(m.device))
