@@ -150,7 +150,8 @@ int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_lay
  * material -- can overflow that range; the sums of squares stay finite but the gradient comes back non-finite.  OR
  * PINN_ADJOINT_SHIFT(k) into precision_mode to run the reverse pass on adjoints scaled by 2^-k (the gradient is scaled back
  * by 2^k in the reduction, so the result is the same number); k > 0 costs accuracy only for adjoint elements that drop below
- * fp16's normal range.  The host classes raise k when a gradient comes back non-finite and lower it again as the loss falls. */
+ * fp16's normal range.  The host classes raise k when a gradient comes back non-finite and lower it again as the loss falls.
+ * (pinn_stream_loss_grad, whose reported sums carry the normalised weights, ignores the shift.) */
 #define PINN_ADJOINT_SHIFT(k) (((k) & 0x1f) << 16)
 
 /* Several value-only sets in ONE call (the reference evaluates loss_IC, loss_SRC, loss_NB / loss_FIX of a step from one set of
