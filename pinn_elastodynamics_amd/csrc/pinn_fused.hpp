@@ -94,7 +94,11 @@ struct Fused {
     // The S tensor is double buffered (layer parity) and filled by LDS-DMA straight from the scratch image, so it is padded
     // to whole 1 KB DMA chunks; the scratch holds the same [stream][point][feature] image per parked layer.
     static constexpr int SBUF_B = (TENSOR_S_B + 1023) / 1024 * 1024;
-    static constexpr int WAVE_B = TENSOR_Z_B + 2 * SBUF_B;
+    // NS = 1 ("SLDS"): one stream's state is small enough to keep S_0..S_NL of a tile in LDS (NL+1 slots), so nothing is parked in
+    // scratch and no LDS-DMA round trip sits between the short layer phases; NS = 4: two slots (layer parity), filled by LDS-DMA
+    static constexpr bool SLDS = NS == 1;
+    static constexpr int S_SLOTS = SLDS ? NL + 1 : 2;
+    static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * SBUF_B;
     static constexpr int LDS_B = 4 * WAVE_B;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
     static constexpr int TILES = 4;                                           // 16-point tiles per workgroup step (one per chain wave)
@@ -187,7 +191,7 @@ struct Fused {
     template <int L>
     static __device__ __forceinline__ void wgrad(const char* lanebase, Acc& A, int quad) {
         const char* zl = lanebase;                  // Z tensor of chain wave 0
-        const char* sl = lanebase + TENSOR_Z_B + (L & 1) * SBUF_B;     // S tensor (parity buffer of layer L) of chain wave 0
+        const char* sl = lanebase + TENSOR_Z_B + (SLDS ? L : (L & 1)) * SBUF_B;     // S tensor (slot of layer L) of chain wave 0
         const int wi = quad >> 1, wo = quad & 1;
         if constexpr (L == 0) {
             if (quad < WB) {
@@ -304,7 +308,7 @@ struct Fused {
             tracer = false;
         }
         __device__ __forceinline__ char* rowZ() const { return tenZ + rowoff; }
-        __device__ __forceinline__ char* rowS(int L) const { return tenZ + TENSOR_Z_B + (L & 1) * SBUF_B + rowoff; }
+        __device__ __forceinline__ char* rowS(int L) const { return tenZ + TENSOR_Z_B + (SLDS ? L : (L & 1)) * SBUF_B + rowoff; }
     };
 
     // chain-layout fragments -> [point][feature] rows of this wave's LDS tensor (row = lane's point, 8 bytes per feature block)
@@ -462,6 +466,7 @@ struct Fused {
     // parked state S_l: asynchronous LDS-DMA of the scratch image into the parity buffer of layer l (no registers involved;
     // completion is covered by the vmcnt(0) of the next workgroup barrier)
     static __device__ __forceinline__ void dma_state(const Ctx& x, int l /*1..NL-1*/) {
+        if constexpr (SLDS) return;
         char* dst = x.tenZ + TENSOR_Z_B + (l & 1) * SBUF_B;
 #pragma unroll
         for (int i = 0; i < SBUF_B / 1024; ++i)
@@ -478,8 +483,12 @@ struct Fused {
     }
     template <int MB>
     static __device__ __forceinline__ void park_state(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
-        park_block<MB>(x, l, Sf);
-        if constexpr (MB + 1 < WB) park_state<MB + 1>(x, l, Sf);
+        if constexpr (SLDS) {
+            if constexpr (MB == 0) put_tensor<KS, WB, 1>(x.rowS(l), Sf);      // the tile's own rows of slot l; nobody else touches them in the forward
+        } else {
+            park_block<MB>(x, l, Sf);
+            if constexpr (MB + 1 < WB) park_state<MB + 1>(x, l, Sf);
+        }
     }
 
     // Force the fragments to be fully computed at this point: without it the compiler sinks the reverse elementwise work past
