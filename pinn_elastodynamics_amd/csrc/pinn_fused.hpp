@@ -94,9 +94,9 @@ struct Fused {
     // The S tensor is double buffered (layer parity) and filled by LDS-DMA straight from the scratch image, so it is padded
     // to whole 1 KB DMA chunks; the scratch holds the same [stream][point][feature] image per parked layer.
     static constexpr int SBUF_B = (TENSOR_S_B + 1023) / 1024 * 1024;
-    // NS = 1 ("SLDS"): one stream's state is small enough to keep S_0..S_NL of a tile in LDS (NL+1 slots), so nothing is parked in
-    // scratch and no LDS-DMA round trip sits between the short layer phases; NS = 4: two slots (layer parity), filled by LDS-DMA
-    static constexpr bool SLDS = NS == 1;
+    // "SLDS": where S_0..S_NL of a tile fit in LDS (NL+1 slots: every 1-stream case, and the 4-stream 4x32 net) nothing is parked in
+    // scratch and no LDS-DMA round trip sits between the layer phases; otherwise two slots (layer parity), filled by LDS-DMA
+    static constexpr bool SLDS = 4 * (TENSOR_Z_B + (NL + 1) * SBUF_B) <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
     static constexpr int S_SLOTS = SLDS ? NL + 1 : 2;
     static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * SBUF_B;
     static constexpr int LDS_B = 4 * WAVE_B;
