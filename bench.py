@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--points-per-gpu", type=int, default=2_000_000)
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "f16", "bf16x3"])
     ap.add_argument("--chunk-points", type=int, default=1 << 18, help="points held in the spill workspace per pass")
-    ap.add_argument("--ramp-seconds", type=float, default=1.0, help="untimed clock-ramp period before the warm-up steps")
+    ap.add_argument("--ramp-steps", type=int, default=100, help="untimed clock-ramp steps before the warm-up steps (~0.7 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--extra-modes", default="bf16", help="comma list of other precision modes to time briefly (rank 0 / N=1)")
     args = ap.parse_args()
@@ -132,9 +132,9 @@ def main():
 
     # clock ramp: the GPU idles at a few hundred MHz; run the step untimed for a moment before the counted warm-up so that the
     # K timed steps see settled clocks (not part of W or K; the weights simply train a little longer)
-    t_ramp = time.perf_counter()
-    while time.perf_counter() - t_ramp < args.ramp_seconds:
-        model.train(5, 1e-3, 1)
+    # (a fixed number of steps, not a time limit: every rank must issue the same sequence of all-reduces)
+    if args.ramp_steps > 0:
+        model.train(args.ramp_steps, 1e-3, 1)
         torch.cuda.synchronize()
     model.train(args.warmup, 1e-3, 1)
     barrier()
