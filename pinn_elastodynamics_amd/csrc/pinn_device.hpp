@@ -29,6 +29,10 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
+// Scale carried by the weights in the fused kernel's fragment format (see repack_kernel / pinn_fused.hpp).  2^5 keeps the low
+// part of the scaled weight in the 16-bit normal range for |w| > 4e-3 (measured on the reference's trained nets: same field /
+// residual / gradient error as 2^11) and lets |w| reach 2047 before the high part overflows fp16.
+constexpr float FUSED_WEIGHT_SCALE = 32.0f;
 constexpr int MAX_WLAYERS = 16;   // weight matrices per net (hidden layers + 1)
 constexpr int NOUT_PAD = 16;      // network outputs are padded to one 16-row MFMA block
 
@@ -88,6 +92,32 @@ __device__ __forceinline__ void split2<OpF16>(float a, float b, uint32_t& hi, ui
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, %2, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
         : "=&v"(l)
         : "v"(h), "s"(nls), "v"(ta), "v"(tb));
+    hi = h;
+    lo = l;
+}
+#endif
+// (a, b) -> packed hi pair and packed UNSCALED low pair  lo = T(x - float(T(x))).  Used for the forward activations of the fused
+// kernel, whose weights carry the 2^11 scale instead (see repack_fused_kernel): measured in tools/precision_study3.py, an
+// unscaled (possibly subnormal) low part of the ACTIVATIONS costs nothing in accuracy, an unscaled low part of the weights does.
+template <class Op>
+__device__ __forceinline__ void split2u(float a, float b, uint32_t& hi, uint32_t& lo) {
+    typename Op::V2 h, l;
+    h[0] = (typename Op::T)a;
+    h[1] = (typename Op::T)b;
+    l[0] = (typename Op::T)(a - (float)h[0]);
+    l[1] = (typename Op::T)(b - (float)h[1]);
+    hi = __builtin_bit_cast(uint32_t, h);
+    lo = __builtin_bit_cast(uint32_t, l);
+}
+#if defined(__AMDGCN__) && !defined(PINN_GENERIC_SPLIT)
+// fp16 on the GPU:  v_cvt_pk_f16_f32 ; v_fma_mixlo_f16 ; v_fma_mixhi_f16  -- 1.5 vector instructions per value
+template <>
+__device__ __forceinline__ void split2u<OpF16>(float a, float b, uint32_t& hi, uint32_t& lo) {
+    const uint32_t h = pack2<OpF16>(a, b);
+    uint32_t l;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(l)
+        : "v"(h), "v"(a), "v"(b));
     hi = h;
     lo = l;
 }
@@ -193,6 +223,7 @@ struct RepackArgs {
     float* bias_mid;
     float* bias_last;
     u32x4* frags;
+    u32x4* frags_fused;        // second copy in the fused kernel's format (see repack_kernel), or nullptr
 };
 
 // k-slot -> feature permutation shared by every A/B fragment pair of the chain
@@ -246,6 +277,7 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackArgs a) {
         else if ((rem -= FI::KS) < FM) { kind = 2; l = 1 + rem / (FI::WB * FI::KS); mb = (rem / FI::KS) % FI::WB; kk = rem % FI::KS; }
         else { kind = 3; mb = rem - FM; }
         uint32_t hi[4], lo[4];
+        float wv[8];
         for (int d = 0; d < 4; ++d) {
             float w2[2];
             for (int e = 0; e < 2; ++e) {
@@ -257,6 +289,8 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackArgs a) {
                 else { wl = nl; in = 16 * mb + c; out = kmap(0, q, j); n_in = H; n_out = NO; }
                 w2[e] = (in < n_in && out < n_out) ? a.params[a.net.w_off[wl] + in * n_out + out] : 0.0f;
             }
+            wv[2 * d] = w2[0];
+            wv[2 * d + 1] = w2[1];
             hi[d] = pack2<Op>(w2[0], w2[1]);
             lo[d] = pack2<Op>((w2[0] - round16<Op>(w2[0])) * Op::LO_SCALE, (w2[1] - round16<Op>(w2[1])) * Op::LO_SCALE);
         }
@@ -267,6 +301,27 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackArgs a) {
         if (NP == 2) {
             u32x4 vl = {lo[0], lo[1], lo[2], lo[3]};
             a.frags[((long)frag * NPS + 1) * 64 + lane] = vl;
+        }
+        // fused-kernel format (pinn_fused.hpp): the WEIGHT carries a scale.  With V = FUSED_WEIGHT_SCALE * w:
+        //   part 0 = T(V), part 1 = T(V - part0)  (the remainder stays in the normal range because V is large),  part 2 = T(part0 / LO_SCALE)
+        // so that  part0.x_hi + part0.x_lo + part1.x_hi  = FUSED_WEIGHT_SCALE * (w.x)  accumulates in ONE MFMA chain (forward, unscaled x_lo)
+        // and      part0.z_hi + part2.z_lo' + part1.z_hi = FUSED_WEIGHT_SCALE * (w.z)  (reverse, z_lo' = LO_SCALE-scaled low part).
+        if (a.frags_fused != nullptr) {
+            if (NP == 2) {
+                uint32_t p0[4], p1[4], p2[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const float v0 = wv[2 * d] * FUSED_WEIGHT_SCALE, v1 = wv[2 * d + 1] * FUSED_WEIGHT_SCALE;
+                    p0[d] = pack2<Op>(v0, v1);
+                    p1[d] = pack2<Op>(v0 - round16<Op>(v0), v1 - round16<Op>(v1));
+                    p2[d] = pack2<Op>(round16<Op>(v0) * (1.0f / Op::LO_SCALE), round16<Op>(v1) * (1.0f / Op::LO_SCALE));
+                }
+                a.frags_fused[((long)frag * 3 + 0) * 64 + lane] = u32x4{p0[0], p0[1], p0[2], p0[3]};
+                a.frags_fused[((long)frag * 3 + 1) * 64 + lane] = u32x4{p1[0], p1[1], p1[2], p1[3]};
+                a.frags_fused[((long)frag * 3 + 2) * 64 + lane] = u32x4{p2[0], p2[1], p2[2], p2[3]};
+            } else {
+                a.frags_fused[(long)frag * 64 + lane] = vh;
+            }
         }
     }
     // fp32 side tables

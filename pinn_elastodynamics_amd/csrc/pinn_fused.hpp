@@ -5,18 +5,24 @@
 // [feature][point] panel:
 //   * a workgroup = 8 waves in two roles (2 waves per SIMD, <= 256 registers each): waves 0-3 are
 //     CHAIN waves, each owning a 16-point tile (64 points per workgroup step); waves 4-7 are
-//     WEIGHT-GRADIENT waves, each owning one quadrant of every Wbar_l in persistent accumulators.
-//     The matrix pipe of a SIMD is shared by one wave of each role, so weight-gradient MFMAs fill
-//     the gaps the chain wave leaves while it runs the tanh / tangent VALU chain;
-//   * forward state S_l (fp16, see below) is parked in a per-wave scratch slot as the very
-//     [stream][point][feature] image the LDS hand-off needs and comes back by asynchronous LDS-DMA
-//     (buffer_load ... lds, probed in tools/probes/lds_dma_probe.hip) into a double-buffered LDS
-//     tensor one layer ahead of its use, so the reload costs no registers and no exposed latency;
+//     WEIGHT-GRADIENT waves, each owning one quadrant of every Wbar_l in persistent accumulators;
+//   * what bounds a SIMD here is INSTRUCTION ISSUE, not a pipe (round-2 measurements, tools/probes/coexec_probe.hip: a plain
+//     vector instruction costs ~4.5 cycles of the SIMD whichever wave issues it, a transcendental or packed-fp32 one 8-10, an MFMA
+//     ~6 of issue on top of its 16 pipe cycles, and two waves of one SIMD do not issue concurrently).  So the chain is written for
+//     FEW instructions: the weights carry a scale (repack_kernel's fused format, FUSED_WEIGHT_SCALE), which lets the three MFMAs of a
+//     product accumulate in ONE chain (no per-value recombination), lets the bias ride in as the accumulator's initial value, and
+//     lets the forward activations use an unscaled low part (1.5 instead of 2.5 instructions per value);
+//   * and for OVERLAP INSIDE the wave: the MFMAs of feature block m+1 are issued between the vector instructions of block m
+//     (software pipeline over the blocks of a layer and, in the forward, across layers);
+//   * forward state S_l (fp16 high parts, see below) is parked per tile as its REGISTER IMAGE: one fully coalesced 1 KB store per
+//     (stream, k-step) fragment, issued behind the next weight-fragment loads (CDNA4 returns loads and stores in order on one
+//     counter, so a store in front of a load is waited for with it).  In the reverse pass the weight-gradient wave that shares
+//     the SIMD brings the image back by LDS-DMA (no registers, and off the chain wave's instruction stream); the chain wave reads
+//     its own lanes' records back from LDS and the weight-gradient waves rebuild MFMA fragments from the same image with
+//     ds_read_b64_tr_b16 (the record order is rotated per 16-lane group so that those reads are at most 2-way bank conflicted);
 //   * for the weight gradient  Wbar_l = sum_points S_l^T Z_l  the contraction runs over points, so
 //     both operands are needed "feature per lane, points in registers" -- the transpose of the
-//     chain layout.  Every chain wave drops its S_l and Z_l tiles into LDS as [point][feature] rows
-//     (ds_write_b64) and the weight-gradient waves rebuild MFMA fragments from all four tiles with
-//     ds_read_b64_tr_b16 (semantics probed in tools/probes/tr_read_probe.hip);
+//     chain layout.  Every chain wave drops its Z_l tile into LDS as [point][feature] rows (ds_write_b64);
 //   * the weight-gradient accumulators are PERSISTENT MFMA accumulators, written once per launch
 //     as per-workgroup partials (deterministic two-stage reduction, no atomics).
 // Addressing discipline (this kernel is unrolled over 9 weight layers, so every loop-invariant
@@ -38,7 +44,7 @@ constexpr int FUSED_MAX_SETS = 4;
 
 struct FusedArgs {
     NetDesc net;
-    PackedWeights pw;
+    PackedWeights pw;          // pw.frags: the FUSED-format fragment store (repack_kernel: frags_fused)
     unsigned frags_bytes;      // size of pw.frags
     const float* x;
     const float* y;
@@ -62,6 +68,7 @@ struct FusedArgs {
     u32x4* scratch;            // [gridDim.x * TILES][SCRATCH_BYTES]: per-tile images of the parked states
     float* loss_part;          // [gridDim.x * TILES][8]
     float* partial;            // [gridDim.x][nparams]
+    u32x4* wg_acc;             // [gridDim.x * 4 waves][WG_ACC_BYTES]: weight-gradient accumulators kept in memory (see Fused::NG)
     unsigned long long* dbg;   // optional phase timestamps (s_memtime) of workgroup 0, chain wave 0 / weight-gradient wave 0; nullptr = off
 };
 
@@ -75,37 +82,46 @@ template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4>
 struct Fused {
     static constexpr int NS = NS_, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1;
     static_assert(NS == 4 || NS == 1, "wave residual head (4 streams) or value-only data head (1 stream)");
-    // weight fragments as stored by repack_kernel: [hi, lo, hi*LO_SCALE] when split; the fused kernel accumulates
-    //   acc = (hi*LS).x_hi + hi.x_lo + lo.x_hi = LS * (W.x)   in ONE accumulator per stream (x_lo, lo carry the 2^11 scale)
-    static constexpr int NPS = NP;                     // stored parts per weight fragment: [hi, lo] when split
+    // weight fragments in the fused format of repack_kernel: [T(V), T(V - T(V)), T(T(V)/LO_SCALE)] with V = FUSED_WEIGHT_SCALE * w
+    // when split, [T(w)] otherwise.  Every accumulator of this kernel holds WS * (W . x).
+    static constexpr int P3 = NP == 2 ? 3 : 1;
+    static constexpr float WS = NP == 2 ? FUSED_WEIGHT_SCALE : 1.0f;
+    static constexpr float INV_WS = 1.0f / WS;
     static_assert(WB == 2 || WB == 4, "fused kernel supports padded widths 32 and 64");
     static_assert(NL >= 2, "fused kernel needs at least two hidden layers");
     static constexpr int IBW = WB / 2, OBW = WB / 2;          // weight-gradient wave (i,o) owns IBW x OBW blocks of every mid Wbar
     static constexpr float INV_LS = 1.0f / Op::LO_SCALE;
     typedef Chain<Op, SPLIT, WIDTH, 1, NS, NS == 4 ? HEAD_WAVE : HEAD_DATA> CH;
     typedef FragIndex<WIDTH> FI;
-    // LDS: per chain wave [Z tensor | S tensor]; tensor = NS*NP panels of [16 points][ROWB bytes]
+    // LDS per chain wave: [Z tensor | S images].  Z tensor = NS*NP panels of [16 points][ROWB bytes] (adjoints, hi and scaled lo);
+    // an S image = the NS*KS fragment records (1 KB each: 64 lanes x 16 B) of the state's high parts, lane records rotated (imgoff)
     static constexpr int ROWB = WIDTH * 2 + 8;
     static constexpr int PANEL_B = 16 * ROWB;
     // The parked state S is kept in the operand type's precision only (no low part): measured in tools/precision_study2.py,
     // rounding S for the reverse pass changes the gradient error by < 10 % of itself as long as adjoints and weights stay split.
     static constexpr int TENSOR_Z_B = NS * NP * PANEL_B;
-    static constexpr int TENSOR_S_B = NS * PANEL_B;
-    // The S tensor is double buffered (layer parity) and filled by LDS-DMA straight from the scratch image, so it is padded
-    // to whole 1 KB DMA chunks; the scratch holds the same [stream][point][feature] image per parked layer.
-    static constexpr int SBUF_B = (TENSOR_S_B + 1023) / 1024 * 1024;
+    static constexpr int IMG_B = NS * KS * 1024;
     // "SLDS": where S_0..S_NL of a tile fit in LDS (NL+1 slots: every 1-stream case, and the 4-stream 4x32 net) nothing is parked in
     // scratch and no LDS-DMA round trip sits between the layer phases; otherwise two slots (layer parity), filled by LDS-DMA
-    static constexpr bool SLDS = 4 * (TENSOR_Z_B + (NL + 1) * SBUF_B) <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
+    static constexpr bool SLDS = 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
     static constexpr int S_SLOTS = SLDS ? NL + 1 : 2;
-    static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * SBUF_B;
+    static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * IMG_B;
     static constexpr int LDS_B = 4 * WAVE_B;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
     static constexpr int TILES = 4;                                           // 16-point tiles per workgroup step (one per chain wave)
-    static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * SBUF_B);   // per tile: parked states S_1..S_{NL-1}
+    static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * IMG_B);    // per tile: parked states S_1..S_{NL-1}
+    static __device__ __forceinline__ constexpr int slot_of(int L) { return SLDS ? L : (L & 1); }
 
+    // The NG mid weight layers that the reverse sweep reaches first (L = NL-1 .. NL-NG) keep their accumulator blocks in memory
+    // (loaded in the layer's hand-off window, stored one layer later so that the write acknowledgement never sits in front of a
+    // full drain): with all NL-1 layers in registers the compiler spilled several layers' worth anyway, reloaded and stored them
+    // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
+    static constexpr int NG = NL >= 8 ? 4 : (NL >= 4 ? 2 : 0);
+    static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
+    static constexpr unsigned WG_ACC_BYTES = (unsigned)((NG > 0 ? NG : 1) * IBW * OBW * 1024);
+    static __device__ __forceinline__ constexpr bool in_memory(int L) { return L >= 1 && L <= NL - 1 && L > NREG; }
     struct Acc {                       // persistent across the whole launch, all statically indexed
-        f32x4 mid[NL - 1][IBW][OBW];
+        f32x4 mid[NREG > 0 ? NREG : 1][IBW][OBW];
         f32x4 first;                   // Wbar_0 block (in-block 0, out-block = quad) if quad < WB
         f32x4 last;                    // Wbar_NL block (in-block = quad, out-block 0) if quad < WB
         float bias[NL + 1];
@@ -114,22 +130,35 @@ struct Fused {
     // ---------------------------------------------------------------------------------------------
     // weight-gradient role
     // ---------------------------------------------------------------------------------------------
-    // MFMA fragment "16-feature block at byte column `off` of stream/part panel, 32 points of one k-step" rebuilt from the
-    // chain waves' [point][feature] rows.  k-slot (q, e) <-> chain wave 2j + (q>>1), local point 8(q&1) + e (same map for both
-    // operands); the lane-dependent part of the address lives in `base`, everything else is an immediate.
-    static __device__ __forceinline__ u32x4 get_frag(const char* base, int off) {
+    // MFMA fragment "16-feature block, 32 points of one k-step" rebuilt from the chain waves' LDS data.  k-slot (q, e) <-> chain wave
+    // 2j + (q>>1), local point 8(q&1) + e (same map for both operands); the lane-dependent part of the address lives in the base
+    // pointer(s), everything else is an immediate.
+    //   Z: [point][feature] rows, block at byte column `off`; the second read is 4 rows further on
+    static __device__ __forceinline__ u32x4 zfrag(const char* base, int off) {
         const v4i16 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(base + off));
         const v4i16 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(base + off + 4 * ROWB));
         const u32x2 d0 = __builtin_bit_cast(u32x2, v0), d1 = __builtin_bit_cast(u32x2, v1);
         return u32x4{d0[0], d0[1], d1[0], d1[1]};
     }
+    //   S: the register image; lane (c, q) reads the 8 bytes "features 4(c&3)..+3 of point 8(q&1)+(c>>2) [+4]" = one half of the
+    //   record of chain lane (point, c&3).  The record rotation makes the +4-point address lane dependent: two base pointers.
+    static __device__ __forceinline__ u32x4 sfrag(const char* b0, const char* b1, int off) {
+        const v4i16 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(b0 + off));
+        const v4i16 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(b1 + off));
+        const u32x2 d0 = __builtin_bit_cast(u32x2, v0), d1 = __builtin_bit_cast(u32x2, v1);
+        return u32x4{d0[0], d0[1], d1[0], d1[1]};
+    }
+    // byte offset of lane (c = point, q)'s record inside a 1 KB fragment record block: records of a 16-lane group rotated by 4q
+    static __device__ __forceinline__ unsigned img_record(int point, int q) { return (unsigned)((((point + 4 * q) & 15) + 16 * q) * 16); }
 
-    // NA x NBK blocks of one weight gradient:  acc[a][b] += sum over 64 points, 4 streams of  S(block fa+a)^T . Z(block fb+b).
+    // NA x NBK blocks of one weight gradient:  acc[a][b] += sum over 64 points, NS streams of  S(block fa+a)^T . Z(block fb+b).
     // Operand fragments are fetched once per (k-step, stream) and shared by the NA*NBK blocks; a scheduling fence after every
     // group keeps the compiler from hoisting all transpose-reads of a layer ahead of the MFMAs.
-    // sbase/zbase: lane base of the S / Z tensor of chain wave 0 (+ 32 bytes per feature block already added by the caller).
+    // s0/s1: lane bases of the S image of chain wave 0 (+ the first in-block's offset), NA > 1 steps 8 bytes (the other half of
+    // the record: in-blocks 2k, 2k+1 share a record).  zbase: lane base of the Z tensor of chain wave 0 (+ 32 bytes per out-block).
     template <int NA, int NBK>
-    static __device__ __forceinline__ void wg_blocks(const char* sbase, const char* zbase, f32x4 (&acc)[NA][NBK], float (&bias_out)[NBK]) {
+    static __device__ __forceinline__ void wg_blocks(const char* s0, const char* s1, const char* zbase, f32x4 (&acc)[NA][NBK], float (&bias_out)[NBK]) {
+        static_assert(NA <= 2, "in-blocks of one call share a fragment record");
         f32x4 cc[NA][NBK], bm[NBK], bc[NBK];
 #pragma unroll
         for (int b = 0; b < NBK; ++b) {
@@ -140,40 +169,46 @@ struct Fused {
         }
         const uint32_t one2 = pack2<Op>(1.0f, 1.0f);
         const u32x4 ones = {one2, one2, one2, one2};
-        // software pipeline over the 8 (k-step, stream) groups: the transpose-reads of group g+1 are issued before the MFMAs
-        // of group g, so LDS latency hides behind matrix work; the fence after each group bounds how far the compiler may hoist
+        // software pipeline over the 2*NS (k-step, stream) groups: the transpose-reads of group g+1 are issued before the MFMAs
+        // of group g, so LDS latency hides behind matrix work; the fence after each group bounds how far the compiler may hoist.
+        // Two fragment sets used in strict alternation (no copies: a third set would not fit beside the persistent accumulators).
         struct Frags { u32x4 Ah[NA], Bh[NBK], Bl[NBK]; };
         auto fetch = [&](int g, Frags& f) {
             const int j = g / NS, st = g % NS;
 #pragma unroll
-            for (int a = 0; a < NA; ++a) f.Ah[a] = get_frag(sbase, 2 * j * WAVE_B + st * PANEL_B + 32 * a);
+            for (int a = 0; a < NA; ++a) f.Ah[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * KS * 1024 + 8 * a);
 #pragma unroll
             for (int b = 0; b < NBK; ++b) {
-                f.Bh[b] = get_frag(zbase, 2 * j * WAVE_B + (st * NP) * PANEL_B + 32 * b);
-                if (NP == 2) f.Bl[b] = get_frag(zbase, 2 * j * WAVE_B + (st * NP + 1) * PANEL_B + 32 * b);
+                f.Bh[b] = zfrag(zbase, 2 * j * WAVE_B + (st * NP) * PANEL_B + 32 * b);
+                if (NP == 2) f.Bl[b] = zfrag(zbase, 2 * j * WAVE_B + (st * NP + 1) * PANEL_B + 32 * b);
             }
         };
-        Frags cur, nxt;
-        fetch(0, cur);
-#pragma unroll
-        for (int g = 0; g < 2 * NS; ++g) {
-            if (g + 1 < 2 * NS) fetch(g + 1, nxt);
+        auto work = [&](int g, const Frags& f) {
 #pragma unroll
             for (int a = 0; a < NA; ++a)
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
-                    acc[a][b] = Op::mfma(cur.Ah[a], cur.Bh[b], acc[a][b]);
-                    if (NP == 2) cc[a][b] = Op::mfma(cur.Ah[a], cur.Bl[b], cc[a][b]);
+                    acc[a][b] = Op::mfma(f.Ah[a], f.Bh[b], acc[a][b]);
+                    if (NP == 2) cc[a][b] = Op::mfma(f.Ah[a], f.Bl[b], cc[a][b]);
                 }
             if (g % NS == 0) {                    // bias gradient = ones^T . Z (value stream)
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
-                    bm[b] = Op::mfma(ones, cur.Bh[b], bm[b]);
-                    if (NP == 2) bc[b] = Op::mfma(ones, cur.Bl[b], bc[b]);
+                    bm[b] = Op::mfma(ones, f.Bh[b], bm[b]);
+                    if (NP == 2) bc[b] = Op::mfma(ones, f.Bl[b], bc[b]);
                 }
             }
+        };
+        Frags fa, fb;
+        fetch(0, fa);
+#pragma unroll
+        for (int g = 0; g < 2 * NS; g += 2) {
+            fetch(g + 1, fb);
+            work(g, fa);
             __builtin_amdgcn_sched_barrier(0);
-            if (g + 1 < 2 * NS) cur = nxt;
+            if (g + 2 < 2 * NS) fetch(g + 2, fa);
+            work(g + 1, fb);
+            __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
         for (int b = 0; b < NBK; ++b) {
@@ -187,17 +222,26 @@ struct Fused {
         }
     }
 
-    // weight gradient of weight layer L (quad = weight-gradient wave index 0..3); lanebase = LDS base + lane part of the address
+    struct WgCtx {                     // lane bases of a weight-gradient wave (chain wave 0's tensors + the lane part)
+        const char* z;                 // Z tensor rows
+        const char* s0;                // S image slot 0, first four points of the k-slots
+        const char* s1;                // S image slot 0, the +4 points
+    };
+    // byte offset of in-block mb inside an image: fragment record block (mb >> 1), half (mb & 1) of the 16-byte lane record
+    static __device__ __forceinline__ int img_block(int mb) { return (mb >> 1) * 1024 + 8 * (mb & 1); }
+
+    // weight gradient of weight layer L (quad = weight-gradient wave index 0..3)
     template <int L>
-    static __device__ __forceinline__ void wgrad(const char* lanebase, Acc& A, int quad) {
-        const char* zl = lanebase;                  // Z tensor of chain wave 0
-        const char* sl = lanebase + TENSOR_Z_B + (SLDS ? L : (L & 1)) * SBUF_B;     // S tensor (slot of layer L) of chain wave 0
+    static __device__ __forceinline__ void wgrad(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW]) {
+        const char* zl = w.z;
+        const char* s0 = w.s0 + slot_of(L) * IMG_B;
+        const char* s1 = w.s1 + slot_of(L) * IMG_B;
         const int wi = quad >> 1, wo = quad & 1;
         if constexpr (L == 0) {
             if (quad < WB) {
                 f32x4 t[1][1] = {{A.first}};
                 float b[1];
-                wg_blocks<1, 1>(sl, zl + 32 * quad, t, b);
+                wg_blocks<1, 1>(s0, s1, zl + 32 * quad, t, b);
                 A.first = t[0][0];
                 A.bias[0] += b[0];
             }
@@ -205,36 +249,122 @@ struct Fused {
             if (quad < WB) {
                 f32x4 t[1][1] = {{A.last}};
                 float b[1];
-                wg_blocks<1, 1>(sl + 32 * quad, zl, t, b);
+                wg_blocks<1, 1>(s0 + img_block(quad), s1 + img_block(quad), zl, t, b);
                 A.last = t[0][0];
                 if (quad == 0) A.bias[NL] += b[0];
             }
         } else {
             float b[OBW];
-            wg_blocks<IBW, OBW>(sl + 32 * (wi * IBW), zl + 32 * (wo * OBW), A.mid[L - 1], b);
+            if constexpr (in_memory(L)) {
+#pragma unroll
+                for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                    for (int o = 0; o < OBW; ++o) pend[i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+                wg_blocks<IBW, OBW>(s0 + img_block(wi * IBW), s1 + img_block(wi * IBW), zl + 32 * (wo * OBW), pend, b);
+#pragma unroll
+                for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                    for (int o = 0; o < OBW; ++o) pend[i][o] += ld[i][o];
+            } else {
+                wg_blocks<IBW, OBW>(s0 + img_block(wi * IBW), s1 + img_block(wi * IBW), zl + 32 * (wo * OBW), A.mid[L - 1], b);
+            }
             // one bias block per wave per layer: out-block wo*OBW + wi (OBW == 2) or wo (OBW == 1, waves with wi == 0)
             if (OBW == 1) { if (wi == 0) A.bias[L] += b[0]; }
             else A.bias[L] += wi ? b[OBW - 1] : b[0];
         }
     }
 
+    // parked state S_l of chain tile `quad`: asynchronous LDS-DMA of its scratch image into the layer's LDS slot, issued by the
+    // weight-gradient wave that shares the SIMD.  Written as inline assembly on the GPU: through the builtin the compiler treats the
+    // DMA as an LDS store it cannot disambiguate and drains it (s_waitcnt vmcnt(0)) in front of this wave's next transpose-read --
+    // a full memory round trip per layer.  Completion is covered by the counted wait in front of the layer's second barrier.
+    struct DmaSrc {
+#if defined(__AMDGCN__)
+        u32x4 desc;                    // buffer descriptor words (wave-uniform): base, base_hi, bytes, flags
+#else
+        __amdgpu_buffer_rsrc_t rsrc;
+#endif
+        __device__ __forceinline__ void init(char* base, unsigned bytes) {
+#if defined(__AMDGCN__)
+            const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+            desc = u32x4{(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p), (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p >> 32)) & 0xffffu,
+                         bytes, 0x00020000u};
+#else
+            rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+#endif
+        }
+    };
+    static __device__ __forceinline__ void dma_state(const DmaSrc& src, unsigned lane16, char* tile_lds, int l /*1..NL-1*/) {
+        if constexpr (SLDS) return;
+        char* dst = tile_lds + TENSOR_Z_B + slot_of(l) * IMG_B;
+#pragma unroll
+        for (int i = 0; i < IMG_B / 1024; ++i) {
+#if defined(__AMDGCN__)
+            const unsigned lds_addr = (unsigned)(uintptr_t)((lds_void*)(dst + i * 1024));
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                         :: "v"(lane16), "s"(src.desc), "s"(lds_addr), "s"((unsigned)((l - 1) * IMG_B + i * 1024)) : "memory");
+#else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_void*)(dst + i * 1024), 16, lane16, (l - 1) * IMG_B + i * 1024, 0, 0);
+#endif
+        }
+    }
+
+    // accumulator blocks of an in-memory layer: record (L - NREG - 1, i, o) of this wave's 1 KB-record area
+    static __device__ __forceinline__ int acc_record(int L, int i, int o) { return ((L - NREG - 1) * IBW * OBW + i * OBW + o) * 1024; }
+
+    // "wait until at most N of this wave's vector-memory operations are outstanding" (they complete in issue order)
+    template <int N>
+    static __device__ __forceinline__ void wait_vmcnt() {
+#if defined(__AMDGCN__)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory");
+#endif
+    }
+
     template <int L>
     struct WgDown {     // same barrier sequence as the chain role's Down<>
-        static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const char* lanebase, Acc& A, int quad) {
-            __syncthreads();                                   // (chain waves now overwrite the tensors)
+        // vector-memory operations this wave issues in the hand-off window of layer L (between the two barriers), in this order:
+        // the stores of layer L+1's in-memory sums, the loads of layer L's, the LDS-DMA of S_{L-1}
+        static constexpr int N_STORE = in_memory(L + 1) ? IBW * OBW : 0;
+        static constexpr int N_LOAD = in_memory(L) ? IBW * OBW : 0;
+        static constexpr int N_DMA = (!SLDS && L >= 2) ? IMG_B / 1024 : 0;
+        static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const WgCtx& w, const DmaSrc& scr, __amdgpu_buffer_rsrc_t accr,
+                                                   unsigned lane16, char* tile_lds, Acc& A, int quad, f32x4 (&pend)[IBW][OBW]) {
+            __syncthreads();                                   // (chain waves now overwrite the tensors; everything this wave had in flight is done)
             fused_stamp(a, tracer, 64 + 3 * (NL - L));
-            __syncthreads();                                   // tensors of layer L are complete
+            // While the chain waves write their Z rows this wave has nothing to compute: it issues its memory traffic here, off
+            // the critical phase.  The slot of S_{L-1} is free (its last readers finished before the barrier above).
+            if constexpr (in_memory(L + 1)) {                  // the layer before: its sums go back to memory, a whole layer ahead of the next full drain
+#pragma unroll
+                for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                    for (int o = 0; o < OBW; ++o) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[i][o]), accr, lane16, acc_record(L + 1, i, o), 0);
+            }
+            f32x4 ld[IBW][OBW];
+            if constexpr (in_memory(L)) {
+#pragma unroll
+                for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                    for (int o = 0; o < OBW; ++o) ld[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), 0));
+            }
+            if constexpr (L >= 2) dma_state(scr, lane16, tile_lds, L - 1);      // S_{L-1} streams in while layer L is worked on
+            // Second barrier: the tensors of layer L are complete.  This wave's contribution is the LDS-DMA of S_L, issued one layer
+            // ago; everything issued since (the operations above) may stay in flight, so the drain is a COUNTED one.  (A surplus
+            // operation the compiler might add only makes the wait more conservative: completion is in issue order.)
+            __builtin_amdgcn_sched_barrier(0);
+            wait_vmcnt<N_STORE + N_LOAD + N_DMA>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
             fused_stamp(a, tracer, 65 + 3 * (NL - L));
-            wgrad<L>(lanebase, A, quad);
+            wgrad<L>(w, A, quad, ld, pend);
             fused_stamp(a, tracer, 66 + 3 * (NL - L));
-            if constexpr (L >= 1) WgDown<L - 1>::run(a, tracer, lanebase, A, quad);
+            if constexpr (L >= 1) WgDown<L - 1>::run(a, tracer, w, scr, accr, lane16, tile_lds, A, quad, pend);
         }
     };
 
-    static __device__ __forceinline__ void wgrad_role(const FusedArgs& a, const char* lds, int quad, int c, int q) {
+    static __device__ __forceinline__ void wgrad_role(const FusedArgs& a, char* lds, int quad, int lane, int c, int q) {
         Acc A;
 #pragma unroll
-        for (int l = 0; l < NL - 1; ++l)
+        for (int l = 0; l < NREG; ++l)
 #pragma unroll
             for (int i = 0; i < IBW; ++i)
 #pragma unroll
@@ -243,9 +373,30 @@ struct Fused {
         A.last = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
-        const char* lanebase = lds + (q >> 1) * WAVE_B + (8 * (q & 1) + (c >> 2)) * ROWB + 8 * (c & 3);
+        WgCtx w;
+        {
+            const char* wave0 = lds + (q >> 1) * WAVE_B;
+            const int p0 = 8 * (q & 1) + (c >> 2), sub = c & 3;
+            w.z = wave0 + p0 * ROWB + 8 * sub;
+            w.s0 = wave0 + TENSOR_Z_B + img_record(p0, sub);
+            w.s1 = wave0 + TENSOR_Z_B + img_record(p0 + 4, sub);
+        }
+        // this wave feeds chain tile `quad`: descriptor of that tile's scratch image
+        const long gtile = (long)blockIdx.x * TILES + quad;
+        DmaSrc scr;
+        scr.init(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES, SCRATCH_BYTES);
+        const unsigned lane16 = (unsigned)lane * 16u;
+        char* tile_lds = lds + quad * WAVE_B;
+        // this wave's in-memory accumulator records, zeroed here (same-wave program order makes the first loads see the zeros)
+        const __amdgpu_buffer_rsrc_t accr = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(reinterpret_cast<char*>(a.wg_acc) + gtile * (long)WG_ACC_BYTES), 0, (int)WG_ACC_BYTES, 0x00020000);
+        if constexpr (NG > 0) {
+#pragma unroll
+            for (int r = 0; r < NG * IBW * OBW; ++r) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, accr, lane16, r * 1024, 0);
+        }
+        f32x4 pend[IBW][OBW];
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
-            WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, lanebase, A, quad);
+            WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend);
         }
         // ---- write this workgroup's partial gradient
         float* part = a.partial + (long)blockIdx.x * a.net.nparams;
@@ -276,7 +427,12 @@ struct Fused {
 #pragma unroll
             for (int i = 0; i < IBW; ++i)
 #pragma unroll
-                for (int o = 0; o < OBW; ++o) put_block(A.mid[l - 1][i][o], l, wi * IBW + i, wo * OBW + o, H, H);
+                for (int o = 0; o < OBW; ++o) {
+                    f32x4 v;
+                    if (in_memory(l)) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(l, i, o), 0));
+                    else v = A.mid[l <= NREG ? l - 1 : 0][i][o];
+                    put_block(v, l, wi * IBW + i, wo * OBW + o, H, H);
+                }
             const bool owner = OBW == 1 ? wi == 0 : true;
             const int ob = wo * OBW + (OBW == 1 ? 0 : wi);
             if (owner && q == 0 && 16 * ob + c < H) part[a.net.b_off[l] + 16 * ob + c] = A.bias[l];
@@ -288,9 +444,10 @@ struct Fused {
     // ---------------------------------------------------------------------------------------------
     struct Ctx {                                   // wave-invariant addressing state of a chain wave
         __amdgpu_buffer_rsrc_t frags, scr, bias, w0p;
-        unsigned lane16;                           // lane * 16: the only VGPR offset of the fragment / scratch traffic
-        unsigned rowoff;                           // c*ROWB + 8q: this lane's row/column offset inside a tensor image
-        char* tenZ;                                // wave's Z tensor (uniform); S buffers follow at +TENSOR_Z_B (+SBUF_B)
+        unsigned lane16;                           // lane * 16: the only VGPR offset of the fragment traffic
+        unsigned rowoff;                           // c*ROWB + 8q: this lane's row/column offset inside the Z tensor
+        unsigned imgoff;                           // this lane's (rotated) 16-byte record inside a fragment record block of an S image
+        char* tenZ;                                // wave's Z tensor (uniform); S images follow at +TENSOR_Z_B (+k*IMG_B)
         int c, q;
         bool tracer;                               // workgroup 0, chain wave 0, lane 0
         __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile) {
@@ -303,192 +460,282 @@ struct Fused {
             lane16 = (unsigned)lane * 16u;
             tenZ = lds + slot * WAVE_B;
             rowoff = (unsigned)(c_ * ROWB + 8 * q_);
+            imgoff = img_record(c_, q_);
             c = c_;
             q = q_;
             tracer = false;
         }
         __device__ __forceinline__ char* rowZ() const { return tenZ + rowoff; }
-        __device__ __forceinline__ char* rowS(int L) const { return tenZ + TENSOR_Z_B + (SLDS ? L : (L & 1)) * SBUF_B + rowoff; }
+        __device__ __forceinline__ char* imgS(int L) const { return tenZ + TENSOR_Z_B + slot_of(L) * IMG_B + imgoff; }
     };
 
-    // chain-layout fragments -> [point][feature] rows of this wave's LDS tensor (row = lane's point, 8 bytes per feature block)
-    // NMB = 16-feature blocks actually present (WB for states/adjoints, 1 for inputs/outputs); NPW = parts written (NP for
-    // adjoints, 1 for states)
-    template <int KSF, int NMB, int NPW>
-    static __device__ __forceinline__ void put_tensor(char* row, const u32x4 (&F)[NS][1][KSF][NP]) {
+    // chain-layout adjoint fragments -> [point][feature] rows of this wave's Z tensor (row = lane's point, 8 bytes per feature block)
+    // NMB = 16-feature blocks actually present (WB for hidden adjoints, 1 for the outputs')
+    template <int KSF, int NMB>
+    static __device__ __forceinline__ void put_rows(char* row, const u32x4 (&F)[NS][1][KSF][NP]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int p = 0; p < NPW; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
                 for (int mb = 0; mb < NMB; ++mb) {
                     u32x2 v = {F[s][0][mb >> 1][p][(mb & 1) * 2 + 0], F[s][0][mb >> 1][p][(mb & 1) * 2 + 1]};
-                    *reinterpret_cast<u32x2*>(row + (s * NPW + p) * PANEL_B + 32 * mb) = v;
+                    *reinterpret_cast<u32x2*>(row + (s * NP + p) * PANEL_B + 32 * mb) = v;
                 }
     }
-
-    // state (h, hdot_k) of feature block MB of this wave's own points, read back from its LDS S rows
-    template <int MB>
-    static __device__ __forceinline__ void state_from_lds(const char* rowS, float (&st)[NS][1][4]) {
+    // high parts of chain-layout state fragments -> this lane's records of an LDS image
+    template <int KSF>
+    static __device__ __forceinline__ void put_image(char* img, const u32x4 (&F)[NS][1][KSF][NP]) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const u32x2 h = *reinterpret_cast<const u32x2*>(rowS + s * PANEL_B + 32 * MB);
+        for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int d = 0; d < 2; ++d) {
-                st[s][0][2 * d + 0] = cvt16<Op>((uint16_t)(h[d] & 0xffffu));
-                st[s][0][2 * d + 1] = cvt16<Op>((uint16_t)(h[d] >> 16));
-            }
-        }
+            for (int kk = 0; kk < KSF; ++kk) *reinterpret_cast<u32x4*>(img + (s * KS + kk) * 1024) = F[s][0][kk][0];
     }
 
-    template <int KSB>
-    static __device__ __forceinline__ void load_afrags(const Ctx& x, int frag0, u32x4 (&Af)[KSB][NP]) {
+    // weight fragments of one feature block (NPARTS = 2: forward parts [V_hi, V_lo]; 3: reverse, plus [w_hi])
+    template <int KSB, int NPARTS>
+    static __device__ __forceinline__ void load_afrags(const Ctx& x, int frag0, u32x4 (&Af)[KSB][NPARTS]) {
 #pragma unroll
         for (int kk = 0; kk < KSB; ++kk)
 #pragma unroll
-            for (int p = 0; p < NP; ++p) Af[kk][p] = __builtin_amdgcn_raw_buffer_load_b128(x.frags, x.lane16, ((frag0 + kk) * NPS + p) * 1024, 0);
+            for (int p = 0; p < NPARTS; ++p) Af[kk][p] = __builtin_amdgcn_raw_buffer_load_b128(x.frags, x.lane16, ((frag0 + kk) * P3 + p) * 1024, 0);
     }
-    // acc[s] + accc[s]/LS = sum_k W[.,k] x_s[k]: eight independent MFMA chains (4 streams x {main, correction})
-    template <int KSB>
-    static __device__ __forceinline__ void gemm_pre(const u32x4 (&Af)[KSB][NP], const u32x4 (&B)[NS][1][KSB][NP], f32x4 (&acc)[NS],
-                                                    f32x4 (&accc)[NS]) {
+    static constexpr int FP = NP == 2 ? 2 : 1;      // weight-fragment parts the forward uses
+    static constexpr int RP = P3;                   // ... and the reverse
+
+    // forward k-step of one feature block:  acc[s] += V_hi.x_hi + V_hi.x_lo + V_lo.x_hi  (= WS * W.x; x_lo unscaled)
+    // MFMAs of different streams alternate, so that consecutive ones never share an accumulator
+    template <int KK, int KSB>
+    static __device__ __forceinline__ void fwd_kstep(const u32x4 (&Af)[KSB][FP], const u32x4 (&B)[NS][1][KSB][NP], f32x4 (&acc)[NS]) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            f32x4 m = {0.f, 0.f, 0.f, 0.f}, cc = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < NS; ++s) acc[s] = Op::mfma(Af[KK][0], B[s][0][KK][0], acc[s]);
+        if constexpr (NP == 2) {
 #pragma unroll
-            for (int kk = 0; kk < KSB; ++kk) {
-                m = Op::mfma(Af[kk][0], B[s][0][kk][0], m);
-                if (NP == 2) {
-                    cc = Op::mfma(Af[kk][0], B[s][0][kk][1], cc);
-                    cc = Op::mfma(Af[kk][1], B[s][0][kk][0], cc);
-                }
-            }
-            acc[s] = m;
-            accc[s] = cc;
+            for (int s = 0; s < NS; ++s) acc[s] = Op::mfma(Af[KK][0], B[s][0][KK][1], acc[s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = Op::mfma(Af[KK][1], B[s][0][KK][0], acc[s]);
         }
     }
-    static __device__ __forceinline__ float comb(const f32x4& m, const f32x4& cc, int r) { return NP == 2 ? m[r] + cc[r] * INV_LS : m[r]; }
+    // reverse k-step:  acc[s] += V_hi.z_hi + (V_hi/LS).z_lo' + V_lo.z_hi  (= WS * W^T.z; z_lo' carries the LO_SCALE = LS)
+    template <int KK, int KSB>
+    static __device__ __forceinline__ void bwd_kstep(const u32x4 (&Af)[KSB][RP], const u32x4 (&Zf)[NS][1][KSB][NP], f32x4 (&acc)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = Op::mfma(Af[KK][0], Zf[s][0][KK][0], acc[s]);
+        if constexpr (NP == 2) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = Op::mfma(Af[KK][2], Zf[s][0][KK][1], acc[s]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) acc[s] = Op::mfma(Af[KK][1], Zf[s][0][KK][0], acc[s]);
+        }
+    }
+    template <int K0, int K1, int KSB>
+    static __device__ __forceinline__ void fwd_ksteps(const u32x4 (&Af)[KSB][FP], const u32x4 (&B)[NS][1][KSB][NP], f32x4 (&acc)[NS]) {
+        if constexpr (K0 < K1) {
+            fwd_kstep<K0, KSB>(Af, B, acc);
+            fwd_ksteps<K0 + 1, K1, KSB>(Af, B, acc);
+        }
+    }
+    template <int K0, int K1, int KSB>
+    static __device__ __forceinline__ void bwd_ksteps(const u32x4 (&Af)[KSB][RP], const u32x4 (&Zf)[NS][1][KSB][NP], f32x4 (&acc)[NS]) {
+        if constexpr (K0 < K1) {
+            bwd_kstep<K0, KSB>(Af, Zf, acc);
+            bwd_ksteps<K0 + 1, K1, KSB>(Af, Zf, acc);
+        }
+    }
+    // accumulators of a new forward block: the value stream starts at WS * bias
+    static __device__ __forceinline__ void acc_init(const f32x4& bias, f32x4 (&acc)[NS]) {
+        acc[0] = bias * WS;
+#pragma unroll
+        for (int s = 1; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    static __device__ __forceinline__ void acc_zero(f32x4 (&acc)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    static __device__ __forceinline__ f32x4 load_bias(const Ctx& x, int l /*1..NL-1*/, int mb) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x.bias, (unsigned)x.q * 16u, ((l - 1) * WIDTH + 16 * mb) * 4, 0));
+    }
+
+    // state fragments (hi, unscaled lo) of feature block MB from per-point values
+    template <int MB>
+    static __device__ __forceinline__ void emit_state(u32x4 (&Bn)[NS][1][KS][NP], const float (&vals)[NS][4]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            uint32_t h0, h1, l0 = 0, l1 = 0;
+            if constexpr (NP == 2) {
+                split2u<Op>(vals[s][0], vals[s][1], h0, l0);
+                split2u<Op>(vals[s][2], vals[s][3], h1, l1);
+                Bn[s][0][MB >> 1][1][(MB & 1) * 2 + 0] = l0;
+                Bn[s][0][MB >> 1][1][(MB & 1) * 2 + 1] = l1;
+            } else {
+                h0 = pack2<Op>(vals[s][0], vals[s][1]);
+                h1 = pack2<Op>(vals[s][2], vals[s][3]);
+            }
+            Bn[s][0][MB >> 1][0][(MB & 1) * 2 + 0] = h0;
+            Bn[s][0][MB >> 1][0][(MB & 1) * 2 + 1] = h1;
+        }
+    }
+
+    // tanh and the scaled derivative from a scaled pre-activation  zs = WS * z :
+    //   e = 2^(zs * 2 log2(e) / WS),  r = 1/(1 + e),  h = 1 - 2r,  sds = (1 - h^2)/WS = (4/WS) r (1 - r)
+    static __device__ __forceinline__ void tanh_scaled(float zs, float& h, float& sds) {
+        const float e = __builtin_amdgcn_exp2f(zs * (2.8853900817779268f * INV_WS));
+        const float r = __builtin_amdgcn_rcpf(1.0f + e);
+        h = 1.0f - 2.0f * r;
+        const float c4 = r * (4.0f * INV_WS);
+        sds = c4 - c4 * r;
+    }
+
+    // vector part of a forward block: activation of the value stream, tangent streams, split into the next layer's operand
+    template <int MB>
+    static __device__ __forceinline__ void fwd_valu(const f32x4 (&acc)[NS], u32x4 (&Bn)[NS][1][KS][NP]) {
+        float vals[NS][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float h, sds;
+            tanh_scaled(acc[0][r], h, sds);
+            vals[0][r] = h;
+#pragma unroll
+            for (int s = 1; s < NS; ++s) vals[s][r] = sds * acc[s][r];
+        }
+        emit_state<MB>(Bn, vals);
+    }
 
     // forward first layer (K = 3, VALU): INF:191-195 with the tangent seeds e_k * sx_k
     template <int MB>
     static __device__ __forceinline__ void first_mb(const FusedArgs& a, const Ctx& x, const float (&xin)[3], u32x4 (&Bn)[NS][1][KS][NP]) {
-        float vals[NS][1][4];
+        float vals[NS][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const u32x4 wu = __builtin_amdgcn_raw_buffer_load_b128(x.w0p, (unsigned)x.q * 64u, (16 * MB + r) * 16, 0);
             const f32x4 w = __builtin_bit_cast(f32x4, wu);
             float h, sd;
             tanh_act(w[3] + w[0] * xin[0] + w[1] * xin[1] + w[2] * xin[2], h, sd);
-            vals[0][0][r] = h;
+            vals[0][r] = h;
 #pragma unroll
-            for (int s = 1; s < NS; ++s) vals[s][0][r] = sd * (a.sx[s - 1] * w[s - 1]);
+            for (int s = 1; s < NS; ++s) vals[s][r] = sd * (a.sx[s - 1] * w[s - 1]);
         }
-        CH::template emit<KS, MB>(Bn, vals, nullptr, WIDTH, x.c, x.q);
+        emit_state<MB>(Bn, vals);
         if constexpr (MB + 1 < WB) first_mb<MB + 1>(a, x, xin, Bn);
     }
 
-    // forward hidden layer, one 16-feature block per step; the next block's weight fragments are in flight while this
-    // block's MFMAs and tanh chain run
+    // forward: park the high parts of state S_l as the tile's register image (scratch), or straight into its LDS slot
+    static __device__ __forceinline__ void park_state(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
+        if constexpr (SLDS) {
+            put_image<KS>(x.imgS(l), Sf);               // the tile's own records of slot l; nobody else touches them in the forward
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk)
+                    __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][0], x.scr, x.imgoff, (l - 1) * IMG_B + (s * KS + kk) * 1024, 0);
+        }
+    }
+
+    // One hidden layer of the forward pipeline (weight layer l: `in` = S_l -> `out` = S_{l+1}).
+    //   entry: A[m] = fragments of block m of this layer, all loaded (during the previous layer); acc[0] = block 0, MFMAs issued
+    //   step m: reload A[m] (consumed) with block m of the NEXT weight layer (nfrag0; the output layer has one block), issue the MFMAs
+    //   of block m+1, run the vector part of block m in between.  In the last step the k-steps of the next layer's block 0 that only
+    //   need finished parts of `out` are issued next to the last vector part -- the pipeline runs across layers.
+    //   S_l is parked in step 0 BEHIND that step's fragment load, and every fragment load has a whole layer to arrive: CDNA4 returns
+    //   loads and stores in order on one counter, so a load issued after the park stores waits for their write acknowledgements
+    //   (measured: ~2 k cycles; with a one-block prefetch distance every layer stalled on them).
+    //   exit: the same invariant for the next layer.
+    static constexpr int KOVL = (WB - 1) / 2;      // k-steps of the next layer's block 0 that can start before this layer's last block
     template <int MB>
-    static __device__ __forceinline__ void fwd_mb(const Ctx& x, int frag0, int bias_off, const u32x4 (&Af)[KS][NP],
-                                                  const u32x4 (&B)[NS][1][KS][NP], u32x4 (&Bn)[NS][1][KS][NP]) {
-        u32x4 An[KS][NP];
-        if constexpr (MB + 1 < WB) load_afrags<KS>(x, frag0 + (MB + 1) * KS, An);
-        const u32x4 bu = __builtin_amdgcn_raw_buffer_load_b128(x.bias, (unsigned)x.q * 16u, bias_off + 16 * MB * 4, 0);
-        const f32x4 bias = __builtin_bit_cast(f32x4, bu);
-        f32x4 acc[NS], accc[NS];
-        gemm_pre<KS>(Af, B, acc, accc);
+    static __device__ __forceinline__ void fwd_step(const Ctx& x, int l, int nfrag0, bool next_is_out, const u32x4 (&in)[NS][1][KS][NP],
+                                                    u32x4 (&out)[NS][1][KS][NP], u32x4 (&A)[WB][KS][FP], f32x4 (&acca)[NS], f32x4 (&accb)[NS],
+                                                    const f32x4& bias_next) {
+        f32x4 (&acur)[NS] = (MB & 1) ? accb : acca;      // block MB, complete
+        f32x4 (&anxt)[NS] = (MB & 1) ? acca : accb;      // block MB+1
+        if (MB == 0 || !next_is_out) load_afrags<KS, FP>(x, nfrag0 + MB * KS, A[MB]);
+        if constexpr (MB == 0) park_state(x, l, in);
+        if constexpr (MB + 1 < WB) {
+            acc_init(load_bias(x, l, MB + 1), anxt);
+            fwd_ksteps<0, KS, KS>(A[MB + 1], in, anxt);
+            fwd_valu<MB>(acur, out);
+        } else {
+            // last block: the next layer's block 0 starts on the finished half of `out`
+            acc_init(bias_next, anxt);
+            fwd_ksteps<0, KOVL, KS>(A[0], out, anxt);
+            fwd_valu<MB>(acur, out);
+            __builtin_amdgcn_sched_barrier(0);
+            fwd_ksteps<KOVL, KS, KS>(A[0], out, anxt);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MB + 1 < WB) fwd_step<MB + 1>(x, l, nfrag0, next_is_out, in, out, A, acca, accb, bias_next);
+    }
+
+    // reverse: vector part of block MB of weight layer L's transpose -- the activation below it.  acc = WS * (W_L Z_L) for the NS
+    // streams; state (h, hdot_k) of this lane's point as packed 16-bit pairs sp[s] (fp16: consumed in place by mixed-precision FMAs)
+    //   zbar = sd hbar - 2 h sum_k hdotbar_k hdot_k ,  zdotbar_k = sd hdotbar_k          (INF:131-133, gradient of TanhGrad)
+    template <int MB>
+    static __device__ __forceinline__ void bwd_valu(const f32x4 (&acc)[NS], const u32x2 (&sp)[NS], u32x4 (&Zn)[NS][1][KS][NP], int c, int q) {
         float vals[NS][1][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float h, sd;
-            tanh_act(comb(acc[0], accc[0], r) + bias[r], h, sd);
-            vals[0][0][r] = h;
-#pragma unroll
-            for (int s = 1; s < NS; ++s) vals[s][0][r] = sd * comb(acc[s], accc[s], r);
-        }
-        CH::template emit<KS, MB>(Bn, vals, nullptr, WIDTH, x.c, x.q);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MB + 1 < WB) fwd_mb<MB + 1>(x, frag0, bias_off, An, B, Bn);
-    }
-
-    // reverse through a weight layer (KSB k-steps of its outputs) + the activation below; state from the wave's LDS rows
-    template <int MB, int KSB>
-    static __device__ __forceinline__ void bwd_mb(const Ctx& x, int frag0, const char* rowS, const u32x4 (&Af)[KSB][NP],
-                                                  const u32x4 (&Zf)[NS][1][KSB][NP], u32x4 (&Zn)[NS][1][KS][NP]) {
-        u32x4 An[KSB][NP];
-        if constexpr (MB + 1 < WB) load_afrags<KSB>(x, frag0 + (MB + 1) * KSB, An);
-        f32x4 acc[NS], accc[NS];
-        gemm_pre<KSB>(Af, Zf, acc, accc);
-        float vals[NS][1][4];
-        // reverse of (h = tanh z, hdot_k = (1-h^2) zdot_k); state of this block from the wave's own LDS rows
-        if constexpr (MixF16<Op>::value) {
-            // fp16 state consumed in place by mixed-precision FMAs (no v_cvt_f32_f16: 64 per layer otherwise)
-            u32x2 sp[NS];
-#pragma unroll
-            for (int s = 0; s < NS; ++s) sp[s] = *reinterpret_cast<const u32x2*>(rowS + s * PANEL_B + 32 * MB);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            float sds, hd = 0.0f;
+            if constexpr (MixF16<Op>::value) {
                 const uint32_t hw = sp[0][r >> 1];
                 const float sd = (r & 1) ? MixF16<Op>::template one_minus_sq<1>(hw) : MixF16<Op>::template one_minus_sq<0>(hw);
+                sds = sd * INV_WS;
+                if constexpr (NS > 1) {
+                    float dot = 0.0f;
+#pragma unroll
+                    for (int s = 1; s < NS; ++s)
+                        dot = (r & 1) ? MixF16<Op>::template fma<1>(sp[s][r >> 1], acc[s][r], dot) : MixF16<Op>::template fma<0>(sp[s][r >> 1], acc[s][r], dot);
+                    hd = (r & 1) ? MixF16<Op>::template fma<1>(hw, dot, 0.0f) : MixF16<Op>::template fma<0>(hw, dot, 0.0f);
+                }
+            } else {
+                const float h = cvt16<Op>((uint16_t)((r & 1) ? (sp[0][r >> 1] >> 16) : (sp[0][r >> 1] & 0xffffu)));
+                sds = (1.0f - h * h) * INV_WS;
                 float dot = 0.0f;
 #pragma unroll
-                for (int s = 1; s < NS; ++s) {
-                    const float hdb = comb(acc[s], accc[s], r);
-                    dot = (r & 1) ? MixF16<Op>::template fma<1>(sp[s][r >> 1], hdb, dot) : MixF16<Op>::template fma<0>(sp[s][r >> 1], hdb, dot);
-                    vals[s][0][r] = sd * hdb;
-                }
-                const float hd = (r & 1) ? MixF16<Op>::template fma<1>(hw, dot, 0.0f) : MixF16<Op>::template fma<0>(hw, dot, 0.0f);
-                vals[0][0][r] = sd * comb(acc[0], accc[0], r) - 2.0f * hd;
+                for (int s = 1; s < NS; ++s)
+                    dot += acc[s][r] * cvt16<Op>((uint16_t)((r & 1) ? (sp[s][r >> 1] >> 16) : (sp[s][r >> 1] & 0xffffu)));
+                hd = h * dot;
             }
-        } else {
-            float st[NS][1][4];
-            state_from_lds<MB>(rowS, st);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float h = st[0][0][r];
-                const float sd = 1.0f - h * h;
-                float dot = 0.0f;
-#pragma unroll
-                for (int s = 1; s < NS; ++s) {
-                    const float hdb = comb(acc[s], accc[s], r);
-                    dot += hdb * st[s][0][r];
-                    vals[s][0][r] = sd * hdb;
-                }
-                vals[0][0][r] = sd * comb(acc[0], accc[0], r) - 2.0f * h * dot;
-            }
+            for (int s = 1; s < NS; ++s) vals[s][0][r] = sds * acc[s][r];
+            vals[0][0][r] = NS > 1 ? sds * acc[0][r] - (2.0f * INV_WS) * hd : sds * acc[0][r];
         }
-        CH::template emit<KS, MB>(Zn, vals, nullptr, WIDTH, x.c, x.q);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MB + 1 < WB) bwd_mb<MB + 1, KSB>(x, frag0, rowS, An, Zf, Zn);
+        CH::template emit<KS, MB>(Zn, vals, nullptr, WIDTH, c, q);
     }
 
-    // parked state S_l: asynchronous LDS-DMA of the scratch image into the parity buffer of layer l (no registers involved;
-    // completion is covered by the vmcnt(0) of the next workgroup barrier)
-    static __device__ __forceinline__ void dma_state(const Ctx& x, int l /*1..NL-1*/) {
-        if constexpr (SLDS) return;
-        char* dst = x.tenZ + TENSOR_Z_B + (l & 1) * SBUF_B;
-#pragma unroll
-        for (int i = 0; i < SBUF_B / 1024; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(x.scr, (lds_void*)(dst + i * 1024), 16, x.lane16, (l - 1) * SBUF_B + i * 1024, 0, 0);
-    }
-    // forward: park feature block MB of S_l (hi parts) as rows of the scratch image
+    // this lane's state pairs of feature block MB from its records of an LDS image
     template <int MB>
-    static __device__ __forceinline__ void park_block(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
+    static __device__ __forceinline__ void state_from_image(const char* img, u32x2 (&sp)[NS]) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const u32x2 v = {Sf[s][0][MB >> 1][0][(MB & 1) * 2 + 0], Sf[s][0][MB >> 1][0][(MB & 1) * 2 + 1]};
-            __builtin_amdgcn_raw_buffer_store_b64(v, x.scr, x.rowoff, (l - 1) * SBUF_B + s * PANEL_B + 32 * MB, 0);
-        }
+        for (int s = 0; s < NS; ++s) sp[s] = *reinterpret_cast<const u32x2*>(img + (s * KS + (MB >> 1)) * 1024 + 8 * (MB & 1));
     }
     template <int MB>
-    static __device__ __forceinline__ void park_state(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
-        if constexpr (SLDS) {
-            if constexpr (MB == 0) put_tensor<KS, WB, 1>(x.rowS(l), Sf);      // the tile's own rows of slot l; nobody else touches them in the forward
-        } else {
-            park_block<MB>(x, l, Sf);
-            if constexpr (MB + 1 < WB) park_state<MB + 1>(x, l, Sf);
+    static __device__ __forceinline__ void state_from_frags(const u32x4 (&B)[NS][1][KS][NP], u32x2 (&sp)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sp[s] = u32x2{B[s][0][MB >> 1][0][(MB & 1) * 2 + 0], B[s][0][MB >> 1][0][(MB & 1) * 2 + 1]};
+    }
+
+    // Reverse through weight layer L (KSB k-steps of its outputs; fragments frag0 + MB*KSB) and the activation that produced S_L:
+    // Zf = Z_L  ->  Zn = Z_{L-1}.  Same software pipeline as the forward: MFMAs of block MB+1 between the vector part of block MB.
+    // TOP: the state comes from the forward's registers (S_NL), otherwise from the wave's LDS image of S_L.
+    //   entry: Aa = fragments of block 0, Ab = fragments of block 1, both loaded (issued before the hand-off barriers)
+    template <int MB, int KSB, bool TOP>
+    static __device__ __forceinline__ void bwd_step(const Ctx& x, int frag0, const char* img, const u32x4 (&Sreg)[NS][1][KS][NP], const u32x4 (&Zf)[NS][1][KSB][NP],
+                                                    u32x4 (&Zn)[NS][1][KS][NP], u32x4 (&Aa)[KSB][RP], u32x4 (&Ab)[KSB][RP], f32x4 (&acca)[NS], f32x4 (&accb)[NS]) {
+        u32x4 (&Acur)[KSB][RP] = (MB & 1) ? Ab : Aa;
+        u32x4 (&Anxt)[KSB][RP] = (MB & 1) ? Aa : Ab;
+        f32x4 (&acur)[NS] = (MB & 1) ? accb : acca;
+        f32x4 (&anxt)[NS] = (MB & 1) ? acca : accb;
+        if constexpr (MB + 2 < WB) load_afrags<KSB, RP>(x, frag0 + (MB + 2) * KSB, Acur);
+        u32x2 sp[NS];
+        if constexpr (TOP) state_from_frags<MB>(Sreg, sp);
+        else state_from_image<MB>(img, sp);
+        if constexpr (MB + 1 < WB) {
+            acc_zero(anxt);
+            bwd_ksteps<0, KSB, KSB>(Anxt, Zf, anxt);
         }
+        bwd_valu<MB>(acur, sp, Zn, x.c, x.q);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MB + 1 < WB) bwd_step<MB + 1, KSB, TOP>(x, frag0, img, Sreg, Zf, Zn, Aa, Ab, acca, accb);
     }
 
     // Force the fragments to be fully computed at this point: without it the compiler sinks the reverse elementwise work past
@@ -506,13 +753,18 @@ struct Fused {
     // Weight layers L = NL-1 .. 1 (hidden-to-hidden) and finally L = 0, fully unrolled (static fragment indices / offsets).
     template <int L>
     struct Down {
-        // entry: Zc = Z_L (adjoint of weight layer L's pre-activation) in chain fragment order; S_L is (being) DMA'd into its parity buffer
+        // entry: Zc = Z_L (adjoint of weight layer L's pre-activation) in chain fragment order; S_L is (being) DMA'd into its slot
         static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&Zc)[NS][1][KS][NP]) {
+            u32x4 Aa[KS][RP], Ab[KS][RP];
+            if constexpr (L >= 1) {                            // this layer's first fragments travel during the hand-off
+                load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 0, 0), Aa);
+                load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 1, 0), Ab);
+            }
             __syncthreads();                                   // previous layer's fragment reads are done
             fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
-            put_tensor<KS, WB, NP>(x.rowZ(), Zc);
+            put_rows<KS, WB>(x.rowZ(), Zc);
             if constexpr (L == 0) {
-                // S_0: the inputs as a 16-feature tensor (rows 0..2 = x', tangent stream k carries sx_k in row k)
+                // S_0: the inputs as a 16-feature state (rows 0..2 = x', tangent stream k carries sx_k in row k)
                 float v0[NS][1][4];
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
@@ -528,45 +780,52 @@ struct Fused {
                         v0[s][0][r] = v;
                     }
                 u32x4 S0[NS][1][1][NP];
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) S0[s][0][0][p] = u32x4{0u, 0u, 0u, 0u};
                 CH::template emit<1, 0>(S0, v0, nullptr, 16, x.c, x.q);
-                put_tensor<1, 1, 1>(x.rowS(0), S0);
+                put_image<1>(x.imgS(0), S0);
             }
-            __syncthreads();                                   // tensors visible to the weight-gradient waves (also drains the S_L DMA)
+            __syncthreads();                                   // tensors visible to the weight-gradient waves; S_L has landed
             fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
             if constexpr (L >= 1) {
-                // reverse through W_L and the activation that produced S_L -> Z_{L-1}; meanwhile S_{L-1} streams into the other buffer
+                // reverse through W_L and the activation that produced S_L -> Z_{L-1}
                 u32x4 Zn[NS][1][KS][NP];
-                {
-                    const int frag0 = FI::bwd_mid(NL, L, 0, 0);
-                    u32x4 A0[KS][NP];
-                    load_afrags<KS>(x, frag0, A0);
-                    if constexpr (L >= 2) dma_state(x, L - 1);
-                    __builtin_amdgcn_sched_barrier(0);
-                    bwd_mb<0, KS>(x, frag0, x.rowS(L), A0, Zc, Zn);
-                    pin<KS>(Zn);
-                }
+                f32x4 acca[NS], accb[NS];
+                acc_zero(acca);
+                bwd_ksteps<0, KS, KS>(Aa, Zc, acca);
+                bwd_step<0, KS, false>(x, FI::bwd_mid(NL, L, 0, 0), x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb);
+                pin<KS>(Zn);
                 fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
                 Down<L - 1>::run(a, x, xin, Zn);
             }
         }
     };
 
-    // forward (same arithmetic as chain_kernel) + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
-    // parks S_1..S_{NL-1} in the tile's scratch image, returns S_NL (fragments) and the head's adjoint Z_NL, adds the loss sums
+    // forward + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
+    // parks S_1..S_{NL-1} (scratch image or LDS slots), returns S_NL (fragments) and the head's adjoint Z_NL, adds the loss sums
     static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], bool valid, long pidx, int set, float (&lsum)[8],
                                                         u32x4 (&B)[NS][1][KS][NP], u32x4 (&ZL)[NS][1][1][NP]) {
         const int c = x.c, q = x.q;
         first_mb<0>(a, x, xin, B);
-        park_state<0>(x, 1, B);
-        // two layers per loop trip, ping-ponging between B and B2: a one-buffer loop has to copy the 64 fragment registers
-        // back at the end of every layer (48 v_mov per layer in the ISA)
+        // pipeline prologue: all fragments of layer 1, block 0's MFMAs
+        u32x4 A[WB][KS][FP];
+        f32x4 acca[NS], accb[NS];
+#pragma unroll
+        for (int mb = 0; mb < WB; ++mb) load_afrags<KS, FP>(x, FI::fwd_mid(1, mb, 0), A[mb]);
+        acc_init(load_bias(x, 1, 0), acca);
+        fwd_ksteps<0, KS, KS>(A[0], B, acca);
+        __builtin_amdgcn_sched_barrier(0);
+        // two layers per loop trip, ping-ponging between B and B2: a one-buffer loop has to copy the fragment registers
+        // back at the end of every layer
         u32x4 B2[NS][1][KS][NP];
+        const f32x4 blast = *reinterpret_cast<const f32x4*>(a.pw.bias_last + 4 * q);
         auto layer = [&](int l, const u32x4 (&in)[NS][1][KS][NP], u32x4 (&out)[NS][1][KS][NP]) {
-            const int frag0 = FI::fwd_mid(l, 0, 0);
-            u32x4 A0[KS][NP];
-            load_afrags<KS>(x, frag0, A0);
-            fwd_mb<0>(x, frag0, (l - 1) * WIDTH * 4, A0, in, out);
-            if (l + 1 < NL) park_state<0>(x, l + 1, out);      // S_NL is handled by the caller
+            const bool last = l + 1 == NL;
+            const int nfrag0 = last ? FI::fwd_last(NL, 0) : FI::fwd_mid(l + 1, 0, 0);
+            const f32x4 bnext = last ? blast : load_bias(x, last ? l : l + 1, 0);
+            fwd_step<0>(x, l, nfrag0, last, in, out, A, acca, accb, bnext);
         };
         int l = 1;
         for (; l + 1 < NL; l += 2) {
@@ -583,19 +842,13 @@ struct Fused {
                     for (int pp = 0; pp < NP; ++pp) B[s][0][kk][pp] = B2[s][0][kk][pp];
         }
         fused_stamp(a, x.tracer, 1);
-        f32x4 yacc[NS], yaccc[NS];
-        {
-            u32x4 A0[KS][NP];
-            load_afrags<KS>(x, FI::fwd_last(NL, 0), A0);
-            gemm_pre<KS>(A0, B, yacc, yaccc);
-        }
-        const f32x4 bl = *reinterpret_cast<const f32x4*>(a.pw.bias_last + 4 * q);
+        // acca = WS * (Y of the 16 padded outputs, bias included): lane holds outputs 4q+r of its point
         float Y[NS][8];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float own = comb(yacc[s], yaccc[s], r) + (s == 0 ? bl[r] : 0.0f);
+                const float own = acca[s][r] * INV_WS;
                 const float oth = __shfl_xor(own, 16);
                 Y[s][r] = (q & 1) ? oth : own;
                 Y[s][4 + r] = (q & 1) ? own : oth;
@@ -666,20 +919,21 @@ struct Fused {
                                                         const u32x4 (&ZL)[NS][1][1][NP]) {
         // ---- top weight layer NL: hand Z_NL (16 outputs) and S_NL over, then reverse into the hidden chain
         fused_stamp(a, x.tracer, 2);
+        u32x4 Aa[1][RP], Ab[1][RP];
+        load_afrags<1, RP>(x, FI::bwd_last(NL, 0), Aa);
+        load_afrags<1, RP>(x, FI::bwd_last(NL, 1), Ab);
         __syncthreads();
         fused_stamp(a, x.tracer, 3);
-        put_tensor<1, 1, NP>(x.rowZ(), ZL);
-        put_tensor<KS, WB, 1>(x.rowS(NL), B);
+        put_rows<1, 1>(x.rowZ(), ZL);
+        put_image<KS>(x.imgS(NL), B);
         __syncthreads();
         fused_stamp(a, x.tracer, 4);
         u32x4 Zn[NS][1][KS][NP];
         {
-            const int frag0 = FI::bwd_last(NL, 0);
-            u32x4 A0[1][NP];
-            load_afrags<1>(x, frag0, A0);
-            dma_state(x, NL - 1);
-            __builtin_amdgcn_sched_barrier(0);
-            bwd_mb<0, 1>(x, frag0, x.rowS(NL), A0, ZL, Zn);
+            f32x4 acca[NS], accb[NS];
+            acc_zero(acca);
+            bwd_ksteps<0, 1, 1>(Aa, ZL, acca);
+            bwd_step<0, 1, true>(x, FI::bwd_last(NL, 0), nullptr, B, ZL, Zn, Aa, Ab, acca, accb);
             pin<KS>(Zn);
         }
         fused_stamp(a, x.tracer, 5);
@@ -755,7 +1009,7 @@ struct Fused {
         const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
         const int wave8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // provably wave-uniform
         if (wave8 >= 4) {
-            wgrad_role(a, lds, wave8 - 4, c, q);
+            wgrad_role(a, lds, wave8 - 4, lane, c, q);
         } else {
             __builtin_amdgcn_s_setprio(2);          // the chain wave is the critical path of its SIMD: issue it first
             chain_role(a, lds, wave8, lane, c, q);

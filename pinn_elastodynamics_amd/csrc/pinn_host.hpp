@@ -74,6 +74,7 @@ struct Host {
     static constexpr int nb() { return (WIDTH <= 64 && NS != 5) ? 2 : 1; }
     static constexpr int NP = SPLIT == 3 ? 2 : 1;
     static constexpr int NPS = SPLIT == 3 ? 2 : 1;    // stored weight-fragment parts
+    static constexpr int FUSED_PARTS = SPLIT == 3 ? 3 : 1;   // ... of the fused kernel's format (repack_kernel)
     static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
     static constexpr int FUSED_GRID = 256;    // persistent workgroups of the fused kernel (one per MI355X CU)
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
@@ -81,7 +82,7 @@ struct Host {
     typedef FragIndex<WIDTH> FI;
 
     struct Plan {
-        size_t w0p, bias_mid, bias_last, frags, loss_part, partial, panels, fixed_end;
+        size_t w0p, bias_mid, bias_last, frags, frags_fused, loss_part, partial, wg_acc, panels, fixed_end;
         long s_tile, z_tile;     // 16-bit elements per tile
         long ntiles;             // total tiles of the call (even)
         long chunk_tiles;        // tiles per workspace pass (even)
@@ -100,10 +101,14 @@ struct Host {
         o = align_up(o + NOUT_PAD * sizeof(float), 256);
         p.frags = o;
         o = align_up(o + (size_t)FI::total(net.nl) * NPS * 64 * sizeof(u32x4), 256);
+        p.frags_fused = o;      // second copy in the fused kernel's format (narrow nets only)
+        if (WIDTH <= 64) o = align_up(o + (size_t)FI::total(net.nl) * FUSED_PARTS * 64 * sizeof(u32x4), 256);
         p.loss_part = o;
         o = align_up(o + (size_t)MAX_BLOCKS * 4 * 8 * sizeof(float), 256);
         p.partial = o;
         o = align_up(o + (size_t)(NCHUNK > FUSED_GRID ? NCHUNK : FUSED_GRID) * net.nparams * sizeof(float), 256);
+        p.wg_acc = o;           // fused kernel: weight-gradient accumulator blocks kept in memory (<= 2 layers x 4 blocks x 1 KB per wave)
+        if (WIDTH <= 64) o = align_up(o + (size_t)FUSED_GRID * 4 * 32 * 1024, 256);
         p.panels = o;
         p.fixed_end = o;
         p.s_tile = PG::s_tile(net.nl);
@@ -162,6 +167,7 @@ struct Host {
         ra.bias_mid = reinterpret_cast<float*>(b + p.bias_mid);
         ra.bias_last = reinterpret_cast<float*>(b + p.bias_last);
         ra.frags = reinterpret_cast<u32x4*>(b + p.frags);
+        ra.frags_fused = WIDTH <= 64 ? reinterpret_cast<u32x4*>(b + p.frags_fused) : nullptr;
         const long items = (long)FI::total(c.net.nl) * 64;
         const int blocks = (int)((items + 255) / 256);
         hipLaunchKernelGGL((repack_kernel<Op, SPLIT, WIDTH>), dim3(blocks), dim3(256), 0, c.stream, ra);
@@ -311,7 +317,8 @@ struct Host {
             FusedArgs a;
             a.net = c.net;
             a.pw = packed(c, p);
-            a.frags_bytes = (unsigned)((size_t)FI::total(c.net.nl) * NPS * 64 * sizeof(u32x4));
+            a.pw.frags = reinterpret_cast<const u32x4*>(b + p.frags_fused);
+            a.frags_bytes = (unsigned)((size_t)FI::total(c.net.nl) * FUSED_PARTS * 64 * sizeof(u32x4));
             a.x = c.x;
             a.y = c.y;
             a.t = c.t;
@@ -357,6 +364,8 @@ struct Host {
             a.scratch = reinterpret_cast<u32x4*>(b + p.panels);
             a.loss_part = reinterpret_cast<float*>(b + p.loss_part);
             a.partial = reinterpret_cast<float*>(b + p.partial);
+            a.wg_acc = reinterpret_cast<u32x4*>(b + p.wg_acc);
+            static_assert(F::WG_ACC_BYTES <= 32 * 1024, "accumulator area of the plan");
             a.dbg = c.dbg_stamps;
             hipEvent_t ev[2] = {nullptr, nullptr};
             if (c.prof_ms) { hipEventCreate(&ev[0]); hipEventCreate(&ev[1]); hipEventRecord(ev[0], c.stream); }
