@@ -1,13 +1,20 @@
 #!/usr/bin/env python
 """Benchmark of the hot path: collocation points per second through the PDE-residual loss +
-parameter gradient (+ all-reduce + Adam), 8x64 tanh MLP, BASELINE.json configs[1]/[3].
+parameter gradient (+ all-reduce + Adam).
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W [--config wave|plate|nc3d] [--scaling weak|strong]
+  (N>1: launched by torch.distributed.run, one rank per GPU)
 
-One "step" = one Adam step of the infinite-domain wave case (INF:282-319) on a fixed synthetic
-point set: 2M collocation points PER GPU (weak scaling; 16M on 8 GPUs = configs[3]) plus the
-reference's side sets (IC 101x101 grid INF:666, Ricker source 200x352 INF:688-704), fresh Xavier
-weights, seed 1111.  Prints ONE JSON line on rank 0.
+--config wave  (default) BASELINE.json configs[1] / configs[3]: 2-D elastic wave (infinite domain), 8x64 tanh MLP, 2 M collocation
+               points per GPU (weak scaling; x8 GPUs = 16 M = configs[3]) or --global-points in total (--scaling strong, the north
+               star's ">= 6x at 8 GPUs on 2 M points"), plus the reference's side sets (IC 101x101 grid INF:666, Ricker source
+               200x352 INF:688-704).  One step = one Adam step of INF:282-319.
+--config plate configs[2]: plate with hole (hard BC: composite P + D*N, nested u_tt), 8x64 net + frozen 4x20 distance / particular
+               nets, 2 M points; one step = one Adam step of PLATE:475-506.
+--config nc3d  configs[4]: 3-D Navier-Cauchy half space, 10x128 net on (x, y, z, t), 4 M points per GPU (32 M on 8); a build-side
+               extension, not in the reference.
+Fresh Xavier weights, seed 1111, synthetic points.  Prints ONE JSON line on rank 0.  At N = 1 the default (wave) line also carries the
+small reference configuration configs[0] (4x32 net, 50 k points) timed on the GPU and on the host's cores.
 """
 from __future__ import annotations
 
@@ -23,11 +30,15 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LAYERS = [3] + 8 * [64] + [7]
 LB, UB = [0.0, 0.0, 0.0], [30.0, 30.0, 20.0]
-FLOP_PER_PT = 12 * 2 * (3 * 64 + 7 * 64 * 64 + 64 * 7)            # 703,488
-CHAIN_FLOP_PER_PT = 8 * 2 * (7 * 64 * 64 + 64 * 7) + 4 * 2 * 3 * 64   # forward + reverse-chain contractions of the chain kernel
 MFMA_PEAK_TFLOPS = 2500.0                                        # bf16/f16 dense, MI355X_MICROARCH.md
+PRECISION_NOTE = ("f16x3 = fp16 operands split hi+lo, 3 MFMAs per product, fp32 accumulate: fp32-class results (fields 3e-6 vs the "
+                  "float64 oracle); the plain bf16 mode named in BASELINE.json fails field parity by 5-10 % and is reported beside it")
+
+
+def flop_per_point(layers, streams):
+    """algorithmic contraction flops of loss + gradient per point: (value + tangent streams) x (forward + 2 x reverse) x 2 sum(W)  """
+    return 3 * streams * 2 * sum(layers[i] * layers[i + 1] for i in range(len(layers) - 1))
 
 
 def synth_points(n, seed):
@@ -57,46 +68,76 @@ def ic_grid():
     return np.stack([xx.reshape(-1), yy.reshape(-1), np.zeros(101 * 101)], 1)
 
 
-def cpu_baseline(sample_pts=32768, reps=3):
+def cpu_baseline(layers, sample_pts, reps, label):
     """The reference's CPU path, timed as the TF1-graph-shaped torch restatement (TF1 itself cannot
     be installed here): fp32, forward built twice, 12 reverse passes, 7 mean-squares, grad wrt all
     parameters.  Bounded sample of the same workload (same net, same point distribution)."""
     from oracle import pinn_oracle as po
-    from oracle.tf1_shaped import TF1ShapedWave
+    from oracle.tf1_shaped import MinimalWave, TF1ShapedWave
     rng = np.random.default_rng(1111)
-    Ws, bs = po.xavier_init(LAYERS, rng, dtype=np.float32)
+    Ws, bs = po.xavier_init(layers, rng, dtype=np.float32)
     X = synth_points(sample_pts, 7).astype(np.float32)
-    m = TF1ShapedWave(Ws, bs, LB, UB, True, dtype=torch.float32)
-    m.flat_grad(X[:2048])
+    out = {}
+    for key, cls in (("value", TF1ShapedWave), ("minimal_algorithm_value", MinimalWave)):
+        m = cls(Ws, bs, LB, UB, True, dtype=torch.float32)
+        m.flat_grad(X[:2048])
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            m.flat_grad(X)
+        out[key] = sample_pts * reps / (time.perf_counter() - t0)
+    out.update({"unit": "collocation-points/s", "cores": torch.get_num_threads(), "kind": "port", "host_cpus": os.cpu_count(),
+                "sample": f"{reps}x loss+grad of the {label} net on {sample_pts} points, fp32, TF1-graph-shaped torch-CPU restatement "
+                          f"(oracle/tf1_shaped.py; second figure: the minimal algorithm, one forward with three tangents + one reverse pass)"})
+    return out
+
+
+def cpu_baseline_nc3d(layers, lb, ub, sample_pts=4096, reps=2):
+    from oracle import nc3d_oracle as n3
+    from oracle import pinn_oracle as po
+    from oracle.tf1_shaped_nc3d import TF1ShapedNC3D
+    rng = np.random.default_rng(1111)
+    Ws, bs = po.xavier_init(layers, rng, dtype=np.float32)
+    X = n3.halfspace_points(sample_pts, lb, ub, rng).astype(np.float32)
+    m = TF1ShapedNC3D(Ws, bs, lb, ub, True, dtype=torch.float32)
+    m.flat_grad(X[:512])
     t0 = time.perf_counter()
     for _ in range(reps):
         m.flat_grad(X)
     dt = (time.perf_counter() - t0) / reps
-    # second leg: the same numbers by the minimal algorithm (one forward with three tangents + one reverse pass) on the CPU
-    from oracle.tf1_shaped import MinimalWave
-    mm = MinimalWave(Ws, bs, LB, UB, True, dtype=torch.float32)
-    mm.flat_grad(X[:2048])
-    t1 = time.perf_counter()
-    for _ in range(reps):
-        mm.flat_grad(X)
-    dt_min = (time.perf_counter() - t1) / reps
-    return {"value": sample_pts / dt, "minimal_algorithm_value": sample_pts / dt_min, "unit": "collocation-points/s", "cores": torch.get_num_threads(), "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": f"{reps}x loss+grad of the 8x64 net on {sample_pts} points, fp32, TF1-graph-shaped torch-CPU restatement "
-                      f"(oracle/tf1_shaped.py), {dt:.2f} s per pass"}
+    return {"value": sample_pts / dt, "unit": "collocation-points/s", "cores": torch.get_num_threads(), "kind": "port", "host_cpus": os.cpu_count(),
+            "sample": f"{reps}x loss+grad of the 10x128 3-D net on {sample_pts} points, fp32, reverse-mode torch-CPU restatement written like the "
+                      f"reference's graph (oracle/tf1_shaped_nc3d.py), {dt:.2f} s per pass"}
+
+
+def traffic_from_profiles(name):
+    """HBM-side bytes per launch of the dominant kernel from this round's committed PMC passes (separate rocprofv3 --pmc runs of the
+    same command, profiles/README.md) -- NOT measured in this run, hence its own key."""
+    for rnd in ("r02", "r01"):
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_summary.json")))
+            return {"bytes_per_launch": pm.get("hbm_bytes_per_launch"), "source": f"profiles/{rnd}_{name}_pmc_summary.json",
+                    "note": "L2<->fabric request bytes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE); mostly the parked fp16 state, served by "
+                            "L2 / Infinity Cache"}
+        except Exception:
+            continue
+    return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--points-per-gpu", type=int, default=2_000_000)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 wave, 60 plate, 12 nc3d)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="wave", choices=["wave", "plate", "nc3d"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
+    ap.add_argument("--points-per-gpu", type=int, default=None, help="weak scaling: points per GPU (default 2 M; nc3d 4 M)")
+    ap.add_argument("--global-points", type=int, default=2_000_000, help="strong scaling: total points")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "bf16", "f16", "bf16x3"])
-    ap.add_argument("--chunk-points", type=int, default=1 << 18, help="points held in the spill workspace per pass")
-    ap.add_argument("--ramp-steps", type=int, default=100, help="untimed clock-ramp steps before the warm-up steps (~0.7 s)")
+    ap.add_argument("--chunk-points", type=int, default=1 << 18, help="points held in the spill workspace per pass (two-kernel path)")
+    ap.add_argument("--ramp-steps", type=int, default=None, help="untimed clock-ramp steps before the warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--extra-modes", default="bf16", help="comma list of other precision modes to time briefly (rank 0 / N=1)")
+    ap.add_argument("--no-small-config", action="store_true")
+    ap.add_argument("--extra-modes", default="bf16", help="comma list of other precision modes to time briefly (wave, rank 0 / N=1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,15 +156,55 @@ def main():
         else:
             torch.distributed.init_process_group(backend)
 
-    from pinn_elastodynamics_amd.elastic_wave import DeepHPM
     from pinn_elastodynamics_amd.hip_engine import HipEngine
+    cfg = args.config
+    steps = args.steps if args.steps is not None else {"wave": 200, "plate": 60, "nc3d": 12}[cfg]
+    warmup = args.warmup if args.warmup is not None else {"wave": 10, "plate": 5, "nc3d": 2}[cfg]
+    ramp = args.ramp_steps if args.ramp_steps is not None else {"wave": 100, "plate": 30, "nc3d": 3}[cfg]
+    ppg = args.points_per_gpu if args.points_per_gpu is not None else (4_000_000 if cfg == "nc3d" else 2_000_000)
+    n_global = ppg * world if args.scaling == "weak" else args.global_points
+    pts_per_rank = n_global // world
 
-    n_global = args.points_per_gpu * world
-    Collo = synth_points(n_global, 1111)
-    SRC, IC = ricker_source(), ic_grid()
-    UP = np.zeros((0, 3))
-    eng = HipEngine(LAYERS, precision=args.precision, device=dev, max_points=args.chunk_points)
-    model = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, case="infinite", engine=eng, seed=1111, verbose=False)
+    # ------------------------------------------------------------------------------------------------------------------
+    if cfg == "wave":
+        from pinn_elastodynamics_amd.elastic_wave import DeepHPM
+        layers = [3] + 8 * [64] + [7]
+        streams, label = 4, "8x64"
+        Collo = synth_points(n_global, 1111)
+        SRC, IC = ricker_source(), ic_grid()
+        eng = HipEngine(layers, precision=args.precision, device=dev, max_points=args.chunk_points)
+        model = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, case="infinite", engine=eng, seed=1111, verbose=False)
+        step = lambda k: model.train(k, 1e-3, 1)
+        workload = (f"2D elastic wave (infinite), 8x64 tanh MLP, {pts_per_rank} collocation pts per GPU + IC 10201 + SRC 70400, Adam (TF1 rule) step "
+                    f"incl. gradient all-reduce (BASELINE configs[1]; x8 GPUs weak = configs[3]); {PRECISION_NOTE}")
+    elif cfg == "plate":
+        from pinn_elastodynamics_amd import pointsets as ps
+        from pinn_elastodynamics_amd.plate_hole import PINN
+        c = ps.plate_case(seed=1111, n_collo=int(n_global * 0.65), n_refine=int(n_global * 0.38), uv_width=64)
+        c["Collo"] = c["Collo"][:n_global] if c["Collo"].shape[0] >= n_global else c["Collo"]
+        n_global = c["Collo"].shape[0]
+        pts_per_rank = n_global // world
+        layers = c["uv_layers"]
+        streams, label = 5, "8x64 plate"
+        model = PINN(c["Collo"], c["HOLE"], c["IC"], c["LF"], c["RT"], c["UP"], c["LW"], c["DIST"], c["uv_layers"], c["dist_layers"], c["part_layers"],
+                     c["lb"], c["ub"], precision=args.precision, seed=1111, verbose=False)
+        eng = model.eng["uv"]
+        step = lambda k: model.train(k, 1e-3)
+        workload = (f"2D plate with hole (hard BC: composite P + D*N, nested u_tt, plane stress), 8x64 tanh MLP + frozen 4x20 distance / particular "
+                    f"nets, {pts_per_rank} collocation pts per GPU + 9960 hole-traction pts, Adam step (BASELINE configs[2]; its L-BFGS stage runs "
+                    f"on the host over the same kernels); two-kernel path (the fused kernel covers the 4-stream wave head only); {PRECISION_NOTE}")
+    else:
+        from pinn_elastodynamics_amd.navier_cauchy_3d import NavierCauchy3D, halfspace_case
+        c = halfspace_case(n_collo=n_global, n_ic=20000, n_top=20000, n_src=(200, 100), seed=1111, width=128, depth=10)
+        layers = c["uv_layers"]
+        streams, label = 5, "10x128 3-D"
+        eng = HipEngine(layers, precision=args.precision, device=dev, max_points=min(args.chunk_points, 1 << 17))
+        model = NavierCauchy3D(c["Collo"], c["SRC"], c["IC"], c["TOP"], layers, c["lb"], c["ub"], engine=eng, seed=1111, verbose=False)
+        step = lambda k: model.train(k, 1e-3, 1)
+        workload = (f"3D Navier-Cauchy half space (build-side extension, not in the reference; parity unpinned), 10x128 tanh MLP on (x,y,z,t), 12 outputs, "
+                    f"{pts_per_rank} collocation pts per GPU + IC/TOP 20000 each + SRC 20000, Adam step incl. gradient all-reduce (BASELINE configs[4]: "
+                    f"32 M pts on 8 GPUs); 'fp32' is served by f16x3 (fp32-class: sums and gradient within 2e-5 of the float64 oracle); two-kernel path")
+    flop_pt = flop_per_point(layers, streams)
 
     def barrier():
         if world > 1:
@@ -131,82 +212,104 @@ def main():
         torch.cuda.synchronize()
 
     # clock ramp: the GPU idles at a few hundred MHz; run the step untimed for a moment before the counted warm-up so that the
-    # K timed steps see settled clocks (not part of W or K; the weights simply train a little longer)
-    # (a fixed number of steps, not a time limit: every rank must issue the same sequence of all-reduces)
-    if args.ramp_steps > 0:
-        model.train(args.ramp_steps, 1e-3, 1)
+    # K timed steps see settled clocks (a fixed number of steps, not a time limit: every rank must issue the same all-reduces)
+    if ramp > 0:
+        step(ramp)
         torch.cuda.synchronize()
-    model.train(args.warmup, 1e-3, 1)
+    step(warmup)
     barrier()
     t0 = time.perf_counter()
-    losses = model.train(args.steps, 1e-3, 1)
+    losses = step(steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt.item())
-    value = n_global * args.steps / dt
+    value = n_global * steps / dt
+    final_loss = float(losses[-1][-1]) if isinstance(losses, (tuple, list)) and len(losses[-1]) else None
 
     out = {
-        "metric": "collocation-points/sec through PDE-residual loss+grad, 8x64 MLP",
-        "value": value, "unit": "collocation-points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "metric": f"collocation-points/sec through PDE-residual loss+grad, {label} MLP",
+        "value": value, "unit": "collocation-points/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * dt / steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": f"2D elastic wave (infinite), 8x64 tanh MLP, {args.points_per_gpu} collocation pts per GPU + IC 10201 + SRC 70400, "
-                               "Adam (TF1 rule) step incl. gradient all-reduce (BASELINE configs[1]; x8 GPUs = configs[3])",
-                   "collocation_points_global": n_global, "precision_mode": args.precision,
-                   "parallelism": f"dp{world}", "final_loss": losses[4][-1]},
+        "config": {"workload": workload, "bench_config": cfg, "collocation_points_global": n_global, "precision_mode": args.precision,
+                   "parallelism": f"dp{world}", "final_loss": final_loss, "algorithmic_flop_per_point": flop_pt},
+        "whole_path": {"achieved_tflops": flop_pt * value / 1e12, "frac_of_mfma_peak": flop_pt * value / 1e12 / (MFMA_PEAK_TFLOPS * world)},
     }
     if rank == 0:
-        # ---- roofline of the dominant kernel, HIP events on the launch stream (pinn_wave2d_loss_grad_profile)
-        x, y, t = (a[:args.points_per_gpu] for a in model._collo)
-        tw = [1.0 / args.points_per_gpu] * 7
-        eng.wave_loss_grad_profile(model.theta, x, y, t, LB, UB, True, tw)
-        reps = 3
-        acc = {"repack": 0.0, "chain": 0.0, "wgrad": 0.0, "reduce": 0.0}
-        for _ in range(reps):
-            ms = eng.wave_loss_grad_profile(model.theta, x, y, t, LB, UB, True, tw)
-            for k in acc:
-                acc[k] += ms[k] / reps
-        fused = acc["wgrad"] == 0.0          # the fused persistent kernel reports its whole time in the "chain" slot
-        n_launch = 1 if fused else -(-args.points_per_gpu // args.chunk_points)
-        flop_pt = FLOP_PER_PT if fused else CHAIN_FLOP_PER_PT
-        tflops = flop_pt * args.points_per_gpu / (acc["chain"] * 1e-3) / 1e12
-        traffic = None
-        try:    # HBM-side bytes per launch from the committed PMC passes of this kernel (profiles/README.md), if present
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_fused_pmc_summary.json")))
-            traffic = pm.get("hbm_bytes_per_launch") if fused and args.precision == "f16x3" else None
-        except Exception:
-            pass
-        out["roofline"] = {"kernel": "fused_wave_kernel (forward + reverse chain + weight gradient)" if fused
-                           else "chain_kernel (forward + reverse chain)", "bound": "mfma",
-                           "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
-                           "traffic": traffic, "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch,
-                           "algorithmic_flop_per_point": flop_pt,
-                           # what the matrix pipe actually executes in this precision mode: 3 MFMAs per product in the forward and
-                           # reverse chain (8 of the 12 contraction units), 2 in the weight gradient (4 of 12); 1 in the unsplit modes
-                           "issued_mfma_tflops": tflops * ((8 * 3 + 4 * 2) / 12.0 if args.precision in ("f16x3", "bf16x3") else 1.0),
-                           "note": "algorithmic flops: one product per contraction; the f16x3 mode issues 3 (forward/reverse chain) "
-                                   "or 2 (weight gradient) MFMAs per product"}
-        out["kernel_ms_per_step"] = acc
-        out["whole_path"] = {"algorithmic_flop_per_point": FLOP_PER_PT,
-                             "achieved_tflops": FLOP_PER_PT * value / 1e12, "frac_of_mfma_peak": FLOP_PER_PT * value / 1e12 / (MFMA_PEAK_TFLOPS * world)}
+        issued = (8 * 3 + 4 * 2) / 12.0 if args.precision in ("f16x3", "bf16x3") else 1.0
+        if cfg == "wave":
+            # ---- roofline of the dominant kernel, HIP events on the launch stream (pinn_wave2d_loss_grad_profile)
+            x, y, t = (a[:pts_per_rank] for a in model._collo)
+            tw = [1.0 / pts_per_rank] * 7
+            eng.wave_loss_grad_profile(model.theta, x, y, t, LB, UB, True, tw)
+            reps = 5
+            acc = {"repack": 0.0, "chain": 0.0, "wgrad": 0.0, "reduce": 0.0}
+            for _ in range(reps):
+                ms = eng.wave_loss_grad_profile(model.theta, x, y, t, LB, UB, True, tw)
+                for k in acc:
+                    acc[k] += ms[k] / reps
+            fused = acc["wgrad"] == 0.0          # the fused persistent kernel reports its whole time in the "chain" slot
+            n_launch = 1 if fused else -(-pts_per_rank // args.chunk_points)
+            kflop = flop_pt if fused else flop_pt * 8 // 12
+            tflops = kflop * pts_per_rank / (acc["chain"] * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "fused_wave_kernel (forward + reverse chain + weight gradient)" if fused else "chain_kernel (forward + reverse chain)",
+                               "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
+                               "traffic": None, "traffic_from_profiles": traffic_from_profiles("fused") if fused and args.precision == "f16x3" else None,
+                               "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch, "algorithmic_flop_per_point": kflop,
+                               "issued_mfma_tflops": tflops * issued,
+                               "note": "achieved = algorithmic flops (one product per contraction) / HIP-event launch time; the f16x3 mode issues 3 MFMAs per "
+                                       "product in the forward / reverse chain and 2 in the weight gradient, so a 100 %-busy matrix pipe is frac 0.375. "
+                                       "Measured limiter: the SIMD's instruction issue, not a pipe (DESIGN.md section 6). traffic is not measured in this "
+                                       "run (PMC counters need rocprofv3); see traffic_from_profiles"}
+            out["kernel_ms_per_step"] = acc
+        else:
+            # two-kernel path: the step is a sequence of chain + weight-gradient launches over workspace passes; report the whole step
+            tflops = flop_pt * pts_per_rank / (1e-3 * out["ms_per_step"]) / 1e12
+            out["roofline"] = {"kernel": "chain_kernel + wgrad_kernel (whole step, two-kernel path)", "bound": "hbm (spill panels) / mfma", "achieved": tflops,
+                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS, "traffic": None,
+                               "issued_mfma_tflops": tflops * issued, "algorithmic_flop_per_point": flop_pt,
+                               "note": "whole-step algorithmic flops / wall time per step (HIP work of a step is back-to-back on one stream); this path "
+                                       "spills the per-layer state and adjoint panels to HBM and is bound by that traffic, not by the matrix pipe"}
         if world == 1:
-            modes = {}
-            for mode in [m for m in args.extra_modes.split(",") if m in ("f16x3", "bf16", "f16", "bf16x3") and m != args.precision]:
-                e2 = HipEngine(LAYERS, precision=mode, device=dev, max_points=args.chunk_points)
-                m2 = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, case="infinite", engine=e2, seed=1111, verbose=False)
-                m2.train(2, 1e-3, 1)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                m2.train(5, 1e-3, 1)
-                torch.cuda.synchronize()
-                modes[mode] = {"value": n_global * 5 / (time.perf_counter() - t1), "unit": "collocation-points/s"}
-                del m2, e2
-            out["other_precision_modes"] = modes
+            if cfg == "wave":
+                from pinn_elastodynamics_amd.elastic_wave import DeepHPM
+                modes = {}
+                for mode in [m for m in args.extra_modes.split(",") if m in ("f16x3", "bf16", "f16", "bf16x3") and m != args.precision]:
+                    e2 = HipEngine(layers, precision=mode, device=dev, max_points=args.chunk_points)
+                    m2 = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, case="infinite", engine=e2, seed=1111, verbose=False)
+                    m2.train(5, 1e-3, 1)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    m2.train(20, 1e-3, 1)
+                    torch.cuda.synchronize()
+                    modes[mode] = {"value": n_global * 20 / (time.perf_counter() - t1), "unit": "collocation-points/s",
+                                   "note": "fields off by 5-10 % at trained weights (DESIGN.md section 3): not parity-grade" if mode == "bf16" else ""}
+                    del m2, e2
+                out["other_precision_modes"] = modes
+                if not args.no_small_config:
+                    # BASELINE configs[0]: 4x32 net, 50 k collocation points (the reference's own CPU-runnable case), GPU and CPU side by side
+                    l0 = [3] + 4 * [32] + [7]
+                    e0 = HipEngine(l0, precision=args.precision, device=dev, max_points=1 << 16)
+                    m0 = DeepHPM(synth_points(50_000, 1111), SRC, IC, np.zeros((0, 3)), l0, LB, UB, case="infinite", engine=e0, seed=1111, verbose=False)
+                    m0.train(200, 1e-3, 1)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    m0.train(1000, 1e-3, 1)
+                    torch.cuda.synchronize()
+                    d0 = (time.perf_counter() - t1) / 1000
+                    out["small_config"] = {"workload": "BASELINE configs[0]: 2D elastic wave, 4x32 tanh MLP, 50000 collocation pts + IC 10201 + SRC 70400, Adam step",
+                                           "gpu": {"value": 50_000 / d0, "unit": "collocation-points/s", "ms_per_step": 1e3 * d0},
+                                           "cpu_baseline": None if args.no_cpu_baseline else cpu_baseline(l0, 50_000, 2, "4x32")}
             if not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline()
+                if cfg == "nc3d":
+                    out["cpu_baseline"] = cpu_baseline_nc3d(layers, c["lb"], c["ub"])
+                else:
+                    out["cpu_baseline"] = cpu_baseline([3] + 8 * [64] + [layers[-1] if cfg == "wave" else 7], 32768, 3, "8x64")
+                    if cfg == "plate":
+                        out["cpu_baseline"]["sample"] += " (the 2-D wave head on the same net size: the plate's composite graph has no separate CPU restatement in bench.py)"
         print(json.dumps(out))
     if world > 1:
         torch.distributed.barrier()          # rank 0 is still profiling its kernel: leave together

@@ -59,10 +59,11 @@ def main():
             print("Adam: loss %.4e -> %.4e" % (hist[-1][0], hist[-1][-1]))
     if a.bfgs_iters:
         model.train_bfgs(batch_num=a.batch_num, options=dict(maxiter=a.bfgs_iters, maxfun=a.bfgs_iters))
+    final = model.getloss()          # every rank: the evaluation all-reduces across the data-parallel group
     if rank == 0:
         print("--- %.1f seconds ---" % (time.time() - t0))
         model.save_NN(a.save)
-        model.getloss()
+        print("loss terms on the full sets:", " ".join("%.4e" % v for v in final))
         xc, yc, r = c["source"]
         x_star, y_star = ps.probe_points(c["lb"][0], c["ub"][0], c["lb"][1], c["ub"][1], 201, xc, yc, r)
         times = ps.frame_times(c["ub"][2])
@@ -75,6 +76,9 @@ def main():
             else:
                 u, v = model.predict(x_star, y_star, np.full_like(x_star, times[i]))[:2]
                 print("frame %3d t=%5.2f  max |(u,v)| = %.4f" % (i, times[i], float(np.sqrt(u ** 2 + v ** 2).max())))
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -174,6 +174,35 @@ int pinn_data_loss_grad_multi(const float* params_flat, const int* layers, int n
                               float* grad_flat_out, int accumulate,
                               int precision_mode, void* workspace, size_t ws_bytes, void* stream);
 
+/* ---- 3-D Navier-Cauchy extension (BASELINE.json configs[4]).  NOT in the reference: all four reference scripts are 2-D + time
+ * (SURVEY.md section 0), so these entry points have no reference lines to replace; they state the 3-D form of net_f_sig
+ * (INF:221-265) the way oracle/nc3d_oracle.py spells it out, and parity for them is unpinned by definition.
+ *   layers = {4, H x k, 12}; inputs (x, y, z, t); outputs (u,v,w, ut,vt,wt, s11,s22,s33, s12,s13,s23);
+ *   residuals (f_u,f_v,f_w, f_ut,f_vt,f_wt, f_s11,f_s22,f_s33, f_s12,f_s13,f_s23); isotropic Hooke law, E, mu, rho as INF:33-35.
+ *   loss_terms_out[i] = sum_n f_i(n)^2 (12 values), grad_flat_out (+)= d/dparams sum_i term_weights[i] * loss_terms[i].
+ * Split-precision modes only (PINN_PREC_F16X3 / PINN_PREC_BF16X3).  Workspace sizing: the same two functions (layers[0] == 4). */
+int pinn_nc3d_loss_grad(const float* params_flat, const int* layers, int n_layers,
+                        const float* x, const float* y, const float* z, const float* t, int64_t n,
+                        const double lb[4], const double ub[4], int normalize,
+                        double E, double mu, double rho, const float term_weights[12],
+                        float* loss_terms_out, float* grad_flat_out, int accumulate,
+                        int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
+/* Value-only terms of the 4-input net (initial state, sources, the traction-free surface s33 = s13 = s23 = 0 of the half space):
+ * pinn_data_loss_grad with four coordinates; targets SoA [n_out][n] or NULL, out_weights[n_out], loss_terms_out[n_out]. */
+int pinn_nc3d_data_loss_grad(const float* params_flat, const int* layers, int n_layers,
+                             const float* x, const float* y, const float* z, const float* t, int64_t n,
+                             const double lb[4], const double ub[4], int normalize,
+                             const float* targets, const float* out_weights,
+                             float* loss_terms_out, float* grad_flat_out, int accumulate,
+                             int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
+/* Forward only: fields_out [5][n_out][n] = the outputs and their derivatives w.r.t. x, y, z, t (predict of the 3-D case). */
+int pinn_nc3d_fields(const float* params_flat, const int* layers, int n_layers,
+                     const float* x, const float* y, const float* z, const float* t, int64_t n,
+                     const double lb[4], const double ub[4], int normalize,
+                     float* fields_out, int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
 /* Replaces tf.train.AdamOptimizer's update (INF:131-133; TF1 rule: epsilon outside the bias
  * correction).  step is 1-based.  All arrays are length n_params, updated in place. */
 int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_flat, int64_t n_params,

@@ -78,6 +78,12 @@ class PinnLib:
         L.pinn_plate2d_traction_loss_grad.restype = i32
         L.pinn_stream_loss_grad.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, pf32, vp, vp, i32, i32, vp, sz, vp]
         L.pinn_stream_loss_grad.restype = i32
+        L.pinn_nc3d_loss_grad.argtypes = [vp, pi32, i32, vp, vp, vp, vp, i64, pf64, pf64, i32, f64, f64, f64, pf32, vp, vp, i32, i32, vp, sz, vp]
+        L.pinn_nc3d_loss_grad.restype = i32
+        L.pinn_nc3d_data_loss_grad.argtypes = [vp, pi32, i32, vp, vp, vp, vp, i64, pf64, pf64, i32, vp, pf32, vp, vp, i32, i32, vp, sz, vp]
+        L.pinn_nc3d_data_loss_grad.restype = i32
+        L.pinn_nc3d_fields.argtypes = [vp, pi32, i32, vp, vp, vp, vp, i64, pf64, pf64, i32, vp, i32, vp, sz, vp]
+        L.pinn_nc3d_fields.restype = i32
         L.pinn_adam_step.argtypes = [vp, vp, vp, vp, i64, f64, f64, f64, f64, i64, vp]
         L.pinn_adam_step.restype = i32
 
@@ -89,6 +95,10 @@ class PinnLib:
     @staticmethod
     def _d3(v):
         return (C.c_double * 3)(*[float(x) for x in v])
+
+    @staticmethod
+    def _d4(v):
+        return (C.c_double * 4)(*[float(x) for x in v])
 
     @staticmethod
     def _floats(v, n):
@@ -184,6 +194,26 @@ class PinnLib:
                                             int(bool(normalize)), targets, (C.c_float * len(w))(*w), loss_out, grad_out,
                                             int(bool(accumulate)), mode_bits(prec), ws, int(ws_bytes), stream)
         self.check(rc, "pinn_stream_loss_grad")
+
+    # -- 3-D Navier-Cauchy extension (4 inputs x, y, z, t; 12 outputs) ---------------------------------------------
+    def nc3d_loss_grad(self, params, layers, x, y, z, t, n, lb, ub, normalize, E, mu, rho, term_weights, loss_out, grad_out, accumulate,
+                       prec, ws, ws_bytes, stream=0):
+        rc = self.lib.pinn_nc3d_loss_grad(params, self._ints(layers), len(layers), x, y, z, t, int(n), self._d4(lb), self._d4(ub),
+                                          int(bool(normalize)), float(E), float(mu), float(rho), self._floats(term_weights, 12), loss_out,
+                                          grad_out, int(bool(accumulate)), mode_bits(prec), ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_nc3d_loss_grad")
+
+    def nc3d_data_loss_grad(self, params, layers, x, y, z, t, n, lb, ub, normalize, targets, out_weights, loss_out, grad_out, accumulate,
+                            prec, ws, ws_bytes, stream=0):
+        rc = self.lib.pinn_nc3d_data_loss_grad(params, self._ints(layers), len(layers), x, y, z, t, int(n), self._d4(lb), self._d4(ub),
+                                               int(bool(normalize)), targets, self._floats(out_weights, 16), loss_out, grad_out,
+                                               int(bool(accumulate)), mode_bits(prec), ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_nc3d_data_loss_grad")
+
+    def nc3d_fields(self, params, layers, x, y, z, t, n, lb, ub, normalize, fields_out, prec, ws, ws_bytes, stream=0):
+        rc = self.lib.pinn_nc3d_fields(params, self._ints(layers), len(layers), x, y, z, t, int(n), self._d4(lb), self._d4(ub),
+                                       int(bool(normalize)), fields_out, mode_bits(prec), ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_nc3d_fields")
 
     def adam_step(self, params, m, v, grad, n_params, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, stream=0):
         rc = self.lib.pinn_adam_step(params, m, v, grad, int(n_params), float(lr), float(beta1), float(beta2), float(eps),

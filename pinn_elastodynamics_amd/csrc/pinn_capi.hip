@@ -28,18 +28,20 @@ static const Impl* find_impl(int precision_mode, int width) {
     return nullptr;
 }
 
-static int decode_net(const int* layers, int n_layers, NetDesc& net, int& width) {
+// din: 3 for the reference's (x, y, t) nets (up to 8 outputs), 4 for the (x, y, z, t) nets of the 3-D entry points (up to 16)
+static int decode_net(const int* layers, int n_layers, NetDesc& net, int& width, int din = 3) {
     if (!layers) return PINN_ERR_NULL;
     if (n_layers < 3 || n_layers - 1 > MAX_WLAYERS) return PINN_ERR_LAYERS;
-    if (layers[0] != 3) return PINN_ERR_LAYERS;
+    if (layers[0] != din) return PINN_ERR_LAYERS;
     const int h = layers[1], nout = layers[n_layers - 1];
     for (int i = 1; i < n_layers - 1; ++i) if (layers[i] != h) return PINN_ERR_LAYERS;
-    if (nout < 1 || nout > 8) return PINN_ERR_LAYERS;
+    if (nout < 1 || nout > (din == 4 ? 16 : 8)) return PINN_ERR_LAYERS;
     width = pinn_supported_width(h);
     if (!width) return PINN_ERR_LAYERS;
     net.nl = n_layers - 2;
     net.h = h;
     net.nout = nout;
+    net.din = din;
     int o = 0;
     for (int l = 0; l <= net.nl; ++l) {
         const int n_in = layers[l], n_out = layers[l + 1];
@@ -53,8 +55,10 @@ static int decode_net(const int* layers, int n_layers, NetDesc& net, int& width)
     return PINN_OK;
 }
 
-static void input_map(const double lb[3], const double ub[3], int normalize, Call& c) {
-    for (int k = 0; k < 3; ++k) {
+static void input_map(const double* lb, const double* ub, int normalize, Call& c, int din = 3) {
+    c.sx[3] = 1.0f;
+    c.ox[3] = 0.0f;
+    for (int k = 0; k < din; ++k) {
         if (normalize) {   // INF:191  H = 2 (X - lb)/(ub - lb) - 1
             const double s = 2.0 / (ub[k] - lb[k]);
             c.sx[k] = (float)s;
@@ -95,7 +99,7 @@ const char* pinn_error_string(int code) {
     switch (code) {
         case PINN_OK: return "ok";
         case PINN_ERR_NULL: return "required pointer is NULL";
-        case PINN_ERR_LAYERS: return "unsupported layer list (need {3, H x k, n_out<=8}, H<=160, <=16 weight layers, and a compiled variant)";
+        case PINN_ERR_LAYERS: return "unsupported layer list (need {3, H x k, n_out<=8} -- {4, H x k, 12} for the 3-D entry points --, H<=160, <=16 weight layers, and a compiled variant)";
         case PINN_ERR_PRECISION: return "unknown precision_mode";
         case PINN_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
         case PINN_ERR_SIZE: return "n must not be negative";
@@ -113,29 +117,30 @@ static int empty_batch(const Call& c, int nterms) {
 }
 
 static int prepare(const float* params, const int* layers, int n_layers, const float* x, const float* y, const float* t, int64_t n,
-                   const double lb[3], const double ub[3], int normalize, int precision_mode, void* ws, size_t ws_bytes, void* stream,
-                   Call& c, const Impl*& impl) {
+                   const double* lb, const double* ub, int normalize, int precision_mode, void* ws, size_t ws_bytes, void* stream,
+                   Call& c, const Impl*& impl, int din = 3, const float* z = nullptr) {
     if (!params || !ws) return PINN_ERR_NULL;
     if (n < 0) return PINN_ERR_SIZE;
-    if (n > 0 && (!x || !y || !t)) return PINN_ERR_NULL;          // n == 0 is a valid empty batch (see empty_batch)
+    if (n > 0 && (!x || !y || !t || (din == 4 && !z))) return PINN_ERR_NULL;          // n == 0 is a valid empty batch (see empty_batch)
     if (normalize && (!lb || !ub)) return PINN_ERR_NULL;
     c.weights_packed = (precision_mode & PINN_FLAG_WEIGHTS_PACKED) ? 1 : 0;
     c.adj_shift = (precision_mode >> 16) & 0x1f;
     precision_mode &= ~(PINN_FLAG_WEIGHTS_PACKED | (0x1f << 16));
     if (precision_mode < 0 || precision_mode > 3) return PINN_ERR_PRECISION;
     int width = 0;
-    const int rc = decode_net(layers, n_layers, c.net, width);
+    const int rc = decode_net(layers, n_layers, c.net, width, din);
     if (rc) return rc;
     impl = find_impl(precision_mode, width);
     if (!impl) return PINN_ERR_LAYERS;
     c.params = params;
+    c.z = z;
     c.nsets = 0;
     c.targets = nullptr;
     c.x = x;
     c.y = y;
     c.t = t;
     c.n = (long)n;
-    input_map(lb, ub, normalize, c);
+    input_map(lb, ub, normalize, c, din);
     c.ws = ws;
     c.ws_bytes = ws_bytes;
     c.stream = (hipStream_t)stream;
@@ -143,7 +148,7 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     c.grad_out = nullptr;
     c.accumulate = 0;
     c.c1 = c.c2 = c.G = c.rho = 0.0f;
-    for (int i = 0; i < 8; ++i) c.tw[i] = 0.0f;
+    for (int i = 0; i < 16; ++i) c.tw[i] = 0.0f;
     c.targets = nullptr;
     c.fields_out = nullptr;
     c.aux = nullptr;
@@ -155,19 +160,22 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     return PINN_OK;
 }
 
+// the sizing entry points accept the same precision_mode word as the calls (flag and shift bits are ignored) and both input counts
+static int mode_only(int precision_mode) { return precision_mode & ~(PINN_FLAG_WEIGHTS_PACKED | (0x1f << 16)); }
+
 size_t pinn_workspace_bytes(const int* layers, int n_layers, int64_t n, int precision_mode) {
     NetDesc net;
     int width = 0;
-    if (n <= 0 || decode_net(layers, n_layers, net, width)) return 0;
-    const Impl* impl = find_impl(precision_mode, width);
+    if (n <= 0 || !layers || decode_net(layers, n_layers, net, width, layers[0] == 4 ? 4 : 3)) return 0;
+    const Impl* impl = find_impl(mode_only(precision_mode), width);
     return impl ? impl->ws_bytes(net, (long)n, 0) : 0;
 }
 
 size_t pinn_min_workspace_bytes(const int* layers, int n_layers, int precision_mode) {
     NetDesc net;
     int width = 0;
-    if (decode_net(layers, n_layers, net, width)) return 0;
-    const Impl* impl = find_impl(precision_mode, width);
+    if (!layers || decode_net(layers, n_layers, net, width, layers[0] == 4 ? 4 : 3)) return 0;
+    const Impl* impl = find_impl(mode_only(precision_mode), width);
     return impl ? impl->ws_bytes(net, 1L << 40, 1) : 0;
 }
 
@@ -366,6 +374,61 @@ int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_lay
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, c.net.nout);
     return impl->stream_loss_grad(c);
+}
+
+// ---- 4-input family: the 3-D Navier-Cauchy extension (BASELINE.json configs[4]; not in the reference -- oracle/nc3d_oracle.py) ----
+int pinn_nc3d_loss_grad(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* z,
+                        const float* t, int64_t n, const double lb[4], const double ub[4], int normalize, double E, double mu, double rho,
+                        const float term_weights[12], float* loss_terms_out, float* grad_flat_out, int accumulate, int precision_mode,
+                        void* workspace, size_t ws_bytes, void* stream) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl, 4, z);
+    if (rc) return rc;
+    if (!term_weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
+    if (c.net.nout != 12) return PINN_ERR_LAYERS;
+    const double coef = E / ((1.0 + mu) * (1.0 - 2.0 * mu));       // isotropic law: c1 = lambda + 2G, c2 = lambda
+    c.c1 = (float)(coef * (1.0 - mu));
+    c.c2 = (float)(coef * mu);
+    c.G = (float)(E / (2.0 * (1.0 + mu)));
+    c.rho = (float)rho;
+    for (int i = 0; i < 12; ++i) c.tw[i] = term_weights[i];
+    c.loss_out = loss_terms_out;
+    c.grad_out = grad_flat_out;
+    c.accumulate = accumulate;
+    if (n == 0) return empty_batch(c, 12);
+    return impl->nc3d_loss_grad(c);
+}
+
+int pinn_nc3d_data_loss_grad(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* z,
+                             const float* t, int64_t n, const double lb[4], const double ub[4], int normalize, const float* targets,
+                             const float* out_weights, float* loss_terms_out, float* grad_flat_out, int accumulate, int precision_mode,
+                             void* workspace, size_t ws_bytes, void* stream) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl, 4, z);
+    if (rc) return rc;
+    if (!out_weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
+    for (int i = 0; i < c.net.nout; ++i) c.tw[i] = out_weights[i];
+    c.targets = targets;
+    c.loss_out = loss_terms_out;
+    c.grad_out = grad_flat_out;
+    c.accumulate = accumulate;
+    if (n == 0) return empty_batch(c, c.net.nout);
+    return impl->nc3d_data_loss_grad(c);
+}
+
+int pinn_nc3d_fields(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* z,
+                     const float* t, int64_t n, const double lb[4], const double ub[4], int normalize, float* fields_out, int precision_mode,
+                     void* workspace, size_t ws_bytes, void* stream) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl, 4, z);
+    if (rc) return rc;
+    if (n > 0 && !fields_out) return PINN_ERR_NULL;
+    c.fields_out = fields_out;
+    if (n == 0) return 0;
+    return impl->nc3d_fields(c);
 }
 
 int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_flat, int64_t n_params, double lr, double beta1,

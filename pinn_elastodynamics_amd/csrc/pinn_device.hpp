@@ -162,14 +162,15 @@ __device__ __forceinline__ float round16(float a) {
 struct NetDesc {
     int nl;                    // hidden layers; weight matrices = nl + 1
     int h;                     // real hidden width (<= WIDTH template parameter)
-    int nout;                  // real number of outputs (7 for the wave scripts, INF:204-210)
+    int nout;                  // real number of outputs (7 for the wave scripts, INF:204-210; 12 for the 3-D extension)
+    int din;                   // inputs: 3 = (x, y, t) as in the reference, 4 = (x, y, z, t) for the 3-D extension
     int w_off[MAX_WLAYERS];    // offset of W_l in the flat parameter vector (W row-major [in,out])
     int b_off[MAX_WLAYERS];    // offset of b_l
     int nparams;
 };
 
 struct PackedWeights {         // produced by repack_kernel, consumed by chain_kernel
-    const float* w0p;          // [WIDTH][4]  (W0[0][f], W0[1][f], W0[2][f], b0[f])
+    const float* w0p;          // din = 3: [WIDTH][4] (W0[0][f], W0[1][f], W0[2][f], b0[f]);  din = 4: [WIDTH][8] (W0[0..3][f], b0[f], 0, 0, 0)
     const float* bias_mid;     // [nl-1][WIDTH] biases of weight layers 1..nl-1
     const float* bias_last;    // [16]
     const u32x4* frags;        // fragment store, see frag_index()
@@ -181,7 +182,13 @@ struct PackedWeights {         // produced by repack_kernel, consumed by chain_k
 // HEAD_PLATE  : 5 streams (value, x, y, t, tt), composite P + D*N with frozen D/P streams in `aux`, plane-stress residuals (PLATE:358-439)
 // HEAD_TRACTION: 1 stream, hole traction of the composite (PLATE:452-461); aux = D0[5], P0[5], nx, ny per point
 // HEAD_STREAMS: 5 streams, sum_{s,o} w[s][o] (Y[s][o] - target[s][o])^2 -- the D / P pre-training losses (PLATE:194-215)
-enum { HEAD_WAVE = 0, HEAD_DATA = 1, HEAD_FIELDS = 2, HEAD_PLATE = 3, HEAD_TRACTION = 4, HEAD_STREAMS = 5 };
+// HEAD_NC3D   : 5 first-order streams (value, x, y, z, t), 4 inputs, 12 outputs: 3-D Navier-Cauchy residuals (build-side extension of
+//               INF:221-265, stated in oracle/nc3d_oracle.py; BASELINE.json configs[4])
+// HEAD_DATA3D : HEAD_DATA for the 4-input net (up to 16 outputs);  HEAD_FIELDS3D : HEAD_FIELDS for it (5 streams)
+enum { HEAD_WAVE = 0, HEAD_DATA = 1, HEAD_FIELDS = 2, HEAD_PLATE = 3, HEAD_TRACTION = 4, HEAD_STREAMS = 5, HEAD_NC3D = 6, HEAD_DATA3D = 7,
+       HEAD_FIELDS3D = 8 };
+__host__ __device__ constexpr bool head_is_3d(int head) { return head == HEAD_NC3D || head == HEAD_DATA3D || head == HEAD_FIELDS3D; }
+constexpr int LOSS_SLOTS_3D = 16;     // per-wave loss partials: 8 slots for the reference's heads, 16 for the 3-D ones
 
 struct ChainArgs {
     NetDesc net;
@@ -189,18 +196,19 @@ struct ChainArgs {
     const float* x;            // SoA point coordinates
     const float* y;
     const float* t;
+    const float* z;            // third space coordinate of the 4-input heads (input order x, y, z, t), else unused
     long n;                    // total points of this call
     long tile0;                // first tile of this workspace chunk
     long ntiles;               // tiles in this chunk
-    float sx[3], ox[3];        // input map x' = x*sx + ox  (INF:191 when normalising, identity otherwise)
+    float sx[4], ox[4];        // input map x' = x*sx + ox  (INF:191 when normalising, identity otherwise); 4-input heads: index 2 = z, 3 = t
     float c1, c2, G, rho;      // Hooke coefficients (INF:238-241 / PLATE:416-418) and density
-    float tw[8];               // per-residual (HEAD_WAVE) or per-output (HEAD_DATA) weights, max-normalised
+    float tw[16];              // per-residual (HEAD_WAVE / HEAD_NC3D) or per-output (HEAD_DATA) weights, max-normalised
     const float* targets;      // HEAD_DATA: [nout][n] SoA targets or nullptr (= 0)
     uint16_t* S;               // forward-state panels of this chunk
     uint16_t* Z;               // adjoint panels of this chunk
     long S_tile_stride;        // in 16-bit elements
     long Z_tile_stride;
-    float* loss_part;          // [total waves][8] per-wave partial sums of squares
+    float* loss_part;          // [total waves][8 or LOSS_SLOTS_3D] per-wave partial sums of squares
     float* fields_out;         // HEAD_FIELDS: [NS*nout][n]  (Y, dY/dx, dY/dy, dY/dt [, d2Y/dt2])
     const float* aux;          // HEAD_PLATE: [2 nets (D,P)][5 streams][5 fields][n]; HEAD_TRACTION: [12][n]; HEAD_STREAMS: targets [5][nout][n] or null
     float w5[5][8];            // HEAD_STREAMS: per (stream, output) weights, max-normalised
@@ -328,10 +336,17 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackArgs a) {
     for (long i = gid; i < WIDTH; i += nthreads) {
         const int f = (int)i;
         const bool ok = f < H;
-        a.w0p[4 * f + 0] = ok ? a.params[a.net.w_off[0] + 0 * H + f] : 0.0f;
-        a.w0p[4 * f + 1] = ok ? a.params[a.net.w_off[0] + 1 * H + f] : 0.0f;
-        a.w0p[4 * f + 2] = ok ? a.params[a.net.w_off[0] + 2 * H + f] : 0.0f;
-        a.w0p[4 * f + 3] = ok ? a.params[a.net.b_off[0] + f] : 0.0f;
+        if (a.net.din == 4) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a.w0p[8 * f + k] = ok ? a.params[a.net.w_off[0] + k * H + f] : 0.0f;
+            a.w0p[8 * f + 4] = ok ? a.params[a.net.b_off[0] + f] : 0.0f;
+            a.w0p[8 * f + 5] = a.w0p[8 * f + 6] = a.w0p[8 * f + 7] = 0.0f;
+        } else {
+            a.w0p[4 * f + 0] = ok ? a.params[a.net.w_off[0] + 0 * H + f] : 0.0f;
+            a.w0p[4 * f + 1] = ok ? a.params[a.net.w_off[0] + 1 * H + f] : 0.0f;
+            a.w0p[4 * f + 2] = ok ? a.params[a.net.w_off[0] + 2 * H + f] : 0.0f;
+            a.w0p[4 * f + 3] = ok ? a.params[a.net.b_off[0] + f] : 0.0f;
+        }
     }
     for (long i = gid; i < (long)(nl - 1) * WIDTH; i += nthreads) {
         const int l = 1 + (int)(i / WIDTH), f = (int)(i % WIDTH);
@@ -357,8 +372,11 @@ template <class Op, int SPLIT, int WIDTH, int NB, int NS, int HEAD>
 struct Chain {
     static constexpr int WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1, TP = 16 * NB;
     static constexpr int NPS = SPLIT == 3 ? 2 : 1;     // stored weight-fragment parts (see repack_kernel)
-    static constexpr bool SECOND = NS == 5;            // stream 4 = second time derivative (plate, PLATE:427-433)
-    static constexpr int NT = NS >= 4 ? 3 : 0;         // first-order tangent streams 1..NT
+    static constexpr int DIN = head_is_3d(HEAD) ? 4 : 3;                       // inputs (x, y, t) or (x, y, z, t)
+    static constexpr bool SECOND = NS == 5 && DIN == 3;                         // stream 4 = second time derivative (plate, PLATE:427-433)
+    static constexpr int NT = NS >= 4 ? (SECOND ? 3 : NS - 1) : 0;              // first-order tangent streams 1..NT (one per input)
+    static constexpr int NOG = DIN == 4 ? 16 : 8;                               // outputs every lane gathers for the head
+    static constexpr int LT = DIN == 4 ? LOSS_SLOTS_3D : 8;                     // loss partial slots per wave
     static constexpr float INV_LS = 1.0f / Op::LO_SCALE;
     typedef PanelGeom<WIDTH, NB, NS, NP> PG;
     typedef FragIndex<WIDTH> FI;
@@ -485,15 +503,26 @@ struct Chain {
     template <int MB>
     struct MbLoop {
         // forward first layer (K = 3, plain VALU): INF:191-195 with the tangent seeds e_k * sx_k
-        static __device__ __forceinline__ void first(const ChainArgs& a, const float (&xin)[NB][3], u32x4 (&Bn)[NS][NB][KS][NP],
+        static __device__ __forceinline__ void first(const ChainArgs& a, const float (&xin)[NB][DIN], u32x4 (&Bn)[NS][NB][KS][NP],
                                                      uint16_t* panel, int c, int q) {
             float vals[NS][NB][4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(a.pw.w0p + 4 * (16 * MB + 4 * q + r));
+                float w[5];              // input weights of feature 16 MB + 4q + r, then its bias
+                if constexpr (DIN == 4) {
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(a.pw.w0p + 8 * (16 * MB + 4 * q + r));
+                    w[0] = wa[0]; w[1] = wa[1]; w[2] = wa[2]; w[3] = wa[3];
+                    w[4] = a.pw.w0p[8 * (16 * MB + 4 * q + r) + 4];
+                } else {
+                    const f32x4 wa = *reinterpret_cast<const f32x4*>(a.pw.w0p + 4 * (16 * MB + 4 * q + r));
+                    w[0] = wa[0]; w[1] = wa[1]; w[2] = wa[2]; w[3] = 0.0f;
+                    w[4] = wa[3];
+                }
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const float z = w[3] + w[0] * xin[nb][0] + w[1] * xin[nb][1] + w[2] * xin[nb][2];
+                    float z = w[4];
+#pragma unroll
+                    for (int k = 0; k < DIN; ++k) z += w[k] * xin[nb][k];
                     float h, sd;
                     tanh_act(z, h, sd);
                     vals[0][nb][r] = h;
@@ -551,15 +580,16 @@ struct Chain {
         const int wpb = blockDim.x >> 6;
         const long gwave = (long)blockIdx.x * wpb + (threadIdx.x >> 6), nwaves = (long)gridDim.x * wpb;
         const int nl = a.net.nl;
-        constexpr bool SPILL = HEAD != HEAD_FIELDS;
-        float lsum[8];
+        constexpr bool FWD_ONLY = HEAD == HEAD_FIELDS || HEAD == HEAD_FIELDS3D;
+        constexpr bool SPILL = !FWD_ONLY;
+        float lsum[LT];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) lsum[i] = 0.0f;
+        for (int i = 0; i < LT; ++i) lsum[i] = 0.0f;
 
         for (long tile = gwave; tile < a.ntiles; tile += nwaves) {
             uint16_t* St = SPILL ? a.S + tile * a.S_tile_stride : nullptr;
             uint16_t* Zt = SPILL ? a.Z + tile * a.Z_tile_stride : nullptr;
-            float xin[NB][3];
+            float xin[NB][DIN];
             bool valid[NB];
             long pidx[NB];
 #pragma unroll
@@ -569,9 +599,14 @@ struct Chain {
                 pidx[nb] = valid[nb] ? p : a.n - 1;
                 xin[nb][0] = a.x[pidx[nb]] * a.sx[0] + a.ox[0];
                 xin[nb][1] = a.y[pidx[nb]] * a.sx[1] + a.ox[1];
-                xin[nb][2] = a.t[pidx[nb]] * a.sx[2] + a.ox[2];
+                if constexpr (DIN == 4) {
+                    xin[nb][2] = a.z[pidx[nb]] * a.sx[2] + a.ox[2];
+                    xin[nb][3] = a.t[pidx[nb]] * a.sx[3] + a.ox[3];
+                } else {
+                    xin[nb][2] = a.t[pidx[nb]] * a.sx[2] + a.ox[2];
+                }
             }
-            // ---- S_0: the inputs as a 16-row panel (rows 0..2 = x'; tangent stream k has sx_k in row k)
+            // ---- S_0: the inputs as a 16-row panel (rows 0..DIN-1 = x'; tangent stream k has sx_k in row k)
             if (SPILL) {
                 float v0[NS][NB][4];
 #pragma unroll
@@ -581,7 +616,7 @@ struct Chain {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = 0.0f;
-                            if (q == 0 && r < 3 && s <= 3) v = (s == 0) ? xin[nb][r] : (r == s - 1 ? a.sx[r] : 0.0f);
+                            if (q == 0 && r < DIN && s <= NT) v = (s == 0) ? xin[nb][r] : (r == s - 1 ? a.sx[r] : 0.0f);
                             v0[s][nb][r] = v;
                         }
                 u32x4 dummy[NS][NB][1][NP];
@@ -607,8 +642,8 @@ struct Chain {
             f32x4 yacc[NS][NB], yaccc[NS][NB];
             gemm_block<KS>(a.pw.frags + (long)FI::fwd_last(nl, 0) * NPS * 64, lane, B, yacc, yaccc);
             const f32x4 bl = *reinterpret_cast<const f32x4*>(a.pw.bias_last + 4 * q);
-            // Every lane gathers all 8 (padded) outputs of its point: own block + the q^1 partner's
-            float Y[NS][NB][8];
+            // Every lane gathers the NOG (padded) outputs of its point: own block + the q^1 partner's (8 outputs), or all four (16)
+            float Y[NS][NB][NOG];
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -616,12 +651,17 @@ struct Chain {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float own = comb(yacc[s][nb], yaccc[s][nb], r) + (s == 0 ? bl[r] : 0.0f);
-                        const float oth = __shfl_xor(own, 16);
-                        Y[s][nb][r] = (q & 1) ? oth : own;
-                        Y[s][nb][4 + r] = (q & 1) ? own : oth;
+                        if constexpr (NOG == 16) {
+#pragma unroll
+                            for (int qq = 0; qq < 4; ++qq) Y[s][nb][4 * qq + r] = __shfl(own, c + 16 * qq);
+                        } else {
+                            const float oth = __shfl_xor(own, 16);
+                            Y[s][nb][r] = (q & 1) ? oth : own;
+                            Y[s][nb][4 + r] = (q & 1) ? own : oth;
+                        }
                     }
             // ---- head
-            float adj[NS][NB][8];     // dL/d(stream s of output o) for the 8 padded outputs
+            float adj[NS][NB][NOG];     // dL/d(stream s of output o) for the padded outputs
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const float vm = valid[nb] ? 1.0f : 0.0f;
@@ -667,6 +707,73 @@ struct Chain {
                     adj[3][nb][1] = g[3];
                     adj[3][nb][2] = -a.rho * g[0];
                     adj[3][nb][3] = -a.rho * g[1];
+                } else if constexpr (HEAD == HEAD_NC3D) {
+                    // 3-D Navier-Cauchy residuals (oracle/nc3d_oracle.py: the 3-D statement of INF:221-265); outputs
+                    // (u,v,w, ut,vt,wt, s11,s22,s33, s12,s13,s23); streams (value, d/dx, d/dy, d/dz, d/dt); c1 = lambda+2G, c2 = lambda
+                    const float(&V)[16] = Y[0][nb];
+                    const float(&X)[16] = Y[1][nb];
+                    const float(&Yy)[16] = Y[2][nb];
+                    const float(&Zz)[16] = Y[3][nb];
+                    const float(&T)[16] = Y[4][nb];
+                    const float e11 = X[0], e22 = Yy[1], e33 = Zz[2];
+                    const float e12 = Yy[0] + X[1], e13 = Zz[0] + X[2], e23 = Zz[1] + Yy[2];
+                    float f[12];
+                    f[0] = X[6] + Yy[9] + Zz[10] - a.rho * T[3];
+                    f[1] = X[9] + Yy[7] + Zz[11] - a.rho * T[4];
+                    f[2] = X[10] + Yy[11] + Zz[8] - a.rho * T[5];
+                    f[3] = T[0] - V[3];
+                    f[4] = T[1] - V[4];
+                    f[5] = T[2] - V[5];
+                    f[6] = V[6] - (a.c1 * e11 + a.c2 * (e22 + e33));
+                    f[7] = V[7] - (a.c1 * e22 + a.c2 * (e11 + e33));
+                    f[8] = V[8] - (a.c1 * e33 + a.c2 * (e11 + e22));
+                    f[9] = V[9] - a.G * e12;
+                    f[10] = V[10] - a.G * e13;
+                    f[11] = V[11] - a.G * e23;
+                    float g[12];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        if (q == 0) lsum[i] += vm * f[i] * f[i];
+                        g[i] = 2.0f * a.tw[i] * f[i] * vm;
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int o = 0; o < NOG; ++o) adj[s][nb][o] = 0.0f;
+                    // value stream
+                    adj[0][nb][3] = -g[3];
+                    adj[0][nb][4] = -g[4];
+                    adj[0][nb][5] = -g[5];
+#pragma unroll
+                    for (int i = 6; i < 12; ++i) adj[0][nb][i] = g[i];
+                    // d/dx
+                    adj[1][nb][0] = -(a.c1 * g[6] + a.c2 * (g[7] + g[8]));
+                    adj[1][nb][1] = -a.G * g[9];
+                    adj[1][nb][2] = -a.G * g[10];
+                    adj[1][nb][6] = g[0];
+                    adj[1][nb][9] = g[1];
+                    adj[1][nb][10] = g[2];
+                    // d/dy
+                    adj[2][nb][0] = -a.G * g[9];
+                    adj[2][nb][1] = -(a.c1 * g[7] + a.c2 * (g[6] + g[8]));
+                    adj[2][nb][2] = -a.G * g[11];
+                    adj[2][nb][9] = g[0];
+                    adj[2][nb][7] = g[1];
+                    adj[2][nb][11] = g[2];
+                    // d/dz
+                    adj[3][nb][0] = -a.G * g[10];
+                    adj[3][nb][1] = -a.G * g[11];
+                    adj[3][nb][2] = -(a.c1 * g[8] + a.c2 * (g[6] + g[7]));
+                    adj[3][nb][10] = g[0];
+                    adj[3][nb][11] = g[1];
+                    adj[3][nb][8] = g[2];
+                    // d/dt
+                    adj[4][nb][0] = g[3];
+                    adj[4][nb][1] = g[4];
+                    adj[4][nb][2] = g[5];
+                    adj[4][nb][3] = -a.rho * g[0];
+                    adj[4][nb][4] = -a.rho * g[1];
+                    adj[4][nb][5] = -a.rho * g[2];
                 } else if constexpr (HEAD == HEAD_PLATE) {
                     // composite F = P + D*N (PLATE:383-387) with product-rule derivatives, then net_f_sig PLATE:404-439
                     // outputs (u,v,s11,s22,s12); streams (value, x, y, t, tt); aux = [D|P][stream][field][n]
@@ -761,10 +868,10 @@ struct Chain {
                             if (q == 0) lsum[o] += vm * w * d * d;
                             adj[s][nb][o] = 2.0f * w * d * vm;
                         }
-                } else if constexpr (HEAD == HEAD_DATA) {
+                } else if constexpr (HEAD == HEAD_DATA || HEAD == HEAD_DATA3D) {
                     // loss_IC / loss_SRC / loss_NB / loss_FIX (INF:111-118, CONF:145-146): sum_o w_o (Y_o - target_o)^2
 #pragma unroll
-                    for (int o = 0; o < 8; ++o) {
+                    for (int o = 0; o < NOG; ++o) {
                         float d = 0.0f;
                         if (o < a.net.nout) d = Y[0][nb][o] - (a.targets ? a.targets[(long)o * a.n + pidx[nb]] : 0.0f);
                         if (q == 0) lsum[o] += vm * d * d;
@@ -776,13 +883,13 @@ struct Chain {
 #pragma unroll
                         for (int s = 0; s < NS; ++s)
 #pragma unroll
-                            for (int o = 0; o < 8; ++o)
+                            for (int o = 0; o < NOG; ++o)
                                 if (o < a.net.nout) a.fields_out[((long)s * a.net.nout + o) * a.n + pidx[nb]] = Y[s][nb][o];
                     }
                 }
             }
-            if constexpr (HEAD != HEAD_FIELDS) {
-                // ---- Z_nl: adjoint of the outputs, lane keeps outputs 4(q&1)+r for q<2, zeros otherwise
+            if constexpr (!FWD_ONLY) {
+                // ---- Z_nl: adjoint of the outputs, lane keeps outputs 4q+r (zeros beyond the gathered ones)
                 u32x4 ZL[NS][NB][1][NP];
                 {
                     float vals[NS][NB][4];
@@ -791,7 +898,12 @@ struct Chain {
 #pragma unroll
                         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) vals[s][nb][r] = q < 2 ? ((q & 1) ? adj[s][nb][4 + r] : adj[s][nb][r]) : 0.0f;
+                            for (int r = 0; r < 4; ++r) {
+                                float v = 0.0f;
+#pragma unroll
+                                for (int qq = 0; qq < NOG / 4; ++qq) v = q == qq ? adj[s][nb][4 * qq + r] : v;
+                                vals[s][nb][r] = v;
+                            }
 #pragma unroll
                     for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -819,16 +931,16 @@ struct Chain {
                 }
             }
         }
-        if constexpr (HEAD != HEAD_FIELDS) {
+        if constexpr (!FWD_ONLY) {
             // per-wave partial sums of squares (only q == 0 lanes hold data): reduce over the 16 points
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < LT; ++i) {
                 float v = lsum[i];
                 v += __shfl_xor(v, 1);
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 4);
                 v += __shfl_xor(v, 8);
-                if (lane == 0) a.loss_part[gwave * 8 + i] = v;
+                if (lane == 0) a.loss_part[gwave * LT + i] = v;
             }
         }
     }
@@ -859,7 +971,7 @@ __global__ __launch_bounds__(64 * WgradCfg<WIDTH>::NW) void wgrad_kernel(const W
     const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4, wave = threadIdx.x >> 6;
     const int IB = l == 0 ? 1 : WB, OB = l == nl ? 1 : WB;
     const int rowsS = l == 0 ? 16 : WIDTH, rowsZ = l == nl ? 16 : WIDTH;
-    const int real_in = l == 0 ? 3 : a.net.h, real_out = l == nl ? a.net.nout : a.net.h;
+    const int real_in = l == 0 ? a.net.din : a.net.h, real_out = l == nl ? a.net.nout : a.net.h;
 
     f32x4 acc[IBW][OBN], accc[IBW][OBN], bacc[OBN], baccc[OBN];
 #pragma unroll
@@ -1028,21 +1140,24 @@ __global__ __launch_bounds__(256) void reduce_grad_loss_kernel(const float* part
     }
 }
 
-// loss_terms[i] (+)= sum over waves of loss_part[w][i]   (one block of 256 threads: 32 lanes per term, nterms <= 8)
+// loss_terms[i] (+)= sum over waves of loss_part[w][i]   (one block of 256 threads: 32 lanes per term and pass, `slots` partial
+// slots per wave: 8, or LOSS_SLOTS_3D for the 3-D heads; nterms <= slots)
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void reduce_loss_kernel(const float* loss_part, long nwaves, int nterms, float* loss_terms,
-                                                          int accumulate) {
-    const int term = threadIdx.x >> 5, sub = threadIdx.x & 31;
-    double s = 0.0;
-    if (term < nterms)
-        for (long w = sub; w < nwaves; w += 32) s += (double)loss_part[w * 8 + term];
-    float v = (float)s;
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 16);
-    if (sub == 0 && term < nterms) loss_terms[term] = (accumulate ? loss_terms[term] : 0.0f) + v;
+                                                          int accumulate, int slots) {
+    const int sub = threadIdx.x & 31;
+    for (int term = threadIdx.x >> 5; term < slots; term += 8) {
+        double s = 0.0;
+        if (term < nterms)
+            for (long w = sub; w < nwaves; w += 32) s += (double)loss_part[w * slots + term];
+        float v = (float)s;
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        if (sub == 0 && term < nterms) loss_terms[term] = (accumulate ? loss_terms[term] : 0.0f) + v;
+    }
 }
 
 // tf.train.AdamOptimizer (TF1 rule; INF:131-133): epsilon added to the UNCORRECTED sqrt(v); the bias

@@ -25,8 +25,9 @@ struct Call {
     const float* x;
     const float* y;
     const float* t;
+    const float* z;            // 4-input heads only (input order x, y, z, t)
     long n;
-    float sx[3], ox[3];
+    float sx[4], ox[4];        // input map; 4-input heads: index 2 = z, 3 = t
     void* ws;
     size_t ws_bytes;
     hipStream_t stream;
@@ -35,7 +36,7 @@ struct Call {
     int accumulate;
     // wave residual head
     float c1, c2, G, rho;
-    float tw[8];
+    float tw[16];
     // data head
     const float* targets;
     int nsets;                 // > 0: pinn_data_loss_grad_multi -- the value-only sets of this call (else the single set x, y, t, n, targets, tw)
@@ -63,9 +64,23 @@ struct Impl {
     int (*traction_loss_grad)(const Call&);
     int (*stream_loss_grad)(const Call&);
     int (*streams)(const Call&);
+    // 4-input family (3-D Navier-Cauchy extension: value + 4 first-order streams, 12 outputs), split-precision variants only
+    int (*nc3d_loss_grad)(const Call&);
+    int (*nc3d_data_loss_grad)(const Call&);
+    int (*nc3d_fields)(const Call&);
 };
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// pair of HIP events of the optional per-kernel timing, released on every exit path
+struct EventPair {
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool on;
+    explicit EventPair(bool enable) : on(enable) { if (on) { hipEventCreate(&ev[0]); hipEventCreate(&ev[1]); } }
+    ~EventPair() { if (on) { hipEventDestroy(ev[0]); hipEventDestroy(ev[1]); } }
+    EventPair(const EventPair&) = delete;
+    EventPair& operator=(const EventPair&) = delete;
+};
 
 template <class Op, int SPLIT, int WIDTH>
 struct Host {
@@ -94,7 +109,7 @@ struct Host {
         typedef PanelGeom<WIDTH, NB, NS, NP> PG;
         size_t o = 0;
         p.w0p = o;
-        o = align_up(o + (size_t)WIDTH * 4 * sizeof(float), 256);
+        o = align_up(o + (size_t)WIDTH * 8 * sizeof(float), 256);
         p.bias_mid = o;
         o = align_up(o + (size_t)(net.nl > 1 ? net.nl - 1 : 1) * WIDTH * sizeof(float), 256);
         p.bias_last = o;
@@ -104,7 +119,7 @@ struct Host {
         p.frags_fused = o;      // second copy in the fused kernel's format (narrow nets only)
         if (WIDTH <= 64) o = align_up(o + (size_t)FI::total(net.nl) * FUSED_PARTS * 64 * sizeof(u32x4), 256);
         p.loss_part = o;
-        o = align_up(o + (size_t)MAX_BLOCKS * 4 * 8 * sizeof(float), 256);
+        o = align_up(o + (size_t)MAX_BLOCKS * 4 * LOSS_SLOTS_3D * sizeof(float), 256);
         p.partial = o;
         o = align_up(o + (size_t)(NCHUNK > FUSED_GRID ? NCHUNK : FUSED_GRID) * net.nparams * sizeof(float), 256);
         p.wg_acc = o;           // fused kernel: weight-gradient accumulator blocks kept in memory (<= 2 layers x 4 blocks x 1 KB per wave)
@@ -180,8 +195,9 @@ struct Host {
         a.x = c.x;
         a.y = c.y;
         a.t = c.t;
+        a.z = c.z;
         a.n = c.n;
-        for (int k = 0; k < 3; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
+        for (int k = 0; k < 4; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
         a.c1 = c.c1;
         a.c2 = c.c2;
         a.G = c.G;
@@ -213,10 +229,10 @@ struct Host {
         int rc = make_plan<NS>(c, p, true);
         if (rc) return rc;
         // optional HIP-event timing of each kernel class (bench.py's roofline leg)
-        hipEvent_t ev[2] = {nullptr, nullptr};
         float acc_ms[4] = {0.f, 0.f, 0.f, 0.f};
         const bool prof = c.prof_ms != nullptr;
-        if (prof) { hipEventCreate(&ev[0]); hipEventCreate(&ev[1]); }
+        EventPair evp(prof);
+        hipEvent_t (&ev)[2] = evp.ev;
         auto tic = [&]() { if (prof) hipEventRecord(ev[0], c.stream); };
         auto toc = [&](int slot) {
             if (!prof) return;
@@ -231,11 +247,11 @@ struct Host {
         if (rc) return rc;
         toc(0);
         float twmax = 0.0f;
-        for (int i = 0; i < 8; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
+        for (int i = 0; i < 16; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
         if (HEAD != HEAD_STREAMS) twmax *= (float)(1u << c.adj_shift);      // the weights are only ever used normalised: folds the shift in
         ChainArgs a;
         fill_common(c, p, a);
-        for (int i = 0; i < 8; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
+        for (int i = 0; i < 16; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
         if (HEAD == HEAD_STREAMS) {
             twmax = 0.0f;
             for (int i = 0; i < 5; ++i)
@@ -265,7 +281,7 @@ struct Host {
             toc(1);
             tic();
             hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)blocks * 4, nterms,
-                               c.loss_out, pass > 0 ? 1 : 0);
+                               c.loss_out, pass > 0 ? 1 : 0, head_is_3d(HEAD) ? LOSS_SLOTS_3D : 8);
             if ((rc = (int)hipGetLastError())) return rc;
             toc(3);
             w.ntiles = nt;
@@ -280,11 +296,8 @@ struct Host {
                            (int)NCHUNK, c.net.nparams, twmax, c.grad_out, c.accumulate);
         rc = (int)hipGetLastError();
         toc(3);
-        if (prof) {
+        if (prof)
             for (int i = 0; i < 4; ++i) c.prof_ms[i] = acc_ms[i];
-            hipEventDestroy(ev[0]);
-            hipEventDestroy(ev[1]);
-        }
         return rc;
     }
 
@@ -367,8 +380,9 @@ struct Host {
             a.wg_acc = reinterpret_cast<u32x4*>(b + p.wg_acc);
             static_assert(F::WG_ACC_BYTES <= 32 * 1024, "accumulator area of the plan");
             a.dbg = c.dbg_stamps;
-            hipEvent_t ev[2] = {nullptr, nullptr};
-            if (c.prof_ms) { hipEventCreate(&ev[0]); hipEventCreate(&ev[1]); hipEventRecord(ev[0], c.stream); }
+            EventPair evp(c.prof_ms != nullptr);
+            hipEvent_t (&ev)[2] = evp.ev;
+            if (c.prof_ms) hipEventRecord(ev[0], c.stream);
             hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL, NS>), dim3(grid), dim3(512), 0, c.stream, a);
             if ((rc = (int)hipGetLastError())) return rc;
             if (c.prof_ms) {
@@ -376,8 +390,6 @@ struct Host {
                 hipEventSynchronize(ev[1]);
                 c.prof_ms[0] = c.prof_ms[2] = c.prof_ms[3] = 0.f;
                 hipEventElapsedTime(&c.prof_ms[1], ev[0], ev[1]);
-                hipEventDestroy(ev[0]);
-                hipEventDestroy(ev[1]);
             }
             // loss partials are [wave][set][8] with set = FUSED_MAX_SETS slots for NS = 1 and one slot for NS = 4
             constexpr int SLOTS = NS == 1 ? FUSED_MAX_SETS : 1;
@@ -450,7 +462,7 @@ struct Host {
         return 0;
     }
 
-    template <int NS>
+    template <int NS, int HEAD>
     static int fields_ns(const Call& c) {
         Plan p;
         int rc = make_plan<NS>(c, p, false);
@@ -459,13 +471,13 @@ struct Host {
         if (rc) return rc;
         ChainArgs a;
         fill_common(c, p, a);
-        for (int i = 0; i < 8; ++i) a.tw[i] = 0.0f;
+        for (int i = 0; i < 16; ++i) a.tw[i] = 0.0f;
         a.tile0 = 0;
         a.ntiles = p.ntiles;
-        hipLaunchKernelGGL((chain_kernel<Op, SPLIT, WIDTH, nb<NS>(), NS, HEAD_FIELDS>), dim3(chain_blocks(p.ntiles)), dim3(256), 0, c.stream, a);
+        hipLaunchKernelGGL((chain_kernel<Op, SPLIT, WIDTH, nb<NS>(), NS, HEAD>), dim3(chain_blocks(p.ntiles)), dim3(256), 0, c.stream, a);
         return (int)hipGetLastError();
     }
-    static int fields(const Call& c) { return fields_ns<4>(c); }
+    static int fields(const Call& c) { return fields_ns<4, HEAD_FIELDS>(c); }
 
     // 5-stream family (plate): split-precision variants only
     static int plate_loss_grad(const Call& c) {
@@ -481,13 +493,27 @@ struct Host {
         return PINN_ERR_PRECISION;
     }
     static int streams(const Call& c) {
-        if constexpr (SPLIT == 3) return fields_ns<5>(c);
+        if constexpr (SPLIT == 3) return fields_ns<5, HEAD_FIELDS>(c);
+        return PINN_ERR_PRECISION;
+    }
+    // 4-input family (two-kernel path; the fused kernel covers the reference's 3-input nets only)
+    static int nc3d_loss_grad(const Call& c) {
+        if constexpr (SPLIT == 3) return loss_grad<5, HEAD_NC3D>(c, 12);
+        return PINN_ERR_PRECISION;
+    }
+    static int nc3d_data_loss_grad(const Call& c) {
+        if constexpr (SPLIT == 3) return loss_grad<1, HEAD_DATA3D>(c, c.net.nout);
+        return PINN_ERR_PRECISION;
+    }
+    static int nc3d_fields(const Call& c) {
+        if constexpr (SPLIT == 3) return fields_ns<5, HEAD_FIELDS3D>(c);
         return PINN_ERR_PRECISION;
     }
 
     static const Impl* impl() {
         static const Impl I = {&wave_loss_grad, &data_loss_grad, &fields, &ws_bytes,
-                               &plate_loss_grad, &traction_loss_grad, &stream_loss_grad, &streams};
+                               &plate_loss_grad, &traction_loss_grad, &stream_loss_grad, &streams,
+                               &nc3d_loss_grad, &nc3d_data_loss_grad, &nc3d_fields};
         return &I;
     }
 };

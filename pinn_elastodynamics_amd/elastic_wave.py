@@ -195,8 +195,13 @@ class DeepHPM:
             return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.device)
 
         Collo = np.asarray(Collo, dtype=np.float64)
-        self.x_c, self.y_c, self.t_c = Collo[:, 0:1], Collo[:, 1:2], Collo[:, 2:3]
-        self._collo = tuple(dev(_col(Collo[:, k])) for k in range(3))
+        self.x_c, self.y_c, self.t_c = Collo[:, 0:1], Collo[:, 1:2], Collo[:, 2:3]      # host copies, as the reference keeps them (INF:40-42)
+        # Device residency: one process holds the whole set; a data-parallel rank holds only ITS rows of each collocation block
+        # (uploaded when a block is first used, see _rows), so device memory and upload time scale with 1/world.
+        self._n_collo = Collo.shape[0]
+        self._collo_host = tuple(np.ascontiguousarray(_col(Collo[:, k]), dtype=np.float32) for k in range(3))
+        self._collo_full = tuple(dev(a) for a in self._collo_host) if self.world == 1 else None
+        self._collo_cache = {}
         self._sides = {}      # name -> (x, y, t, targets[7,n] or None, out columns)
 
         def side(name, A, cols, target_cols=None):
@@ -303,6 +308,10 @@ class DeepHPM:
         f_v = Y[5] + X[6] - rho * T[3]
         return torch.stack([f_u, f_v, T[0] - V[2], T[1] - V[3], V[4] - sp11, V[5] - sp22, V[6] - sp12])
 
+    # BASELINE.json's north_star calls these net_uvp / net_f; the reference's names are net_uv / net_f_sig
+    net_uvp = net_uv
+    net_f = net_f_sig
+
     def net_surf_var(self, x, y, t, nx, ny):         # INF:267-276
         u, v, ut, vt, s11, s22, s12 = self.net_uv(x, y, t)
         return s11 * nx + s12 * ny, s12 * nx + s22 * ny
@@ -320,6 +329,23 @@ class DeepHPM:
         n = hi - lo
         return lo + n * self.rank // self.world, lo + n * (self.rank + 1) // self.world
 
+    def _rows(self, lo, hi):
+        """Device tensors (x, y, t) of THIS rank's rows of the collocation block [lo, hi)."""
+        s, e = self._shard(lo, hi)
+        if self._collo_full is not None:
+            return tuple(a[s:e] for a in self._collo_full)
+        key = (lo, hi)
+        if key not in self._collo_cache:
+            if len(self._collo_cache) >= 64:          # a new batching: drop the previous one's shards
+                self._collo_cache.clear()
+            self._collo_cache[key] = tuple(torch.from_numpy(h[s:e]).to(self.device) for h in self._collo_host)
+        return self._collo_cache[key]
+
+    @property
+    def _collo(self):
+        """this rank's rows of the whole collocation set"""
+        return self._rows(0, self._n_collo)
+
     def _loss_and_grad(self, idx_start, idx_end, sums_out=None):
         """Fills self._buf = [grad (P) | 8 floats per slot] with this rank's partial sums, then
         all-reduces.  Returns nothing; everything stays on the device.  Single process only: ``sums_out`` (a view of
@@ -336,7 +362,7 @@ class DeepHPM:
         tw = [lay["f_uv"] / n_blk] * 4 + [lay["f_s"] / n_blk] * 3
         wrote = False
         if e > s:
-            x, y, t = (a[s:e] for a in self._collo)
+            x, y, t = self._rows(idx_start, idx_end)
             eng.wave_loss_grad(self.theta, x, y, t, self.lb, self.ub, self.normalize, tw, self.E, self.mu, self.rho, True,
                                grad_out=grad, accumulate=False, loss_out=sums[0:8])
             wrote = True
@@ -377,15 +403,17 @@ class DeepHPM:
     # ------------------------------------------------------------------------------------------
     # training drivers
     # ------------------------------------------------------------------------------------------
-    def train(self, iter, learning_rate, batch_num):
+    def train(self, iter, learning_rate, batch_num, record="pre"):
         """Adam loop of INF:282-319: contiguous collocation blocks, ``iter`` steps per block, all
         side sets fed whole to every block.  Returns the per-step lists
-        (loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss).  Deviation: each recorded value is the loss
-        the step's gradient was taken at (the reference re-evaluates every term after the update
-        with four to six extra sess.run calls per step, INF:308-317)."""
+        (loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss).  ``record="pre"`` (default): each recorded value is the loss
+        the step's gradient was taken at -- free.  ``record="post"``: the reference's own bookkeeping, every term re-evaluated
+        AFTER the update (its four to six extra sess.run calls per step, INF:308-317) -- one more loss+gradient evaluation per step."""
+        if record not in ("pre", "post"):
+            raise ValueError("record must be 'pre' or 'post'")
         loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss = [], [], [], [], []
         P = self.n_params
-        col_num = self._collo[0].numel()
+        col_num = self._n_collo
         for i in range(batch_num):
             idx_start = int(i * col_num / batch_num)
             idx_end = int((i + 1) * col_num / batch_num)
@@ -405,6 +433,9 @@ class DeepHPM:
                     rec[it].copy_(self._buf[P:])
                 self.adam_t += 1
                 self.engine.adam_step(self.theta, self.adam_m, self.adam_v, self._buf[:P], learning_rate, self.adam_t)
+                if record == "post":                 # INF:308-317: the terms at the updated weights
+                    self._loss_and_grad(idx_start, idx_end)
+                    rec[it].copy_(self._buf[P:])
                 if self.verbose and it % 10 == 0 and self.rank == 0:
                     tm = self._terms_from_sums(rec[it].detach().cpu().numpy().reshape(len(_SLOTS), 8), idx_end - idx_start)
                     print('It: %d, Loss: %.3e' % (it, tm["loss"]))
@@ -431,7 +462,7 @@ class DeepHPM:
         opts = dict(BFGS_OPTIONS[self.case])
         if options:
             opts.update(options)
-        col_num = self._collo[0].numel()
+        col_num = self._n_collo
         result = None
         for i in range(batch_num):
             idx_start = int(i * col_num / batch_num)
@@ -475,7 +506,7 @@ class DeepHPM:
 
     def getloss(self):
         """INF:361-376: (loss, loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss_NB) on the full sets."""
-        n = self._collo[0].numel()
+        n = self._n_collo
         self._loss_and_grad(0, n)
         host = self._buf[self.n_params:].detach().cpu().numpy().reshape(len(_SLOTS), 8)
         tm = self._terms_from_sums(host, n)
@@ -494,10 +525,41 @@ class DeepHPM:
 
 class DeepHPMConfined(DeepHPM):
     """Signature of the confined-domain script (CONF:23): its distance/particular networks are
-    created but never enter the graph there (CONF:282-294 ignores them), so they are accepted and
-    ignored here too."""
+    created but never enter the graph there (CONF:282-294 ignores them), so they are accepted,
+    initialised (so that save_NN can write them, CONF:197-217) and otherwise ignored here too."""
 
     def __init__(self, Collo, SRC, IC, FIXED, DIST, uv_layers, dist_layers, part_layers, lb, ub,
                  uvDir='', partDir='', distDir='', **kw):
         super().__init__(Collo, SRC, IC, None, uv_layers, lb, ub, ExistModel=1 if uvDir else 0, modelDir=uvDir,
                          case="confined", FIX=FIXED, **kw)
+        self.DIST = DIST
+        self.dist_layers = None if dist_layers is None else [int(v) for v in dist_layers]
+        self.part_layers = None if part_layers is None else [int(v) for v in part_layers]
+        seed = kw.get("seed", 1111)
+        self._aux_nets = {}
+        for name, layers, path, off in (("DIST", self.dist_layers, distDir, 1), ("PART", self.part_layers, partDir, 2)):
+            if layers is not None:
+                self._aux_nets[name] = self.load_NN(path, layers) if path else xavier_init(layers, np.random.default_rng(seed + off))
+
+    def train(self, iter, learning_rate, batch_num, record="pre"):
+        """CONF:373-408 returns three lists: (loss_f_uv, loss_f_s, loss)."""
+        loss_f_uv, loss_f_s, _, _, loss = super().train(iter, learning_rate, batch_num, record)
+        return loss_f_uv, loss_f_s, loss
+
+    def save_NN(self, fileDir, TYPE=''):
+        """CONF:197-217: TYPE selects the net ('UV', 'DIST', 'PART'); anything else writes nothing."""
+        if TYPE in ('UV', ''):
+            return super().save_NN(fileDir)
+        if TYPE in ('DIST', 'PART') and TYPE in self._aux_nets:
+            W, b = self._aux_nets[TYPE]
+            with open(fileDir, 'wb') as f:
+                pickle.dump([W, b], f)
+            if self.verbose:
+                print("Save %s NN parameters successfully..." % TYPE)
+
+    def getloss(self):
+        """CONF:453-472: (loss, loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss_FIX) on the full sets."""
+        n = self._n_collo
+        self._loss_and_grad(0, n)
+        tm = self._terms_from_sums(self._buf[self.n_params:].detach().cpu().numpy().reshape(len(_SLOTS), 8), n)
+        return tm["loss"], tm["loss_f_uv"], tm["loss_f_s"], tm["loss_IC"], tm["loss_SRC"], tm["loss_FIX"]

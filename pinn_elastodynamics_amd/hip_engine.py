@@ -24,7 +24,8 @@ class HipEngine:
     """
 
     def __init__(self, layers: Sequence[int], precision: str = "f16x3", device: Optional[torch.device] = None,
-                 max_points: int = 1 << 18, lib_path: str = DEFAULT_LIB, workspace_bytes: Optional[int] = None):
+                 max_points: int = 1 << 18, lib_path: str = DEFAULT_LIB, workspace_bytes: Optional[int] = None,
+                 workspace_cap_bytes: int = 8 << 30):
         if not torch.cuda.is_available():
             raise PinnLibError("HipEngine needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = PinnLib(lib_path)
@@ -38,7 +39,9 @@ class HipEngine:
             raise PinnLibError(f"hidden width {self.layers[1]} is not supported by the compiled kernels")
         want = workspace_bytes if workspace_bytes is not None else self.lib.workspace_bytes(self.layers, max_points, precision)
         if workspace_bytes is None:
-            want = min(want, 8 << 30)      # larger point sets are walked in several passes; 8 GiB already amortises the launches
+            # larger point sets are walked in several passes; the default cap of 8 GiB already amortises the launches
+            # (``workspace_cap_bytes`` raises or lowers it, ``workspace_bytes`` fixes the size outright)
+            want = min(want, int(workspace_cap_bytes))
         want = max(want, self.lib.min_workspace_bytes(self.layers, precision))
         if want == 0:
             raise PinnLibError(f"no kernel variant for layers={self.layers} precision={precision}")
@@ -192,6 +195,56 @@ class HipEngine:
                                   weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate, self.precision, self._ws_ptr,
                                   self.ws_bytes, self._stream())
         return loss_out[:nout], grad_out
+
+    # ---- 3-D Navier-Cauchy extension (layers [4, H, ..., H, 12]; inputs x, y, z, t) -------------------------------------
+    def nc3d_loss_grad(self, params, x, y, z, t, lb, ub, normalize, term_weights, E=2.5, mu=0.25, rho=1.0,
+                       grad_out=None, accumulate=False, loss_out=None, packed=False):
+        """Returns (sumsq[12], grad): residuals (f_u,f_v,f_w,f_ut,f_vt,f_wt,f_s11,f_s22,f_s33,f_s12,f_s13,f_s23), see include/pinn_hip.h."""
+        n = x.numel()
+        for v in (x, y, z, t):
+            self._chk(v, n)
+        self._chk(params, self.n_params)
+        if grad_out is None:
+            grad_out = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+            accumulate = False
+        if loss_out is None:
+            loss_out = torch.empty(16, dtype=torch.float32, device=self.device)
+        self.lib.nc3d_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), z.data_ptr(), t.data_ptr(), n, lb, ub, normalize,
+                                E, mu, rho, term_weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate, self._mode(packed),
+                                self._ws_ptr, self.ws_bytes, self._stream())
+        return loss_out[:12], grad_out
+
+    def nc3d_data_loss_grad(self, params, x, y, z, t, lb, ub, normalize, targets, out_weights,
+                            grad_out=None, accumulate=False, loss_out=None, packed=False):
+        """Value-only terms of the 4-input net.  targets: [n_out, n] device tensor or None.  Returns (sumsq[n_out], grad)."""
+        n, nout = x.numel(), self.layers[-1]
+        for v in (x, y, z, t):
+            self._chk(v, n)
+        self._chk(params, self.n_params)
+        tptr = 0
+        if targets is not None:
+            self._chk(targets, nout * n)
+            tptr = targets.data_ptr()
+        if grad_out is None:
+            grad_out = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+            accumulate = False
+        if loss_out is None:
+            loss_out = torch.empty(16, dtype=torch.float32, device=self.device)
+        self.lib.nc3d_data_loss_grad(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), z.data_ptr(), t.data_ptr(), n, lb, ub,
+                                     normalize, tptr, out_weights, loss_out.data_ptr(), grad_out.data_ptr(), accumulate,
+                                     self._mode(packed), self._ws_ptr, self.ws_bytes, self._stream())
+        return loss_out[:nout], grad_out
+
+    def nc3d_fields(self, params, x, y, z, t, lb, ub, normalize):
+        """Returns [5, n_out, n]: the outputs and their derivatives w.r.t. x, y, z, t."""
+        n, nout = x.numel(), self.layers[-1]
+        for v in (x, y, z, t):
+            self._chk(v, n)
+        self._chk(params, self.n_params)
+        out = torch.empty((5, nout, n), dtype=torch.float32, device=self.device)
+        self.lib.nc3d_fields(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), z.data_ptr(), t.data_ptr(), n, lb, ub, normalize,
+                             out.data_ptr(), self.precision, self._ws_ptr, self.ws_bytes, self._stream())
+        return out
 
     def adam_step(self, params, m, v, grad, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
         for a in (params, m, v, grad):

@@ -87,6 +87,31 @@ class OracleEngine:
                                     None if targets is None else self._np(targets), w)
         return self._put(g, ((w / np.abs(w).max()) * ss).sum(0), self.layers[-1], grad_out, accumulate, loss_out)
 
+    # ---- 3-D Navier-Cauchy extension -----------------------------------------------------------------------
+    def nc3d_loss_grad(self, params, x, y, z, t, lb, ub, normalize, term_weights, E=2.5, mu=0.25, rho=1.0,
+                       grad_out=None, accumulate=False, loss_out=None, packed=False):
+        from oracle import nc3d_oracle as n3
+        ss, g, _ = n3.nc3d_loss_grad(self._np(params), self.layers, self._np(x), self._np(y), self._np(z), self._np(t), lb, ub, normalize,
+                                     E, mu, rho, np.asarray(term_weights, dtype=np.float64))
+        if loss_out is None:
+            loss_out = torch.zeros(16, dtype=torch.float32)
+        return self._put(g, ss, 12, grad_out, accumulate, loss_out)
+
+    def nc3d_data_loss_grad(self, params, x, y, z, t, lb, ub, normalize, targets, out_weights, grad_out=None, accumulate=False,
+                            loss_out=None, packed=False):
+        from oracle import nc3d_oracle as n3
+        tg = None if targets is None else self._np(targets).T
+        ss, g, _ = n3.nc3d_data_loss_grad(self._np(params), self.layers, self._np(x), self._np(y), self._np(z), self._np(t), lb, ub,
+                                          normalize, tg, np.asarray(out_weights, dtype=np.float64)[:12])
+        if loss_out is None:
+            loss_out = torch.zeros(16, dtype=torch.float32)
+        return self._put(g, ss, 12, grad_out, accumulate, loss_out)
+
+    def nc3d_fields(self, params, x, y, z, t, lb, ub, normalize):
+        from oracle import nc3d_oracle as n3
+        out = n3.nc3d_fields(self._np(params), self.layers, self._np(x), self._np(y), self._np(z), self._np(t), lb, ub, normalize)
+        return torch.from_numpy(np.stack([out["Y"].T] + [d.T for d in out["dY"]]).astype(np.float32))
+
     def data_loss_grad_multi(self, params, sets, lb, ub, normalize, grad_out, accumulate=False, packed=False):
         for x, y, t, tg, ow, lo in sets:
             self.data_loss_grad(params, x, y, t, lb, ub, normalize, tg, ow, grad_out=grad_out, accumulate=accumulate, loss_out=lo)

@@ -309,3 +309,69 @@ def test_data_loss_grad_multi_emulated(emu, layers, fused):
             assert np.all(keep[k][4][:7] == 0)
     assert rel(grad, g_ref) < 2e-4
     emu.set_fused(1)
+
+
+# ---- 3-D Navier-Cauchy extension (4 inputs, 12 outputs, value + 4 first-order streams; oracle/nc3d_oracle.py) ----
+@pytest.mark.parametrize("layers,n,normalize", [([4] + 2 * [32] + [12], 45, True), ([4] + 3 * [48] + [12], 21, False), ([4] + 2 * [128] + [12], 17, True)])
+def test_nc3d_entry_points_emulated(emu, layers, n, normalize):
+    """pinn_nc3d_loss_grad / pinn_nc3d_fields / pinn_nc3d_data_loss_grad on the emulator vs the float64 oracle"""
+    from oracle import nc3d_oracle as n3
+    lb, ub = [0.0, 0.0, -20.0, 0.0], [30.0, 30.0, 0.0, 15.0]
+    rng = np.random.default_rng(21)
+    Ws, bs = po.xavier_init(layers, rng)
+    bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
+    X = n3.halfspace_points(n, lb, ub, rng) if normalize else rng.uniform(-1.0, 1.0, (n, 4))
+    flat = po.pack_params(Ws, bs)
+    tw = (0.5 + rng.random(12)) / n
+    ss, g, _ = n3.nc3d_loss_grad(flat, layers, *X.T, lb, ub, normalize, term_weights=tw)
+    p32 = flat.astype(np.float32)
+    cols = [X[:, k].astype(np.float32).copy() for k in range(4)]
+    ptr = [v.ctypes.data for v in cols]
+    wsb = emu.workspace_bytes(layers, n, "f16x3")
+    assert wsb > 0
+    ws = aligned(wsb)
+    loss = np.full(16, np.nan, np.float32)
+    grad = np.full(p32.size, np.nan, np.float32)
+    emu.nc3d_loss_grad(p32.ctypes.data, layers, *ptr, n, lb, ub, normalize, 2.5, 0.25, 1.0, tw, loss.ctypes.data, grad.ctypes.data, False,
+                       "f16x3", ws.ctypes.data, wsb)
+    assert rel(loss[:12], ss) < 2e-6 and rel(grad, g) < 2e-6, (rel(loss[:12], ss), rel(grad, g))
+    # forward streams
+    ref = n3.nc3d_fields(flat, layers, *X.T, lb, ub, normalize)
+    out = np.full((5, 12, n), np.nan, np.float32)
+    emu.nc3d_fields(p32.ctypes.data, layers, *ptr, n, lb, ub, normalize, out.ctypes.data, "f16x3", ws.ctypes.data, wsb)
+    assert rel(out[0].T, ref["Y"]) < 2e-6
+    for k in range(4):
+        assert rel(out[1 + k].T, ref["dY"][k]) < 2e-6
+    # value-only side term (e.g. the traction-free surface: s33, s13, s23 -> 0; initial state u, v, w, ut, vt, wt -> targets)
+    tgt = rng.standard_normal((n, 12))
+    ow = np.array([1, 1, 1, 0.5, 0.5, 0.5, 0, 0, 2, 0, 2, 2.0]) / n
+    ss_d, g_d, _ = n3.nc3d_data_loss_grad(flat, layers, *X.T, lb, ub, normalize, tgt, ow)
+    tg = np.ascontiguousarray(tgt.T.astype(np.float32))
+    emu.nc3d_data_loss_grad(p32.ctypes.data, layers, *ptr, n, lb, ub, normalize, tg.ctypes.data, ow, loss.ctypes.data, grad.ctypes.data, False,
+                            "f16x3", ws.ctypes.data, wsb)
+    assert rel(loss[:12], ss_d) < 2e-6 and rel(grad, g_d) < 2e-6
+    # accumulate + empty batch
+    emu.nc3d_loss_grad(p32.ctypes.data, layers, *ptr, n, lb, ub, normalize, 2.5, 0.25, 1.0, tw, loss.ctypes.data, grad.ctypes.data, True,
+                       "f16x3", ws.ctypes.data, wsb)
+    assert rel(grad, g + g_d) < 2e-6
+    keep = grad.copy()
+    emu.nc3d_loss_grad(p32.ctypes.data, layers, 0, 0, 0, 0, 0, lb, ub, normalize, 2.5, 0.25, 1.0, tw, loss.ctypes.data, grad.ctypes.data, True,
+                       "f16x3", ws.ctypes.data, wsb)
+    assert np.array_equal(grad, keep) and np.all(loss[:12] == 0)
+
+
+def test_nc3d_argument_checks_emulated(emu):
+    layers = [4, 32, 32, 12]
+    assert emu.workspace_bytes([4, 32, 32, 17], 10, "f16x3") == 0          # at most 16 outputs
+    assert emu.workspace_bytes([5, 32, 32, 12], 10, "f16x3") == 0
+    assert emu.workspace_bytes(layers, 10, "f16x3+packed") == emu.workspace_bytes(layers, 10, "f16x3")     # flag bits are ignored when sizing
+    p = np.zeros(po.param_count(layers), np.float32)
+    ws = aligned(emu.workspace_bytes(layers, 16, "f16x3"))
+    z = np.zeros(16, np.float32)
+    from pinn_elastodynamics_amd.capi import PinnLibError
+    with pytest.raises(PinnLibError):        # the 3-input entry refuses a 4-input net
+        emu.wave2d_loss_grad(p.ctypes.data, layers, z.ctypes.data, z.ctypes.data, z.ctypes.data, 16, LB, UB, True, 2.5, 0.25, 1.0, True,
+                             np.ones(7), z.ctypes.data, p.ctypes.data, False, "f16x3", ws.ctypes.data, ws.size)
+    with pytest.raises(PinnLibError):        # unsplit modes have no 5-stream kernels
+        emu.nc3d_loss_grad(p.ctypes.data, layers, *[z.ctypes.data] * 4, 16, [0] * 4, [1] * 4, True, 2.5, 0.25, 1.0, np.ones(12), z.ctypes.data,
+                           p.ctypes.data, False, "bf16", ws.ctypes.data, ws.size)

@@ -1,0 +1,42 @@
+"""-m gpu: the multi-process data-parallel path with the REAL HipEngine.  Only one GPU is available to the tests, so both ranks
+share cuda:0 and the collective runs over gloo; everything else is the product path (sharded device-resident sets, HIP kernels,
+one all-reduce of [gradient | loss sums], on-device TF1 Adam)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LAYERS = [3] + 8 * [64] + [7]
+LB, UB = [0.0, 0.0, 0.0], [30.0, 30.0, 20.0]
+
+
+def sets(n=30001):
+    from oracle import pinn_oracle as po
+    rng = np.random.default_rng(8)
+    return po.collocation_points(n, LB, UB, rng), po.ricker_source_set(n_pt=40, n_time=31), po.ic_grid(num=41), np.zeros((0, 3))
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_match_a_single_process(tmp_path):
+    import torch
+    from pinn_elastodynamics_amd.elastic_wave import DeepHPM
+    from pinn_elastodynamics_amd.hip_engine import HipEngine
+    out = str(tmp_path / "dp_gpu.npz")
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(ROOT, "tests", "_dp_worker_gpu.py"), out], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = np.load(out)
+    Collo, SRC, IC, UP = sets()
+    eng = HipEngine(LAYERS, precision="f16x3", device=torch.device("cuda:0"), max_points=1 << 15)
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, case="infinite", engine=eng, verbose=False, seed=9)
+    losses = m.train(8, 1e-3, 2)
+    assert np.array_equal(z["theta0"], z["theta1"])                                   # ranks stay bit-identical
+    one = m.theta.cpu().numpy()
+    assert np.linalg.norm(z["theta0"] - one) < 1e-5 * np.linalg.norm(one)
+    np.testing.assert_allclose(z["loss"], np.array(losses[4]), rtol=1e-4)
+    assert int(z["rows"][0]) == 15000                                                 # rank 0 holds its half of the rows only
