@@ -3,7 +3,7 @@
 The reference's four scripts are 2-D + time.  This class carries their model-class surface
 (``class DeepHPM``, ElasticWaveSemiInfinite/ElasticWave.py = SEMI) over to four inputs (x, y, z, t) and twelve outputs
 (u, v, w, ut, vt, wt, s11, s22, s33, s12, s13, s23): same method names and column-tensor convention, the mixed-variable
-formulation of SEMI:228-272 written for three dimensions (stated exactly in oracle/nc3d_oracle.py), the loss layout of
+formulation of SEMI:228-272 written for three dimensions (stated term by term in include/pinn_hip.h and DESIGN.md), the loss layout of
 SEMI:112-127 with the traction-free top surface as the ``loss_NB`` term.  Kernels: pinn_nc3d_* of include/pinn_hip.h.
 Parity for this case is unpinned by definition (there is nothing in the reference to compare with).
 
