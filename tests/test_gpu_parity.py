@@ -401,3 +401,69 @@ def test_adjoint_shift_keeps_the_gradient_and_rescues_overflow(dev):
     eng.adjoint_shift = 12
     ls, gs = eng.wave_loss_grad(theta_b, *xm, LB, UB, True, np.ones(7) / m)
     assert bool(torch.isfinite(gs).all()) and rel(gs.cpu().numpy(), g) < 1e-3
+
+
+# ---- parity that cancellation cannot excuse: everything measured against what an fp32 evaluation of the same formulas achieves ----
+@pytest.mark.parametrize("case", ["inf20s", "inf10s", "semi16s", "conf14s"])
+def test_residual_vector_and_layer_gradients_within_fp32_bounds(dev, golden_dir, case):
+    """At the reference's TRAINED weights the residuals are ~1e-3 differences of O(1) numbers, so relative errors of sums / gradients look
+    large for ANY finite precision.  The fair bar is what the reference's own arithmetic (fp32, INF:71-92) achieves: the float64 oracle
+    evaluated in fp32 gives the error scale, and the device (f16x3) has to stay within a small factor of it -- per point for the residual
+    vector f (golden files store it), per weight layer for the gradient blocks.  A 1-2 % error in one layer's gradient fails this."""
+    w = np.load(f"{golden_dir}/weights_{case}.npz")
+    g = np.load(f"{golden_dir}/golden_{case}.npz")
+    layers = [int(v) for v in w["layers"]]
+    L = len(layers) - 1
+    flat = po.pack_params([w[f"W{i}"] for i in range(L)], [w[f"b{i}"] for i in range(L)])
+    X, lb, ub, norm = g["X"], g["lb"], g["ub"], bool(g["normalize"])
+    n = X.shape[0]
+    tw = np.ones(7) / n
+    f64, grad64 = g["f"].astype(np.float64), g["grad"].astype(np.float64)
+    # the error scale: the same formulas in fp32 on the host
+    _, grad32, f32 = po.wave2d_loss_grad(flat.astype(np.float32), layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, norm, term_weights=tw, dtype=np.float32)
+    eng = engine(layers, "f16x3", dev, n)
+    theta = to_dev(flat, dev)
+    xs = [to_dev(X[:, k], dev) for k in range(3)]
+    F = eng.fields(theta, *xs, lb, ub, norm).cpu().numpy().astype(np.float64)
+    f_dev = po.wave2d_residuals(F[0].T, [F[1 + k].T for k in range(3)])
+    e32, edev = np.linalg.norm(f32 - f64), np.linalg.norm(f_dev - f64)
+    assert edev <= 2.0 * e32, (edev, e32)
+    # per residual column as well (a wrong coefficient in one residual would hide in the norm of all seven)
+    for i in range(7):
+        assert np.linalg.norm(f_dev[:, i] - f64[:, i]) <= 3.0 * np.linalg.norm(f32[:, i] - f64[:, i]) + 1e-7 * np.linalg.norm(f64[:, i]), i
+    _, grad = eng.wave_loss_grad(theta, *xs, lb, ub, norm, tw)
+    gdev = grad.cpu().numpy().astype(np.float64)
+    Wd, bd = po.unpack_params(gdev, layers)
+    W32, b32 = po.unpack_params(grad32.astype(np.float64), layers)
+    W64, b64 = po.unpack_params(grad64, layers)
+    for l in range(L):
+        for d_, s_, r_ in ((Wd[l], W32[l], W64[l]), (bd[l], b32[l], b64[l])):
+            assert np.linalg.norm(d_ - r_) <= 6.0 * np.linalg.norm(s_ - r_) + 1e-6 * np.linalg.norm(r_), (l, np.linalg.norm(d_ - r_), np.linalg.norm(s_ - r_))
+
+
+@pytest.mark.parametrize("case", ["inf20s", "semi16s", "conf14s"])
+def test_fem_bands_on_device(dev, golden_dir, case):
+    """The reference's only validation is PINN-vs-FEM scatter plots (INF:427-610).  On the committed sub-sample of its FEM frames the
+    device's predict reproduces, frame by frame and field by field, the relative L2 distances the float64 oracle measured when the
+    fixtures were made (SURVEY Appx C bands) -- so normalisation flag, column order, coordinate shifts and frame times are right on
+    the device for all three wave scripts, not only the infinite-domain one."""
+    w = np.load(f"{golden_dir}/weights_{case}.npz")
+    g = np.load(f"{golden_dir}/golden_{case}.npz")
+    fz = np.load(f"{golden_dir}/fem_{case}.npz")
+    fem, ref = fz["fem"].astype(np.float64), fz["rel_l2"]
+    layers = [int(v) for v in w["layers"]]
+    L = len(layers) - 1
+    flat = po.pack_params([w[f"W{i}"] for i in range(L)], [w[f"b{i}"] for i in range(L)])
+    eng = engine(layers, "f16x3", dev, fem.shape[0])
+    F = eng.fields(to_dev(flat, dev), *[to_dev(fem[:, k], dev) for k in range(3)], g["lb"], g["ub"], bool(g["normalize"])).cpu().numpy()
+    pred = {"u": F[0, 0], "v": F[0, 1], "s11": F[0, 4], "s22": F[0, 5], "s12": F[0, 6]}
+    nfr = ref.shape[1]
+    per = fem.shape[0] // nfr
+    for j, q in enumerate(("u", "v", "s11", "s22", "s12")):
+        for i in range(nfr):
+            sl = slice(per * i, per * (i + 1))
+            den = np.linalg.norm(fem[sl, 3 + j])
+            if den < 1e-9:
+                continue
+            r = np.linalg.norm(pred[q][sl] - fem[sl, 3 + j]) / den
+            assert abs(r - ref[j, i]) <= 2e-3 * max(1.0, ref[j, i]), (q, i, r, ref[j, i])
