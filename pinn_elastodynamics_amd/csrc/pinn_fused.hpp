@@ -22,7 +22,7 @@
 //     ds_read_b64_tr_b16 (the record order is rotated per 16-lane group so that those reads are at most 2-way bank conflicted);
 //   * for the weight gradient  Wbar_l = sum_points S_l^T Z_l  the contraction runs over points, so
 //     both operands are needed "feature per lane, points in registers" -- the transpose of the
-//     chain layout.  Every chain wave drops its Z_l tile into LDS as [point][feature] rows (ds_write_b64);
+//     chain layout.  Every chain wave drops its Z_l tile into LDS as the same kind of register image (ds_write_b128);
 //   * the weight-gradient accumulators are PERSISTENT MFMA accumulators, written once per launch
 //     as per-workgroup partials (deterministic two-stage reduction, no atomics).
 // Addressing discipline (this kernel is unrolled over 9 weight layers, so every loop-invariant
@@ -93,13 +93,13 @@ struct Fused {
     static constexpr float INV_LS = 1.0f / Op::LO_SCALE;
     typedef Chain<Op, SPLIT, WIDTH, 1, NS, NS == 4 ? HEAD_WAVE : HEAD_DATA> CH;
     typedef FragIndex<WIDTH> FI;
-    // LDS per chain wave: [Z tensor | S images].  Z tensor = NS*NP panels of [16 points][ROWB bytes] (adjoints, hi and scaled lo);
-    // an S image = the NS*KS fragment records (1 KB each: 64 lanes x 16 B) of the state's high parts, lane records rotated (imgoff)
-    static constexpr int ROWB = WIDTH * 2 + 8;
-    static constexpr int PANEL_B = 16 * ROWB;
+    // LDS per chain wave: [Z image | S images].  An image = the fragment records (1 KB each: 64 lanes x 16 B) of a chain-layout tensor,
+    // lane records rotated (imgoff): record block (stream, k-step) of the state's high parts (S), (stream, k-step, part) of the
+    // adjoints' high and scaled low parts (Z).  A chain lane writes / reads its own records with 16-byte LDS accesses; the
+    // weight-gradient waves rebuild transposed MFMA fragments from the same bytes with ds_read_b64_tr_b16.
     // The parked state S is kept in the operand type's precision only (no low part): measured in tools/precision_study2.py,
     // rounding S for the reverse pass changes the gradient error by < 10 % of itself as long as adjoints and weights stay split.
-    static constexpr int TENSOR_Z_B = NS * NP * PANEL_B;
+    static constexpr int TENSOR_Z_B = NS * KS * NP * 1024;
     static constexpr int IMG_B = NS * KS * 1024;
     // "SLDS": where S_0..S_NL of a tile fit in LDS (NL+1 slots: every 1-stream case, and the 4-stream 4x32 net) nothing is parked in
     // scratch and no LDS-DMA round trip sits between the layer phases; otherwise two slots (layer parity), filled by LDS-DMA
@@ -133,15 +133,8 @@ struct Fused {
     // MFMA fragment "16-feature block, 32 points of one k-step" rebuilt from the chain waves' LDS data.  k-slot (q, e) <-> chain wave
     // 2j + (q>>1), local point 8(q&1) + e (same map for both operands); the lane-dependent part of the address lives in the base
     // pointer(s), everything else is an immediate.
-    //   Z: [point][feature] rows, block at byte column `off`; the second read is 4 rows further on
-    static __device__ __forceinline__ u32x4 zfrag(const char* base, int off) {
-        const v4i16 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(base + off));
-        const v4i16 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(base + off + 4 * ROWB));
-        const u32x2 d0 = __builtin_bit_cast(u32x2, v0), d1 = __builtin_bit_cast(u32x2, v1);
-        return u32x4{d0[0], d0[1], d1[0], d1[1]};
-    }
-    //   S: the register image; lane (c, q) reads the 8 bytes "features 4(c&3)..+3 of point 8(q&1)+(c>>2) [+4]" = one half of the
-    //   record of chain lane (point, c&3).  The record rotation makes the +4-point address lane dependent: two base pointers.
+    //   lane (c, q) reads the 8 bytes "features 4(c&3)..+3 of point 8(q&1)+(c>>2) [+4]" = one half of the record of chain lane
+    //   (point, c&3).  The record rotation makes the +4-point address lane dependent: two base pointers.
     static __device__ __forceinline__ u32x4 sfrag(const char* b0, const char* b1, int off) {
         const v4i16 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(b0 + off));
         const v4i16 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)(b1 + off));
@@ -154,11 +147,12 @@ struct Fused {
     // NA x NBK blocks of one weight gradient:  acc[a][b] += sum over 64 points, NS streams of  S(block fa+a)^T . Z(block fb+b).
     // Operand fragments are fetched once per (k-step, stream) and shared by the NA*NBK blocks; a scheduling fence after every
     // group keeps the compiler from hoisting all transpose-reads of a layer ahead of the MFMAs.
-    // s0/s1: lane bases of the S image of chain wave 0 (+ the first in-block's offset), NA > 1 steps 8 bytes (the other half of
-    // the record: in-blocks 2k, 2k+1 share a record).  zbase: lane base of the Z tensor of chain wave 0 (+ 32 bytes per out-block).
+    // s0/s1 (z0/z1): lane bases of the S (Z) image of chain wave 0 (+ the first block's offset); a second block steps 8 bytes (the
+    // other half of the record: blocks 2k, 2k+1 share a record).
     template <int NA, int NBK>
-    static __device__ __forceinline__ void wg_blocks(const char* s0, const char* s1, const char* zbase, f32x4 (&acc)[NA][NBK], float (&bias_out)[NBK]) {
-        static_assert(NA <= 2, "in-blocks of one call share a fragment record");
+    static __device__ __forceinline__ void wg_blocks(const char* s0, const char* s1, const char* z0, const char* z1, f32x4 (&acc)[NA][NBK],
+                                                     float (&bias_out)[NBK]) {
+        static_assert(NA <= 2 && NBK <= 2, "blocks of one call share a fragment record");
         f32x4 cc[NA][NBK], bm[NBK], bc[NBK];
 #pragma unroll
         for (int b = 0; b < NBK; ++b) {
@@ -179,8 +173,8 @@ struct Fused {
             for (int a = 0; a < NA; ++a) f.Ah[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * KS * 1024 + 8 * a);
 #pragma unroll
             for (int b = 0; b < NBK; ++b) {
-                f.Bh[b] = zfrag(zbase, 2 * j * WAVE_B + (st * NP) * PANEL_B + 32 * b);
-                if (NP == 2) f.Bl[b] = zfrag(zbase, 2 * j * WAVE_B + (st * NP + 1) * PANEL_B + 32 * b);
+                f.Bh[b] = sfrag(z0, z1, 2 * j * WAVE_B + (st * KS * NP) * 1024 + 8 * b);
+                if (NP == 2) f.Bl[b] = sfrag(z0, z1, 2 * j * WAVE_B + (st * KS * NP + 1) * 1024 + 8 * b);
             }
         };
         auto work = [&](int g, const Frags& f) {
@@ -223,17 +217,18 @@ struct Fused {
     }
 
     struct WgCtx {                     // lane bases of a weight-gradient wave (chain wave 0's tensors + the lane part)
-        const char* z;                 // Z tensor rows
-        const char* s0;                // S image slot 0, first four points of the k-slots
+        const char* z0;                // Z image, first four points of the k-slots
+        const char* z1;                // Z image, the +4 points
+        const char* s0;                // S image slot 0, first four points
         const char* s1;                // S image slot 0, the +4 points
     };
-    // byte offset of in-block mb inside an image: fragment record block (mb >> 1), half (mb & 1) of the 16-byte lane record
+    // byte offset of 16-feature block mb inside an image: fragment record block (mb >> 1), half (mb & 1) of the 16-byte lane record
     static __device__ __forceinline__ int img_block(int mb) { return (mb >> 1) * 1024 + 8 * (mb & 1); }
+    static __device__ __forceinline__ int zimg_block(int mb) { return (mb >> 1) * NP * 1024 + 8 * (mb & 1); }
 
     // weight gradient of weight layer L (quad = weight-gradient wave index 0..3)
     template <int L>
     static __device__ __forceinline__ void wgrad(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW]) {
-        const char* zl = w.z;
         const char* s0 = w.s0 + slot_of(L) * IMG_B;
         const char* s1 = w.s1 + slot_of(L) * IMG_B;
         const int wi = quad >> 1, wo = quad & 1;
@@ -241,7 +236,7 @@ struct Fused {
             if (quad < WB) {
                 f32x4 t[1][1] = {{A.first}};
                 float b[1];
-                wg_blocks<1, 1>(s0, s1, zl + 32 * quad, t, b);
+                wg_blocks<1, 1>(s0, s1, w.z0 + zimg_block(quad), w.z1 + zimg_block(quad), t, b);
                 A.first = t[0][0];
                 A.bias[0] += b[0];
             }
@@ -249,7 +244,7 @@ struct Fused {
             if (quad < WB) {
                 f32x4 t[1][1] = {{A.last}};
                 float b[1];
-                wg_blocks<1, 1>(s0 + img_block(quad), s1 + img_block(quad), zl, t, b);
+                wg_blocks<1, 1>(s0 + img_block(quad), s1 + img_block(quad), w.z0, w.z1, t, b);
                 A.last = t[0][0];
                 if (quad == 0) A.bias[NL] += b[0];
             }
@@ -260,13 +255,13 @@ struct Fused {
                 for (int i = 0; i < IBW; ++i)
 #pragma unroll
                     for (int o = 0; o < OBW; ++o) pend[i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-                wg_blocks<IBW, OBW>(s0 + img_block(wi * IBW), s1 + img_block(wi * IBW), zl + 32 * (wo * OBW), pend, b);
+                wg_blocks<IBW, OBW>(s0 + img_block(wi * IBW), s1 + img_block(wi * IBW), w.z0 + zimg_block(wo * OBW), w.z1 + zimg_block(wo * OBW), pend, b);
 #pragma unroll
                 for (int i = 0; i < IBW; ++i)
 #pragma unroll
                     for (int o = 0; o < OBW; ++o) pend[i][o] += ld[i][o];
             } else {
-                wg_blocks<IBW, OBW>(s0 + img_block(wi * IBW), s1 + img_block(wi * IBW), zl + 32 * (wo * OBW), A.mid[L - 1], b);
+                wg_blocks<IBW, OBW>(s0 + img_block(wi * IBW), s1 + img_block(wi * IBW), w.z0 + zimg_block(wo * OBW), w.z1 + zimg_block(wo * OBW), A.mid[L - 1], b);
             }
             // one bias block per wave per layer: out-block wo*OBW + wi (OBW == 2) or wo (OBW == 1, waves with wi == 0)
             if (OBW == 1) { if (wi == 0) A.bias[L] += b[0]; }
@@ -377,9 +372,10 @@ struct Fused {
         {
             const char* wave0 = lds + (q >> 1) * WAVE_B;
             const int p0 = 8 * (q & 1) + (c >> 2), sub = c & 3;
-            w.z = wave0 + p0 * ROWB + 8 * sub;
-            w.s0 = wave0 + TENSOR_Z_B + img_record(p0, sub);
-            w.s1 = wave0 + TENSOR_Z_B + img_record(p0 + 4, sub);
+            w.z0 = wave0 + img_record(p0, sub);
+            w.z1 = wave0 + img_record(p0 + 4, sub);
+            w.s0 = w.z0 + TENSOR_Z_B;
+            w.s1 = w.z1 + TENSOR_Z_B;
         }
         // this wave feeds chain tile `quad`: descriptor of that tile's scratch image
         const long gtile = (long)blockIdx.x * TILES + quad;
@@ -445,7 +441,6 @@ struct Fused {
     struct Ctx {                                   // wave-invariant addressing state of a chain wave
         __amdgpu_buffer_rsrc_t frags, scr, bias, w0p;
         unsigned lane16;                           // lane * 16: the only VGPR offset of the fragment traffic
-        unsigned rowoff;                           // c*ROWB + 8q: this lane's row/column offset inside the Z tensor
         unsigned imgoff;                           // this lane's (rotated) 16-byte record inside a fragment record block of an S image
         char* tenZ;                                // wave's Z tensor (uniform); S images follow at +TENSOR_Z_B (+k*IMG_B)
         int c, q;
@@ -459,29 +454,24 @@ struct Fused {
             w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * 16, 0x00020000);
             lane16 = (unsigned)lane * 16u;
             tenZ = lds + slot * WAVE_B;
-            rowoff = (unsigned)(c_ * ROWB + 8 * q_);
             imgoff = img_record(c_, q_);
             c = c_;
             q = q_;
             tracer = false;
         }
-        __device__ __forceinline__ char* rowZ() const { return tenZ + rowoff; }
+        __device__ __forceinline__ char* imgZ() const { return tenZ + imgoff; }
         __device__ __forceinline__ char* imgS(int L) const { return tenZ + TENSOR_Z_B + slot_of(L) * IMG_B + imgoff; }
     };
 
-    // chain-layout adjoint fragments -> [point][feature] rows of this wave's Z tensor (row = lane's point, 8 bytes per feature block)
-    // NMB = 16-feature blocks actually present (WB for hidden adjoints, 1 for the outputs')
-    template <int KSF, int NMB>
-    static __device__ __forceinline__ void put_rows(char* row, const u32x4 (&F)[NS][1][KSF][NP]) {
+    // chain-layout adjoint fragments (hi and scaled lo) -> this lane's records of the wave's Z image
+    template <int KSF>
+    static __device__ __forceinline__ void put_zimage(char* img, const u32x4 (&F)[NS][1][KSF][NP]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+            for (int kk = 0; kk < KSF; ++kk)
 #pragma unroll
-                for (int mb = 0; mb < NMB; ++mb) {
-                    u32x2 v = {F[s][0][mb >> 1][p][(mb & 1) * 2 + 0], F[s][0][mb >> 1][p][(mb & 1) * 2 + 1]};
-                    *reinterpret_cast<u32x2*>(row + (s * NP + p) * PANEL_B + 32 * mb) = v;
-                }
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(img + ((s * KS + kk) * NP + p) * 1024) = F[s][0][kk][p];
     }
     // high parts of chain-layout state fragments -> this lane's records of an LDS image
     template <int KSF>
@@ -669,8 +659,21 @@ struct Fused {
     // reverse: vector part of block MB of weight layer L's transpose -- the activation below it.  acc = WS * (W_L Z_L) for the NS
     // streams; state (h, hdot_k) of this lane's point as packed 16-bit pairs sp[s] (fp16: consumed in place by mixed-precision FMAs)
     //   zbar = sd hbar - 2 h sum_k hdotbar_k hdot_k ,  zdotbar_k = sd hdotbar_k          (INF:131-133, gradient of TanhGrad)
+    // The reverse vector part reads the accumulators inside inline assembly (mixed-precision FMAs).  hipcc pads MFMA-result
+    // hazards only for instructions it knows, not for an asm statement that consumes the registers, and its scheduler is free to
+    // put such a statement right behind the block's last MFMA -- seen on the GPU as a timing-dependent wrong first element of one
+    // layer's adjoint.  This fence makes every later reader depend on a statement that opens with the wait states an MFMA result
+    // needs before a vector instruction may read it.
+    static __device__ __forceinline__ void mfma_results_ready(f32x4 (&acc)[NS]) {
+#if defined(__AMDGCN__)
+        if constexpr (NS == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        else asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]));
+#endif
+    }
+
     template <int MB>
-    static __device__ __forceinline__ void bwd_valu(const f32x4 (&acc)[NS], const u32x2 (&sp)[NS], u32x4 (&Zn)[NS][1][KS][NP], int c, int q) {
+    static __device__ __forceinline__ void bwd_valu(f32x4 (&acc)[NS], const u32x2 (&sp)[NS], u32x4 (&Zn)[NS][1][KS][NP], int c, int q) {
+        if constexpr (MixF16<Op>::value) mfma_results_ready(acc);
         float vals[NS][1][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -762,7 +765,7 @@ struct Fused {
             }
             __syncthreads();                                   // previous layer's fragment reads are done
             fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
-            put_rows<KS, WB>(x.rowZ(), Zc);
+            put_zimage<KS>(x.imgZ(), Zc);
             if constexpr (L == 0) {
                 // S_0: the inputs as a 16-feature state (rows 0..2 = x', tangent stream k carries sx_k in row k)
                 float v0[NS][1][4];
@@ -924,7 +927,7 @@ struct Fused {
         load_afrags<1, RP>(x, FI::bwd_last(NL, 1), Ab);
         __syncthreads();
         fused_stamp(a, x.tracer, 3);
-        put_rows<1, 1>(x.rowZ(), ZL);
+        put_zimage<1>(x.imgZ(), ZL);
         put_image<KS>(x.imgS(NL), B);
         __syncthreads();
         fused_stamp(a, x.tracer, 4);
