@@ -423,9 +423,22 @@ struct Chain {
     }
 
     // acc[s][nb] (+ corr) = A(mb) . B over KSB k-steps
-    template <int KSB>
+    // FENCE (first block of a layer): the operand fragments were just written by emit()'s inline assembly, and hipcc pads the
+    // "vector write -> MFMA operand read" wait states only between instructions it knows.  The fragments written last (k-step
+    // KSB-1) pass through a statement that opens with those wait states, so no MFMA reading them can be scheduled closer.
+    template <int KSB, bool FENCE = false>
     static __device__ __forceinline__ void gemm_block(const u32x4* Afr, int lane, const u32x4 (&B)[NS][NB][KSB][NP],
                                                       f32x4 (&acc)[NS][NB], f32x4 (&accc)[NS][NB]) {
+#if defined(__AMDGCN__)
+        if constexpr (FENCE) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) asm volatile("s_nop 1" : "+v"(const_cast<u32x4&>(B[s][nb][KSB - 1][p])));
+        }
+#endif
         u32x4 A[KSB][NP];
 #pragma unroll
         for (int kk = 0; kk < KSB; ++kk)
@@ -541,7 +554,7 @@ struct Chain {
         static __device__ __forceinline__ void fwd(const u32x4* Al, const float* bl, int lane, const u32x4 (&B)[NS][NB][KS][NP],
                                                    u32x4 (&Bn)[NS][NB][KS][NP], uint16_t* panel, int c, int q) {
             f32x4 acc[NS][NB], accc[NS][NB];
-            gemm_block<KS>(Al + (long)MB * KS * NPS * 64, lane, B, acc, accc);
+            gemm_block<KS, MB == 0>(Al + (long)MB * KS * NPS * 64, lane, B, acc, accc);
             const f32x4 bias = *reinterpret_cast<const f32x4*>(bl + 16 * MB + 4 * q);
             float vals[NS][NB][4];
 #pragma unroll
@@ -566,7 +579,7 @@ struct Chain {
         static __device__ __forceinline__ void bwd(const u32x4* Al, int lane, const u32x4 (&Zf)[NS][NB][KSB][NP],
                                                    const uint16_t* spanel, u32x4 (&Zn)[NS][NB][KS][NP], uint16_t* zpanel, int c, int q) {
             f32x4 acc[NS][NB], accc[NS][NB];
-            gemm_block<KSB>(Al + (long)MB * KSB * NPS * 64, lane, Zf, acc, accc);
+            gemm_block<KSB, MB == 0>(Al + (long)MB * KSB * NPS * 64, lane, Zf, acc, accc);
             float st[NS][NB][4], vals[NS][NB][4];
             load_state<MB>(spanel, c, q, st);
             act_bwd(st, acc, accc, vals);
@@ -640,7 +653,7 @@ struct Chain {
             }
             // ---- output layer  Y = h W_L + b_L  (INF:196-198): lane holds outputs 4q+r of its point
             f32x4 yacc[NS][NB], yaccc[NS][NB];
-            gemm_block<KS>(a.pw.frags + (long)FI::fwd_last(nl, 0) * NPS * 64, lane, B, yacc, yaccc);
+            gemm_block<KS, true>(a.pw.frags + (long)FI::fwd_last(nl, 0) * NPS * 64, lane, B, yacc, yaccc);
             const f32x4 bl = *reinterpret_cast<const f32x4*>(a.pw.bias_last + 4 * q);
             // Every lane gathers the NOG (padded) outputs of its point: own block + the q^1 partner's (8 outputs), or all four (16)
             float Y[NS][NB][NOG];

@@ -103,10 +103,17 @@ struct Fused {
     static constexpr int IMG_B = NS * KS * 1024;
     // "SLDS": where S_0..S_NL of a tile fit in LDS (NL+1 slots: every 1-stream case, and the 4-stream 4x32 net) nothing is parked in
     // scratch and no LDS-DMA round trip sits between the layer phases; otherwise two slots (layer parity), filled by LDS-DMA
-    static constexpr bool SLDS = 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
+    // Net constants the forward reads block by block, staged in LDS once per launch: [(NL-1) x WIDTH hidden biases | 16 output biases]
+    // (both pre-multiplied by WS: they are accumulator start values) and the first layer's [WIDTH][4] weight/bias rows.  From memory
+    // each of these small loads was consumed right behind its issue -- a full L2 round trip per feature block, and behind the park
+    // stores of a layer even the stores' acknowledgements (vector-memory operations return in order): round-2 block-level phase
+    // trace, 1.6 k cycles for the first block step of a forward layer against 0.8 k for the others.
+    static constexpr int CONST_BIAS_F = (NL - 1) * WIDTH + 16, CONST_F = CONST_BIAS_F + WIDTH * 4, CONST_B = CONST_F * 4;
+    static constexpr bool SLDS = 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) + CONST_B <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
     static constexpr int S_SLOTS = SLDS ? NL + 1 : 2;
     static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * IMG_B;
-    static constexpr int LDS_B = 4 * WAVE_B;
+    static constexpr int CONST_OFF = 4 * WAVE_B;
+    static constexpr int LDS_B = CONST_OFF + CONST_B;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
     static constexpr int TILES = 4;                                           // 16-point tiles per workgroup step (one per chain wave)
     static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * IMG_B);    // per tile: parked states S_1..S_{NL-1}
@@ -439,10 +446,12 @@ struct Fused {
     // chain role
     // ---------------------------------------------------------------------------------------------
     struct Ctx {                                   // wave-invariant addressing state of a chain wave
-        __amdgpu_buffer_rsrc_t frags, scr, bias, w0p;
+        __amdgpu_buffer_rsrc_t frags, scr;
         unsigned lane16;                           // lane * 16: the only VGPR offset of the fragment traffic
         unsigned imgoff;                           // this lane's (rotated) 16-byte record inside a fragment record block of an S image
         char* tenZ;                                // wave's Z tensor (uniform); S images follow at +TENSOR_Z_B (+k*IMG_B)
+        const char* cbias;                         // LDS constants: bias table + q * 16 (a lane holds accumulator rows 4q..4q+3)
+        const char* cw0;                           // LDS constants: first-layer rows + q * 64
         int c, q;
         bool tracer;                               // workgroup 0, chain wave 0, lane 0
         __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile) {
@@ -450,10 +459,10 @@ struct Fused {
         }
         __device__ __forceinline__ void init(const FusedArgs& a, char* lds, int slot, int lane, int c_, int q_) {
             frags = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.frags, 0, (int)a.frags_bytes, 0x00020000);
-            bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.bias_mid, 0, (NL - 1) * WIDTH * 4, 0x00020000);
-            w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * 16, 0x00020000);
             lane16 = (unsigned)lane * 16u;
             tenZ = lds + slot * WAVE_B;
+            cbias = lds + CONST_OFF + q_ * 16;
+            cw0 = lds + CONST_OFF + CONST_BIAS_F * 4 + q_ * 64;
             imgoff = img_record(c_, q_);
             c = c_;
             q = q_;
@@ -532,9 +541,9 @@ struct Fused {
             bwd_ksteps<K0 + 1, K1, KSB>(Af, Zf, acc);
         }
     }
-    // accumulators of a new forward block: the value stream starts at WS * bias
+    // accumulators of a new forward block: the value stream starts at WS * bias (the LDS table holds the product)
     static __device__ __forceinline__ void acc_init(const f32x4& bias, f32x4 (&acc)[NS]) {
-        acc[0] = bias * WS;
+        acc[0] = bias;
 #pragma unroll
         for (int s = 1; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -542,8 +551,9 @@ struct Fused {
 #pragma unroll
         for (int s = 0; s < NS; ++s) acc[s] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    static __device__ __forceinline__ f32x4 load_bias(const Ctx& x, int l /*1..NL-1*/, int mb) {
-        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x.bias, (unsigned)x.q * 16u, ((l - 1) * WIDTH + 16 * mb) * 4, 0));
+    // WS * bias of feature block mb of weight layer l (1..NL-1; l = NL, mb = 0: the output layer), from the LDS table
+    static __device__ __forceinline__ f32x4 load_bias(const Ctx& x, int l, int mb) {
+        return *reinterpret_cast<const f32x4*>(x.cbias + ((l - 1) * WIDTH + 16 * mb) * 4);
     }
 
     // state fragments (hi, unscaled lo) of feature block MB from per-point values
@@ -576,6 +586,22 @@ struct Fused {
         sds = c4 - c4 * r;
     }
 
+    // The operand fragments are written by inline assembly (split2u / split2: mixed-precision conversions).  hipcc pads the
+    // "vector write -> MFMA operand read" wait states only between instructions it knows; an MFMA scheduled right behind such a
+    // statement reads stale registers (seen on the GPU as a wrong forward as soon as nothing else happened to sit in between).  This
+    // fence names the fragments of k-step kk and opens with the two wait states; every MFMA reading them is ordered behind it.
+    template <int KSF>
+    static __device__ __forceinline__ void operands_ready(u32x4 (&F)[NS][1][KSF][NP], int kk) {
+#if defined(__AMDGCN__)
+        if constexpr (NS == 4 && NP == 2)
+            asm volatile("s_nop 1" : "+v"(F[0][0][kk][0]), "+v"(F[0][0][kk][1]), "+v"(F[1][0][kk][0]), "+v"(F[1][0][kk][1]),
+                                     "+v"(F[2][0][kk][0]), "+v"(F[2][0][kk][1]), "+v"(F[3][0][kk][0]), "+v"(F[3][0][kk][1]));
+        else if constexpr (NS == 4) asm volatile("s_nop 1" : "+v"(F[0][0][kk][0]), "+v"(F[1][0][kk][0]), "+v"(F[2][0][kk][0]), "+v"(F[3][0][kk][0]));
+        else if constexpr (NP == 2) asm volatile("s_nop 1" : "+v"(F[0][0][kk][0]), "+v"(F[0][0][kk][1]));
+        else asm volatile("s_nop 1" : "+v"(F[0][0][kk][0]));
+#endif
+    }
+
     // vector part of a forward block: activation of the value stream, tangent streams, split into the next layer's operand
     template <int MB>
     static __device__ __forceinline__ void fwd_valu(const f32x4 (&acc)[NS], u32x4 (&Bn)[NS][1][KS][NP]) {
@@ -597,8 +623,7 @@ struct Fused {
         float vals[NS][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const u32x4 wu = __builtin_amdgcn_raw_buffer_load_b128(x.w0p, (unsigned)x.q * 64u, (16 * MB + r) * 16, 0);
-            const f32x4 w = __builtin_bit_cast(f32x4, wu);
+            const f32x4 w = *reinterpret_cast<const f32x4*>(x.cw0 + (16 * MB + r) * 16);
             float h, sd;
             tanh_act(w[3] + w[0] * xin[0] + w[1] * xin[1] + w[2] * xin[2], h, sd);
             vals[0][r] = h;
@@ -635,25 +660,36 @@ struct Fused {
     template <int MB>
     static __device__ __forceinline__ void fwd_step(const Ctx& x, int l, int nfrag0, bool next_is_out, const u32x4 (&in)[NS][1][KS][NP],
                                                     u32x4 (&out)[NS][1][KS][NP], u32x4 (&A)[WB][KS][FP], f32x4 (&acca)[NS], f32x4 (&accb)[NS],
-                                                    const f32x4& bias_next) {
+                                                    f32x4 (&bb)[WB]) {
         f32x4 (&acur)[NS] = (MB & 1) ? accb : acca;      // block MB, complete
         f32x4 (&anxt)[NS] = (MB & 1) ? acca : accb;      // block MB+1
         if (MB == 0 || !next_is_out) load_afrags<KS, FP>(x, nfrag0 + MB * KS, A[MB]);
         if constexpr (MB == 0) park_state(x, l, in);
+        // accumulator start values (LDS table), requested a block step or more ahead of their use.  bb[m], m >= 1: block m of this
+        // layer (bb[1] was requested during the previous layer); bb[0]: block 0 of the next layer.
+        if constexpr (MB == 0) {
+#pragma unroll
+            for (int m = 2; m < WB; ++m) bb[m] = load_bias(x, l, m);
+            bb[0] = load_bias(x, l + 1, 0);
+        }
         if constexpr (MB + 1 < WB) {
-            acc_init(load_bias(x, l, MB + 1), anxt);
+            acc_init(bb[MB + 1], anxt);
+            if constexpr (MB == 0) {
+                if (!next_is_out) bb[1] = load_bias(x, l + 1, 1);       // behind its use just above
+            }
             fwd_ksteps<0, KS, KS>(A[MB + 1], in, anxt);
             fwd_valu<MB>(acur, out);
         } else {
             // last block: the next layer's block 0 starts on the finished half of `out`
-            acc_init(bias_next, anxt);
+            acc_init(bb[0], anxt);
             fwd_ksteps<0, KOVL, KS>(A[0], out, anxt);
             fwd_valu<MB>(acur, out);
             __builtin_amdgcn_sched_barrier(0);
+            operands_ready<KS>(out, KS - 1);
             fwd_ksteps<KOVL, KS, KS>(A[0], out, anxt);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MB + 1 < WB) fwd_step<MB + 1>(x, l, nfrag0, next_is_out, in, out, A, acca, accb, bias_next);
+        if constexpr (MB + 1 < WB) fwd_step<MB + 1>(x, l, nfrag0, next_is_out, in, out, A, acca, accb, bb);
     }
 
     // reverse: vector part of block MB of weight layer L's transpose -- the activation below it.  acc = WS * (W_L Z_L) for the NS
@@ -811,24 +847,27 @@ struct Fused {
     static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], bool valid, long pidx, int set, float (&lsum)[8],
                                                         u32x4 (&B)[NS][1][KS][NP], u32x4 (&ZL)[NS][1][1][NP]) {
         const int c = x.c, q = x.q;
-        first_mb<0>(a, x, xin, B);
-        // pipeline prologue: all fragments of layer 1, block 0's MFMAs
+        // pipeline prologue: all fragments of layer 1 are requested BEFORE the first layer's vector work (they take a full L2 round
+        // trip), then block 0's MFMAs
         u32x4 A[WB][KS][FP];
-        f32x4 acca[NS], accb[NS];
+        f32x4 acca[NS], accb[NS], bb[WB];
 #pragma unroll
         for (int mb = 0; mb < WB; ++mb) load_afrags<KS, FP>(x, FI::fwd_mid(1, mb, 0), A[mb]);
-        acc_init(load_bias(x, 1, 0), acca);
+        bb[0] = load_bias(x, 1, 0);
+        bb[1] = load_bias(x, 1, 1);
+        first_mb<0>(a, x, xin, B);
+        acc_init(bb[0], acca);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) operands_ready<KS>(B, kk);
         fwd_ksteps<0, KS, KS>(A[0], B, acca);
         __builtin_amdgcn_sched_barrier(0);
         // two layers per loop trip, ping-ponging between B and B2: a one-buffer loop has to copy the fragment registers
         // back at the end of every layer
         u32x4 B2[NS][1][KS][NP];
-        const f32x4 blast = *reinterpret_cast<const f32x4*>(a.pw.bias_last + 4 * q);
         auto layer = [&](int l, const u32x4 (&in)[NS][1][KS][NP], u32x4 (&out)[NS][1][KS][NP]) {
             const bool last = l + 1 == NL;
             const int nfrag0 = last ? FI::fwd_last(NL, 0) : FI::fwd_mid(l + 1, 0, 0);
-            const f32x4 bnext = last ? blast : load_bias(x, last ? l : l + 1, 0);
-            fwd_step<0>(x, l, nfrag0, last, in, out, A, acca, accb, bnext);
+            fwd_step<0>(x, l, nfrag0, last, in, out, A, acca, accb, bb);
         };
         int l = 1;
         for (; l + 1 < NL; l += 2) {
@@ -1011,6 +1050,17 @@ struct Fused {
         __shared__ __attribute__((aligned(16))) char lds[LDS_B];
         const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
         const int wave8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // provably wave-uniform
+        {
+            float* cst = reinterpret_cast<float*>(lds + CONST_OFF);
+            for (int i = threadIdx.x; i < CONST_F; i += 512) {
+                float v;
+                if (i < (NL - 1) * WIDTH) v = a.pw.bias_mid[i] * WS;
+                else if (i < CONST_BIAS_F) v = a.pw.bias_last[i - (NL - 1) * WIDTH] * WS;
+                else v = a.pw.w0p[i - CONST_BIAS_F];
+                cst[i] = v;
+            }
+            __syncthreads();
+        }
         if (wave8 >= 4) {
             wgrad_role(a, lds, wave8 - 4, lane, c, q);
         } else {
