@@ -321,8 +321,13 @@ class PINN:
         def fun(th):
             self.theta[key].copy_(torch.from_numpy(th.astype(np.float32)).to(self.device))
             loss, g = self._pretrain_loss_grad(key, sets)
-            cb(1000.0 * loss)                                        # ScipyOptimizerInterface(1000 * loss_X, ...) PLATE:220,230
-            return 1000.0 * loss, 1000.0 * g
+            if not (np.isfinite(loss) and np.isfinite(g).all()):
+                # the stream losses have no adjoint-shift retry (pinn_stream_loss_grad evaluates small nets on O(1) targets); a
+                # non-finite value here means the optimizer was handed a wild point -- say so instead of feeding NaN to scipy
+                raise FloatingPointError(f"pre-training of the {key!r} net produced a non-finite loss or gradient "
+                                         f"(loss = {loss}); restart from other weights or use precision='bf16x3'")
+            cb(loss)                                                 # fetches = [loss_DIST] / [loss_PART]: the callbacks see the unscaled loss (PLATE:527-559)
+            return 1000.0 * loss, 1000.0 * g                         # ScipyOptimizerInterface(1000 * loss_X, ...) PLATE:220,230
         res = self._bfgs(key, fun, dict(BFGS_OPTIONS[key], **(options or {})))
         self.refresh_frozen()
         return res
