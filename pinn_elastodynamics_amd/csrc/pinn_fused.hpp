@@ -55,6 +55,7 @@ struct FusedArgs {
     float c1, c2, G, rho;
     float tw[8];
     const float* targets;      // NS = 1 only: [nout][n] or nullptr (= 0)   (single-set form; the set table below supersedes it)
+    const float* aux;          // NS = 5 (plate head): the frozen nets' streams [2 nets (D,P)][5 streams][5 fields][n]
     // NS = 1: up to FUSED_MAX_SETS value-only point sets in ONE launch (loss_IC, loss_SRC, loss_NB, loss_FIX of a step): set k owns
     // the workgroup steps [set_step0[k], set_step0[k+1]) and has its own points, targets, output weights and loss slot
     int nsets;
@@ -81,7 +82,12 @@ __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int sl
 template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4>
 struct Fused {
     static constexpr int NS = NS_, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1;
-    static_assert(NS == 4 || NS == 1, "wave residual head (4 streams) or value-only data head (1 stream)");
+    static_assert(NS == 4 || NS == 1 || NS == 5, "wave residual head (4 streams), value-only data head (1 stream) or plate head (5 streams)");
+    // NS = 5: streams (value, x, y, t, tt) -- the fifth carries the second time derivative (PLATE:417-419) -- and the plate head:
+    // composite F = P + D*N with the frozen nets' streams, plane-stress residuals (PLATE:358-439)
+    static constexpr bool SECOND = NS == 5;
+    static constexpr int NT = NS >= 4 ? 3 : 0;                 // first-order tangent streams 1..NT
+    static constexpr int HEAD = NS == 4 ? HEAD_WAVE : (NS == 1 ? HEAD_DATA : HEAD_PLATE);
     // weight fragments in the fused format of repack_kernel: [T(V), T(V - T(V)), T(T(V)/LO_SCALE)] with V = FUSED_WEIGHT_SCALE * w
     // when split, [T(w)] otherwise.  Every accumulator of this kernel holds WS * (W . x).
     static constexpr int P3 = NP == 2 ? 3 : 1;
@@ -91,7 +97,7 @@ struct Fused {
     static_assert(NL >= 2, "fused kernel needs at least two hidden layers");
     static constexpr int IBW = WB / 2, OBW = WB / 2;          // weight-gradient wave (i,o) owns IBW x OBW blocks of every mid Wbar
     static constexpr float INV_LS = 1.0f / Op::LO_SCALE;
-    typedef Chain<Op, SPLIT, WIDTH, 1, NS, NS == 4 ? HEAD_WAVE : HEAD_DATA> CH;
+    typedef Chain<Op, SPLIT, WIDTH, 1, NS, HEAD> CH;
     typedef FragIndex<WIDTH> FI;
     // LDS per chain wave: [Z image | S images].  An image = the fragment records (1 KB each: 64 lanes x 16 B) of a chain-layout tensor,
     // lane records rotated (imgoff): record block (stream, k-step) of the state's high parts (S), (stream, k-step, part) of the
@@ -109,11 +115,14 @@ struct Fused {
     // stores of a layer even the stores' acknowledgements (vector-memory operations return in order): round-2 block-level phase
     // trace, 1.6 k cycles for the first block step of a forward layer against 0.8 k for the others.
     static constexpr int CONST_BIAS_F = (NL - 1) * WIDTH + 16, CONST_F = CONST_BIAS_F + WIDTH * 4, CONST_B = CONST_F * 4;
-    static constexpr bool SLDS = 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) + CONST_B <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
+    // (Five streams at width 64 fill the 160 KB with tensors alone: that instantiation reads the constants from memory.)
+    static constexpr bool CONST_LDS = 4 * (TENSOR_Z_B + 2 * IMG_B) + CONST_B <= 160 * 1024;
+    static constexpr int CONST_USED = CONST_LDS ? CONST_B : 0;
+    static constexpr bool SLDS = 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) + CONST_USED <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
     static constexpr int S_SLOTS = SLDS ? NL + 1 : 2;
     static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * IMG_B;
     static constexpr int CONST_OFF = 4 * WAVE_B;
-    static constexpr int LDS_B = CONST_OFF + CONST_B;
+    static constexpr int LDS_B = CONST_OFF + CONST_USED;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
     static constexpr int TILES = 4;                                           // 16-point tiles per workgroup step (one per chain wave)
     static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * IMG_B);    // per tile: parked states S_1..S_{NL-1}
@@ -446,12 +455,13 @@ struct Fused {
     // chain role
     // ---------------------------------------------------------------------------------------------
     struct Ctx {                                   // wave-invariant addressing state of a chain wave
-        __amdgpu_buffer_rsrc_t frags, scr;
+        __amdgpu_buffer_rsrc_t frags, scr, bias, w0p;  // bias / w0p: only where the constants are not in LDS
         unsigned lane16;                           // lane * 16: the only VGPR offset of the fragment traffic
         unsigned imgoff;                           // this lane's (rotated) 16-byte record inside a fragment record block of an S image
         char* tenZ;                                // wave's Z tensor (uniform); S images follow at +TENSOR_Z_B (+k*IMG_B)
         const char* cbias;                         // LDS constants: bias table + q * 16 (a lane holds accumulator rows 4q..4q+3)
         const char* cw0;                           // LDS constants: first-layer rows + q * 64
+        const float* blast;                        // output-layer bias (constants not in LDS)
         int c, q;
         bool tracer;                               // workgroup 0, chain wave 0, lane 0
         __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile) {
@@ -459,6 +469,11 @@ struct Fused {
         }
         __device__ __forceinline__ void init(const FusedArgs& a, char* lds, int slot, int lane, int c_, int q_) {
             frags = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.frags, 0, (int)a.frags_bytes, 0x00020000);
+            if constexpr (!CONST_LDS) {
+                bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.bias_mid, 0, (NL - 1) * WIDTH * 4, 0x00020000);
+                w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * 16, 0x00020000);
+                blast = a.pw.bias_last;
+            }
             lane16 = (unsigned)lane * 16u;
             tenZ = lds + slot * WAVE_B;
             cbias = lds + CONST_OFF + q_ * 16;
@@ -553,7 +568,12 @@ struct Fused {
     }
     // WS * bias of feature block mb of weight layer l (1..NL-1; l = NL, mb = 0: the output layer), from the LDS table
     static __device__ __forceinline__ f32x4 load_bias(const Ctx& x, int l, int mb) {
-        return *reinterpret_cast<const f32x4*>(x.cbias + ((l - 1) * WIDTH + 16 * mb) * 4);
+        if constexpr (CONST_LDS) {
+            return *reinterpret_cast<const f32x4*>(x.cbias + ((l - 1) * WIDTH + 16 * mb) * 4);
+        } else {
+            if (l == NL) return *reinterpret_cast<const f32x4*>(x.blast + 4 * x.q) * WS;
+            return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x.bias, (unsigned)x.q * 16u, ((l - 1) * WIDTH + 16 * mb) * 4, 0)) * WS;
+        }
     }
 
     // state fragments (hi, unscaled lo) of feature block MB from per-point values
@@ -593,7 +613,12 @@ struct Fused {
     template <int KSF>
     static __device__ __forceinline__ void operands_ready(u32x4 (&F)[NS][1][KSF][NP], int kk) {
 #if defined(__AMDGCN__)
-        if constexpr (NS == 4 && NP == 2)
+        if constexpr (NS == 5 && NP == 2)
+            asm volatile("s_nop 1" : "+v"(F[0][0][kk][0]), "+v"(F[0][0][kk][1]), "+v"(F[1][0][kk][0]), "+v"(F[1][0][kk][1]), "+v"(F[2][0][kk][0]),
+                                     "+v"(F[2][0][kk][1]), "+v"(F[3][0][kk][0]), "+v"(F[3][0][kk][1]), "+v"(F[4][0][kk][0]), "+v"(F[4][0][kk][1]));
+        else if constexpr (NS == 5)
+            asm volatile("s_nop 1" : "+v"(F[0][0][kk][0]), "+v"(F[1][0][kk][0]), "+v"(F[2][0][kk][0]), "+v"(F[3][0][kk][0]), "+v"(F[4][0][kk][0]));
+        else if constexpr (NS == 4 && NP == 2)
             asm volatile("s_nop 1" : "+v"(F[0][0][kk][0]), "+v"(F[0][0][kk][1]), "+v"(F[1][0][kk][0]), "+v"(F[1][0][kk][1]),
                                      "+v"(F[2][0][kk][0]), "+v"(F[2][0][kk][1]), "+v"(F[3][0][kk][0]), "+v"(F[3][0][kk][1]));
         else if constexpr (NS == 4) asm volatile("s_nop 1" : "+v"(F[0][0][kk][0]), "+v"(F[1][0][kk][0]), "+v"(F[2][0][kk][0]), "+v"(F[3][0][kk][0]));
@@ -612,7 +637,9 @@ struct Fused {
             tanh_scaled(acc[0][r], h, sds);
             vals[0][r] = h;
 #pragma unroll
-            for (int s = 1; s < NS; ++s) vals[s][r] = sds * acc[s][r];
+            for (int s = 1; s <= NT; ++s) vals[s][r] = sds * acc[s][r];
+            if constexpr (SECOND)                        // h_tt = (1-h^2) z_tt - 2 h h_t z_t   (z_t = acc[3] / WS)
+                vals[4][r] = sds * acc[4][r] - (2.0f * INV_WS) * h * vals[3][r] * acc[3][r];
         }
         emit_state<MB>(Bn, vals);
     }
@@ -623,12 +650,15 @@ struct Fused {
         float vals[NS][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(x.cw0 + (16 * MB + r) * 16);
+            f32x4 w;
+            if constexpr (CONST_LDS) w = *reinterpret_cast<const f32x4*>(x.cw0 + (16 * MB + r) * 16);
+            else w = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x.w0p, (unsigned)x.q * 64u, (16 * MB + r) * 16, 0));
             float h, sd;
             tanh_act(w[3] + w[0] * xin[0] + w[1] * xin[1] + w[2] * xin[2], h, sd);
             vals[0][r] = h;
 #pragma unroll
-            for (int s = 1; s < NS; ++s) vals[s][r] = sd * (a.sx[s - 1] * w[s - 1]);
+            for (int s = 1; s <= NT; ++s) vals[s][r] = sd * (a.sx[s - 1] * w[s - 1]);
+            if constexpr (SECOND) vals[4][r] = -2.0f * h * vals[3][r] * (a.sx[2] * w[2]);      // z_tt = 0 at the first layer
         }
         emit_state<MB>(Bn, vals);
         if constexpr (MB + 1 < WB) first_mb<MB + 1>(a, x, xin, Bn);
@@ -702,7 +732,8 @@ struct Fused {
     // needs before a vector instruction may read it.
     static __device__ __forceinline__ void mfma_results_ready(f32x4 (&acc)[NS]) {
 #if defined(__AMDGCN__)
-        if constexpr (NS == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+        if constexpr (NS == 5) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
+        else if constexpr (NS == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
         else asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]));
 #endif
     }
@@ -721,7 +752,7 @@ struct Fused {
                 if constexpr (NS > 1) {
                     float dot = 0.0f;
 #pragma unroll
-                    for (int s = 1; s < NS; ++s)
+                    for (int s = 1; s <= NT; ++s)
                         dot = (r & 1) ? MixF16<Op>::template fma<1>(sp[s][r >> 1], acc[s][r], dot) : MixF16<Op>::template fma<0>(sp[s][r >> 1], acc[s][r], dot);
                     hd = (r & 1) ? MixF16<Op>::template fma<1>(hw, dot, 0.0f) : MixF16<Op>::template fma<0>(hw, dot, 0.0f);
                 }
@@ -730,13 +761,25 @@ struct Fused {
                 sds = (1.0f - h * h) * INV_WS;
                 float dot = 0.0f;
 #pragma unroll
-                for (int s = 1; s < NS; ++s)
+                for (int s = 1; s <= NT; ++s)
                     dot += acc[s][r] * cvt16<Op>((uint16_t)((r & 1) ? (sp[s][r >> 1] >> 16) : (sp[s][r >> 1] & 0xffffu)));
                 hd = h * dot;
             }
 #pragma unroll
-            for (int s = 1; s < NS; ++s) vals[s][0][r] = sds * acc[s][r];
-            vals[0][0][r] = NS > 1 ? sds * acc[0][r] - (2.0f * INV_WS) * hd : sds * acc[0][r];
+            for (int s = 1; s <= NT; ++s) vals[s][0][r] = sds * acc[s][r];
+            float zb = NS > 1 ? sds * acc[0][r] - (2.0f * INV_WS) * hd : sds * acc[0][r];
+            if constexpr (SECOND) {
+                // adjoint of h_tt = (1-h^2) z_tt - 2 h h_t z_t from post-activation state only:
+                //   d h_tt / d z = -2 h h_tt - 2 h_t^2,   d h_tt / d z_t = -4 h h_t,   d h_tt / d z_tt = 1 - h^2        (PLATE:417-419)
+                const float h = cvt16<Op>((uint16_t)((r & 1) ? (sp[0][r >> 1] >> 16) : (sp[0][r >> 1] & 0xffffu)));
+                const float ht = cvt16<Op>((uint16_t)((r & 1) ? (sp[3][r >> 1] >> 16) : (sp[3][r >> 1] & 0xffffu)));
+                const float htt = cvt16<Op>((uint16_t)((r & 1) ? (sp[4][r >> 1] >> 16) : (sp[4][r >> 1] & 0xffffu)));
+                const float httb = acc[4][r] * INV_WS;
+                vals[4][0][r] = sds * acc[4][r];
+                vals[3][0][r] -= 4.0f * h * ht * httb;
+                zb += httb * (-2.0f * h * htt - 2.0f * ht * ht);
+            }
+            vals[0][0][r] = zb;
         }
         CH::template emit<KS, MB>(Zn, vals, nullptr, WIDTH, c, q);
     }
@@ -901,7 +944,65 @@ struct Fused {
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int o = 0; o < 8; ++o) adj[s][o] = 0.0f;
-        if constexpr (NS == 4) {
+        if constexpr (HEAD == HEAD_PLATE) {
+            // composite F = P + D*N (PLATE:383-387) with product-rule derivatives, then net_f_sig PLATE:404-439
+            // outputs (u,v,s11,s22,s12); streams (value, x, y, t, tt); aux = [D|P][stream][field][n]
+            float D[5][5], F[5][5];
+#pragma unroll
+            for (int st = 0; st < 5; ++st)
+#pragma unroll
+                for (int o = 0; o < 5; ++o) {
+                    D[st][o] = a.aux[((long)(0 * 5 + st) * 5 + o) * a.n + pidx];
+                    F[st][o] = a.aux[((long)(1 * 5 + st) * 5 + o) * a.n + pidx];      // start from P
+                }
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                const float n0 = Y[0][o];
+                F[0][o] += D[0][o] * n0;
+#pragma unroll
+                for (int k = 1; k <= 3; ++k) F[k][o] += D[k][o] * n0 + D[0][o] * Y[k][o];
+                F[4][o] += D[4][o] * n0 + 2.0f * D[3][o] * Y[3][o] + D[0][o] * Y[4][o];
+            }
+            const float e11 = F[1][0], e22 = F[2][1], e12 = F[2][0] + F[1][1];
+            float f[5];
+            f[0] = F[1][2] + F[2][4] - a.rho * F[4][0];                       // f_u   PLATE:436
+            f[1] = F[2][3] + F[1][4] - a.rho * F[4][1];                       // f_v   PLATE:437
+            f[2] = F[0][2] - (a.c1 * e11 + a.c2 * e22);                       // f_s11 PLATE:421
+            f[3] = F[0][3] - (a.c2 * e11 + a.c1 * e22);                       // f_s22 PLATE:423
+            f[4] = F[0][4] - a.G * e12;                                       // f_s12 PLATE:422
+            float g[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) {
+                if (q == 0) lsum[i] += vm * f[i] * f[i];
+                g[i] = 2.0f * a.tw[i] * f[i] * vm;
+            }
+            float Fb[5][5];
+#pragma unroll
+            for (int st = 0; st < 5; ++st)
+#pragma unroll
+                for (int o = 0; o < 5; ++o) Fb[st][o] = 0.0f;
+            Fb[0][2] = g[2];
+            Fb[0][3] = g[3];
+            Fb[0][4] = g[4];
+            Fb[1][0] = -a.c1 * g[2] - a.c2 * g[3];
+            Fb[2][1] = -a.c2 * g[2] - a.c1 * g[3];
+            Fb[2][0] = -a.G * g[4];
+            Fb[1][1] = -a.G * g[4];
+            Fb[1][2] = g[0];
+            Fb[2][4] = g[0];
+            Fb[4][0] = -a.rho * g[0];
+            Fb[2][3] = g[1];
+            Fb[1][4] = g[1];
+            Fb[4][1] = -a.rho * g[1];
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                adj[0][o] = Fb[0][o] * D[0][o] + Fb[1][o] * D[1][o] + Fb[2][o] * D[2][o] + Fb[3][o] * D[3][o] + Fb[4][o] * D[4][o];
+                adj[1][o] = Fb[1][o] * D[0][o];
+                adj[2][o] = Fb[2][o] * D[0][o];
+                adj[3][o] = Fb[3][o] * D[0][o] + 2.0f * Fb[4][o] * D[3][o];
+                adj[4][o] = Fb[4][o] * D[0][o];
+            }
+        } else if constexpr (NS == 4) {
             const float e11 = Y[1][0], e22 = Y[2][1], e12 = Y[2][0] + Y[1][1];
             float f[7];
             f[0] = Y[1][4] + Y[2][6] - a.rho * Y[3][2];
@@ -1050,7 +1151,7 @@ struct Fused {
         __shared__ __attribute__((aligned(16))) char lds[LDS_B];
         const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
         const int wave8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // provably wave-uniform
-        {
+        if constexpr (CONST_LDS) {
             float* cst = reinterpret_cast<float*>(lds + CONST_OFF);
             for (int i = threadIdx.x; i < CONST_F; i += 512) {
                 float v;

@@ -343,6 +343,7 @@ struct Host {
             a.G = c.G;
             a.rho = c.rho;
             a.targets = nullptr;
+            a.aux = c.aux;
             float twmax = 0.0f;
             LossOuts lo = {{nullptr, nullptr, nullptr, nullptr}};
             int nsets = 1;
@@ -481,7 +482,11 @@ struct Host {
 
     // 5-stream family (plate): split-precision variants only
     static int plate_loss_grad(const Call& c) {
-        if constexpr (SPLIT == 3) return loss_grad<5, HEAD_PLATE>(c, 5);
+        if constexpr (SPLIT == 3) {
+            int rc = 0;
+            if (c.use_fused && try_fused<5>(c, &rc, 5)) return rc;      // padded width <= 64: five-stream instantiation of the fused kernel
+            return loss_grad<5, HEAD_PLATE>(c, 5);
+        }
         return PINN_ERR_PRECISION;
     }
     static int traction_loss_grad(const Call& c) {

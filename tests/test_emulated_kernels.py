@@ -183,6 +183,45 @@ def test_emulated_plate_entry_points(emu, lN, lD, n):
     assert rel(loss[:5], ((w / w.max()) * s3).sum(0)) < 2e-6 and rel(gradD, g3) < 2e-6
 
 
+@pytest.mark.parametrize("lN,n", [([3] + 4 * [24] + [5], 70),       # five streams, all layer states in LDS
+                                  ([3] + 8 * [30] + [5], 130),      # parked states + LDS-DMA, several workgroup steps
+                                  ([3] + 4 * [40] + [5], 40)])      # padded width 64: constants from memory (LDS is full)
+def test_emulated_plate_fused(emu, lN, n):
+    """The plate's loss + gradient through the five-stream instantiation of the fused kernel (second time derivative carried as a
+    fifth stream, composite head PLATE:358-439) against the float64 oracle, and the two-kernel path for the same call."""
+    from oracle import plate_oracle as pl
+    prec, LBp, UBp = "f16x3", [0, 0, 0], [0.5, 0.5, 10]
+    rng = np.random.default_rng(5)
+    lD = [3, 10, 10, 5]
+
+    def mk(l):
+        W, b = po.xavier_init(l, rng)
+        return po.pack_params(W, [0.2 * rng.standard_normal(x.shape) for x in b])
+
+    fN, fD, fP = mk(lN), mk(lD), mk(lD)
+    C = np.stack([rng.random(n) * 0.5, rng.random(n) * 0.5, rng.random(n) * 10], 1)
+    x, y, t = (C[:, k].astype(np.float32).copy() for k in range(3))
+    wsb = emu.workspace_bytes(lN, n, prec)
+    ws = aligned(wsb)
+    Dref, Pref = pl.net_streams(fD, lD, C[:, 0], C[:, 1], C[:, 2]), pl.net_streams(fP, lD, C[:, 0], C[:, 1], C[:, 2])
+    tw = np.array([10, 7, 13, 9, 11.0]) / n
+    ss, g, _ = pl.plate_loss_grad(fN, lN, C[:, 0], C[:, 1], C[:, 2], Dref, Pref, term_weights=tw)
+    frozen = np.ascontiguousarray(np.stack([Dref, Pref]).astype(np.float32))
+    pN = fN.astype(np.float32)
+    res = {}
+    for fused in (True, False):
+        emu.set_fused(fused)
+        loss, grad = np.full(8, np.nan, np.float32), np.full(pN.size, np.nan, np.float32)
+        emu.plate2d_loss_grad(pN.ctypes.data, lN, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, frozen.ctypes.data, 20.0, 0.25, 1.0,
+                              tw, loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+        res[fused] = (loss[:5].copy(), grad.copy())
+        # the fused kernel parks the layer states as fp16 high parts (DESIGN section 6): a 2^-12 rounding noise per state element
+        # that averages out as 1/sqrt(points) in the gradient -- 3e-5 at ~100 points, 5e-6 at 4096 (GPU tests use real sizes)
+        assert rel(loss[:5], ss) < 3e-6 and rel(grad, g) < (1e-4 if fused else 2e-6), fused
+    emu.set_fused(True)
+    assert rel(res[True][1], res[False][1].astype(np.float64)) < 1e-4
+
+
 def test_empty_and_ragged_batches_emulated(emu):
     """n = 0 is a valid empty batch (zero sums; gradient zeroed, or left alone when accumulating); sizes around the 16-point tile
     and the 64-point workgroup step go through both paths."""
