@@ -192,7 +192,7 @@ def main():
         step = lambda k: model.train(k, 1e-3)
         workload = (f"2D plate with hole (hard BC: composite P + D*N, nested u_tt, plane stress), 8x64 tanh MLP + frozen 4x20 distance / particular "
                     f"nets, {pts_per_rank} collocation pts per GPU + 9960 hole-traction pts, Adam step (BASELINE configs[2]; its L-BFGS stage runs "
-                    f"on the host over the same kernels); two-kernel path (the fused kernel covers the 4-stream wave head only); {PRECISION_NOTE}")
+                    f"on the host over the same kernels); collocation set through the five-stream fused kernel, hole traction through the two-kernel path; {PRECISION_NOTE}")
     else:
         from pinn_elastodynamics_amd.navier_cauchy_3d import NavierCauchy3D, halfspace_case
         c = halfspace_case(n_collo=n_global, n_ic=20000, n_top=20000, n_src=(200, 100), seed=1111, width=128, depth=10)
@@ -264,6 +264,30 @@ def main():
                                        "product in the forward / reverse chain and 2 in the weight gradient, so a 100 %-busy matrix pipe is frac 0.375. "
                                        "Measured limiter: the SIMD's instruction issue, not a pipe (DESIGN.md section 6). traffic is not measured in this "
                                        "run (PMC counters need rocprofv3); see traffic_from_profiles"}
+            out["kernel_ms_per_step"] = acc
+        elif cfg == "plate" and eng.lib.supported_width(layers[1]) <= 64 and len(layers) - 2 in (4, 8):
+            # ---- the five-stream instantiation of the fused kernel: HIP events around the kernel on the launch stream (process-wide
+            # profiling hook of the library, include/pinn_hip.h)
+            x, y, t = model._collo
+            tw = [1.0 / pts_per_rank] * 5
+            prof = eng.lib.set_profile_buffer(True)
+            acc = {"repack": 0.0, "chain": 0.0, "wgrad": 0.0, "reduce": 0.0}
+            reps = 5
+            for i in range(reps + 1):
+                eng.plate_loss_grad(model.theta["uv"], x, y, t, model.lb, model.ub, False, model._frozen_collo, tw, model.E, model.mu, model.rho)
+                if i > 0:
+                    for j, k in enumerate(acc):
+                        acc[k] += float(prof[j]) / reps
+            eng.lib.set_profile_buffer(False)
+            fused = acc["wgrad"] == 0.0
+            tflops = flop_pt * pts_per_rank / (acc["chain"] * 1e-3) / 1e12 if fused else 0.0
+            out["roofline"] = {"kernel": "fused_wave_kernel<..., NS = 5> (forward with the second time derivative + plate head + reverse chain + weight gradient)",
+                               "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
+                               "traffic": None, "launches_per_step": 1, "avg_launch_ms": acc["chain"], "algorithmic_flop_per_point": flop_pt,
+                               "issued_mfma_tflops": tflops * issued,
+                               "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
+                                       "gradient) / HIP-event launch time of the collocation launch; the hole-traction set (9960 points) runs on the "
+                                       "two-kernel path.  traffic not measured in this run"}
             out["kernel_ms_per_step"] = acc
         else:
             # two-kernel path: the step is a sequence of chain + weight-gradient launches over workspace passes; report the whole step

@@ -214,6 +214,11 @@ int pinn_debug_set_fused(int enable);
 /* Profiling hook (process-wide): device buffer of 128 uint64 that the fused kernel fills with shader-clock
  * stamps of its phases (workgroup 0 only); NULL turns it off. */
 void pinn_debug_set_stamp_buffer(void* device_u64x128);
+/* Profiling hook (process-wide): host array of 4 floats; while set, every loss+gradient call brackets its kernels with HIP
+ * events on the call's stream, synchronises, and writes milliseconds {repack, chain (or the whole fused kernel), weight gradient,
+ * reductions} of that call (what pinn_wave2d_loss_grad_profile does for one entry point, here for all of them: bench.py's
+ * roofline of the plate / 3-D kernels).  NULL turns it off. */
+void pinn_debug_set_profile_buffer(float* host_ms4);
 
 const char* pinn_error_string(int code);
 int pinn_abi_version(void);

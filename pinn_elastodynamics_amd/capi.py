@@ -113,6 +113,18 @@ class PinnLib:
     def abi_version(self) -> int:
         return self.lib.pinn_abi_version()
 
+    def set_profile_buffer(self, enable: bool):
+        """Process-wide profiling hook: while on, every loss+gradient call writes its kernel milliseconds {repack, chain or whole
+        fused kernel, weight gradient, reductions} into the returned float32[4] (and synchronises the stream)."""
+        import numpy as _np
+        if enable:
+            self._prof = _np.zeros(4, dtype=_np.float32)
+            self.lib.pinn_debug_set_profile_buffer(C.c_void_p(self._prof.ctypes.data))
+            return self._prof
+        self.lib.pinn_debug_set_profile_buffer(None)
+        self._prof = None
+        return None
+
     def set_fused(self, enable: bool) -> bool:
         return bool(self.lib.pinn_debug_set_fused(int(bool(enable))))
 

@@ -75,12 +75,14 @@ using namespace pinn;
 
 static int g_use_fused = 1;
 static unsigned long long* g_dbg_stamps = nullptr;
+static float* g_prof_ms = nullptr;
 
 extern "C" {
 
 int pinn_abi_version(void) { return 1; }
 
 void pinn_debug_set_stamp_buffer(void* device_u64x128) { g_dbg_stamps = static_cast<unsigned long long*>(device_u64x128); }
+void pinn_debug_set_profile_buffer(float* host_ms4) { g_prof_ms = host_ms4; }
 
 int pinn_debug_set_fused(int enable) {
     const int old = g_use_fused;
@@ -154,7 +156,7 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     c.aux = nullptr;
     for (int i = 0; i < 5; ++i)
         for (int o = 0; o < 8; ++o) c.w5[i][o] = 0.0f;
-    c.prof_ms = nullptr;
+    c.prof_ms = g_prof_ms;
     c.use_fused = g_use_fused;
     c.dbg_stamps = g_dbg_stamps;
     return PINN_OK;
@@ -207,7 +209,7 @@ static int wave2d_loss_grad_impl(const float* params_flat, const int* layers, in
     c.loss_out = loss_terms_out;
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
-    c.prof_ms = prof_ms;
+    if (prof_ms) c.prof_ms = prof_ms;
     if (n == 0) return empty_batch(c, 7);
     return impl->wave_loss_grad(c);
 }

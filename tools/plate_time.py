@@ -30,3 +30,16 @@ for fused in (True, False):
         eng.plate_loss_grad(th, *xs, [0, 0, 0], [0.5, 0.5, 10], False, frozen, tw)
     torch.cuda.synchronize()
     print(f"{'fused' if fused else 'two-kernel'}: {(time.perf_counter() - t0) * 100:.2f} ms per 1 M points; loss err {e[0]:.1e} grad err {e[1]:.1e} (8192 points vs oracle)", flush=True)
+eng.lib.set_fused(True)
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(12)]
+for i in range(11):
+    ev[i].record()
+    eng.plate_loss_grad(th, *xs, [0, 0, 0], [0.5, 0.5, 10], False, frozen, tw)
+ev[11].record(); torch.cuda.synchronize()
+print('fused, per-call event times (ms):', ' '.join(f'{ev[i].elapsed_time(ev[i+1]):.2f}' for i in range(11)))
+for nn in (250_000, 500_000):
+    a = [v[:nn].contiguous() for v in xs]; fz2 = frozen[:, :, :, :nn].contiguous()
+    for _ in range(3): eng.plate_loss_grad(th, *a, [0, 0, 0], [0.5, 0.5, 10], False, fz2, tw)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): eng.plate_loss_grad(th, *a, [0, 0, 0], [0.5, 0.5, 10], False, fz2, tw)
+    torch.cuda.synchronize(); print(f'fused {nn} points: {(time.perf_counter() - t0) * 100:.2f} ms')
