@@ -234,6 +234,11 @@ struct RepackArgs {
     u32x4* frags_fused;        // second copy in the fused kernel's format (see repack_kernel), or nullptr
 };
 
+typedef short v4i16 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
 // k-slot -> feature permutation shared by every A/B fragment pair of the chain
 __host__ __device__ __forceinline__ int kmap(int kk, int q, int j) { return 32 * kk + 16 * (j >> 2) + 4 * q + (j & 3); }
 
@@ -256,6 +261,8 @@ struct FragIndex {
 // Panel geometry inside one tile record (units: 16-bit elements).  TP = points per tile.
 //   S panels: layer 0 has 16 rows (the inputs), layers 1..nl have WIDTH rows (hidden states h_l)
 //   Z panels: layers 0..nl-1 have WIDTH rows (adjoints of the pre-activations), layer nl has 16 rows
+// Both keep the high and the scaled low part: this path is the accurate one (gradient 2e-7 from the float64 oracle at fresh weights;
+// the fused kernel parks its state as high parts only and trades a 1/sqrt(points) rounding noise for LDS room).
 template <int WIDTH, int NB, int NS, int NP>
 struct PanelGeom {
     static constexpr int TP = 16 * NB;
@@ -422,6 +429,37 @@ struct Chain {
         }
     }
 
+    // Spill of a chain-layout tensor to its [stream][part][feature row][point] panel with WIDE stores.  A lane holds, for its point,
+    // four features of two 16-feature blocks per fragment register quad -- written element by element that is eight 2-byte stores
+    // per lane and fragment, and the chain kernel was bound by its own store instructions (round 2: 30 % of its time).  Instead the
+    // fragment goes through a 1 KB per-wave LDS record (one ds_write_b128 per lane, lane records rotated as in the fused kernel)
+    // and comes back transposed by ds_read_b64_tr_b16: lane (c, q) then holds feature row c of block (q >> 1), points 8 (q & 1)..+7
+    // = 16 contiguous bytes of the panel; the 64 lanes of one store cover 1 KB of consecutive rows.
+    static __device__ __forceinline__ unsigned img_record(int point, int qq) { return (unsigned)((((point + 4 * qq) & 15) + 16 * qq) * 16); }
+    template <int KSF, int PARTS>
+    static __device__ __forceinline__ void spill_frags(char* rec, const u32x4 (&F)[NS][NB][KSF][NP], uint16_t* panel, int rows, int c, int q) {
+        char* wr = rec + img_record(c, q);
+        const int p0 = 8 * (q & 1) + (c >> 2), sub = c & 3;
+        const char* r0 = rec + img_record(p0, sub) + 8 * (q >> 1);
+        const char* r1 = rec + img_record(p0 + 4, sub) + 8 * (q >> 1);
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int kk = 0; kk < KSF; ++kk)
+#pragma unroll
+                    for (int p = 0; p < PARTS; ++p) {
+                        *reinterpret_cast<u32x4*>(wr) = F[s][nb][kk][p];
+                        const v4i16 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)r0);
+                        const v4i16 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16*)r1);
+                        const u32x2 d0 = __builtin_bit_cast(u32x2, v0), d1 = __builtin_bit_cast(u32x2, v1);
+                        const int row = 32 * kk + 16 * (q >> 1) + c;
+                        if (row < rows)
+                            *reinterpret_cast<u32x4*>(panel + ((long)(s * PARTS + p) * rows + row) * TP + 16 * nb + 8 * (q & 1)) = u32x4{d0[0], d0[1], d1[0], d1[1]};
+                    }
+    }
+
     // acc[s][nb] (+ corr) = A(mb) . B over KSB k-steps
     // FENCE (first block of a layer): the operand fragments were just written by emit()'s inline assembly, and hipcc pads the
     // "vector write -> MFMA operand read" wait states only between instructions it knows.  The fragments written last (k-step
@@ -467,6 +505,9 @@ struct Chain {
     }
 
     // load the stored state (h, hdot_k) of one feature block from the S panel of layer l
+    // this lane's state values (features 16 MB + 4q + r of its point) from the S panel.  (Measured in round 2: keeping a second copy
+    // of the states as register images for this read -- one 8-byte load instead of four 2-byte ones -- is SLOWER, 24.0 against
+    // 21.4 ms per 1 M points for the 8x80 net: this path is bound by the bytes it spills, not by its load instructions.)
     template <int MB>
     static __device__ __forceinline__ void load_state(const uint16_t* panel, int c, int q, float (&st)[NS][NB][4]) {
 #pragma unroll
@@ -595,6 +636,8 @@ struct Chain {
         const int nl = a.net.nl;
         constexpr bool FWD_ONLY = HEAD == HEAD_FIELDS || HEAD == HEAD_FIELDS3D;
         constexpr bool SPILL = !FWD_ONLY;
+        __shared__ __attribute__((aligned(16))) char spill_lds[4 * 1024];      // one 1 KB transpose record per wave (256-thread blocks)
+        char* rec = spill_lds + (threadIdx.x >> 6) * 1024;
         float lsum[LT];
 #pragma unroll
         for (int i = 0; i < LT; ++i) lsum[i] = 0.0f;
@@ -632,16 +675,24 @@ struct Chain {
                             if (q == 0 && r < DIN && s <= NT) v = (s == 0) ? xin[nb][r] : (r == s - 1 ? a.sx[r] : 0.0f);
                             v0[s][nb][r] = v;
                         }
-                u32x4 dummy[NS][NB][1][NP];
-                emit<1, 0>(dummy, v0, St + PG::s_off(0), 16, c, q);
+                u32x4 S0[NS][NB][1][NP];
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                        for (int p = 0; p < NP; ++p) S0[s][nb][0][p] = u32x4{0u, 0u, 0u, 0u};
+                emit<1, 0>(S0, v0, nullptr, 16, c, q);
+                spill_frags<1, NP>(rec, S0, St + PG::s_off(0), 16, c, q);
             }
             // ---- forward
             u32x4 B[NS][NB][KS][NP];
-            MbLoop<0>::first(a, xin, B, SPILL ? St + PG::s_off(1) : nullptr, c, q);
+            MbLoop<0>::first(a, xin, B, nullptr, c, q);
+            if (SPILL) spill_frags<KS, NP>(rec, B, St + PG::s_off(1), WIDTH, c, q);
             for (int l = 1; l < nl; ++l) {
                 u32x4 Bn[NS][NB][KS][NP];
-                MbLoop<0>::fwd(a.pw.frags + (long)FI::fwd_mid(l, 0, 0) * NPS * 64, a.pw.bias_mid + (long)(l - 1) * WIDTH, lane, B, Bn,
-                               SPILL ? St + PG::s_off(l + 1) : nullptr, c, q);
+                MbLoop<0>::fwd(a.pw.frags + (long)FI::fwd_mid(l, 0, 0) * NPS * 64, a.pw.bias_mid + (long)(l - 1) * WIDTH, lane, B, Bn, nullptr, c, q);
+                if (SPILL) spill_frags<KS, NP>(rec, Bn, St + PG::s_off(l + 1), WIDTH, c, q);
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -923,16 +974,17 @@ struct Chain {
                         for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                             for (int p = 0; p < NP; ++p) ZL[s][nb][0][p] = u32x4{0u, 0u, 0u, 0u};
-                    emit<1, 0>(ZL, vals, Zt + PG::z_off(nl), 16, c, q);
+                    emit<1, 0>(ZL, vals, nullptr, 16, c, q);
+                    spill_frags<1, NP>(rec, ZL, Zt + PG::z_off(nl), 16, c, q);
                 }
                 // ---- reverse chain
                 u32x4 Zc[NS][NB][KS][NP];
-                MbLoop<0>::template bwd<1>(a.pw.frags + (long)FI::bwd_last(nl, 0) * NPS * 64, lane, ZL, St + PG::s_off(nl), Zc,
-                                           Zt + PG::z_off(nl - 1), c, q);
+                MbLoop<0>::template bwd<1>(a.pw.frags + (long)FI::bwd_last(nl, 0) * NPS * 64, lane, ZL, St + PG::s_off(nl), Zc, nullptr, c, q);
+                spill_frags<KS, NP>(rec, Zc, Zt + PG::z_off(nl - 1), WIDTH, c, q);
                 for (int l = nl - 1; l >= 1; --l) {
                     u32x4 Zn[NS][NB][KS][NP];
-                    MbLoop<0>::template bwd<KS>(a.pw.frags + (long)FI::bwd_mid(nl, l, 0, 0) * NPS * 64, lane, Zc, St + PG::s_off(l), Zn,
-                                                Zt + PG::z_off(l - 1), c, q);
+                    MbLoop<0>::template bwd<KS>(a.pw.frags + (long)FI::bwd_mid(nl, l, 0, 0) * NPS * 64, lane, Zc, St + PG::s_off(l), Zn, nullptr, c, q);
+                    spill_frags<KS, NP>(rec, Zn, Zt + PG::z_off(l - 1), WIDTH, c, q);
 #pragma unroll
                     for (int s = 0; s < NS; ++s)
 #pragma unroll

@@ -35,10 +35,6 @@
 
 namespace pinn {
 
-typedef short v4i16 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) v4i16 lds_v4i16;
-typedef __attribute__((address_space(3))) void lds_void;
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int FUSED_MAX_SETS = 4;
 
