@@ -79,6 +79,38 @@ def test_plate_entry_points_xavier(dev, lN, lD, n):
     assert rel(s3.cpu().numpy(), ((w / w.max()) * s3_o).sum(0)) < 5e-5 and rel(g3.cpu().numpy(), g3_o) < 5e-5
 
 
+@pytest.mark.parametrize("lN,n", [([3] + 8 * [64] + [5], 50000), ([3] + 4 * [40] + [5], 8192), ([3] + 8 * [30] + [5], 8192), ([3] + 4 * [24] + [5], 4099)])
+def test_plate_fused_kernel_against_oracle_and_two_kernel_path(dev, lN, n):
+    """pinn_plate2d_loss_grad takes the five-stream instantiation of the fused kernel for padded width <= 64 and 4 / 8 hidden layers
+    (second time derivative as a fifth stream, composite head PLATE:358-439 in the kernel).  Same numbers as the float64 oracle (on a
+    subsample: the whole set would take the CPU minutes) and as the two-kernel path for the same call, within the rounding noise of
+    the fused kernel's fp16-parked state (it averages out as 1/sqrt(points))."""
+    from pinn_elastodynamics_amd.hip_engine import HipEngine
+    rng = np.random.default_rng(9)
+    fN = rand_net(lN, rng)
+    C = np.stack([rng.random(n) * 0.5, rng.random(n) * 0.5, rng.random(n) * 10], 1)
+    xs = [to_dev(C[:, k], dev) for k in range(3)]
+    frozen_h = rng.standard_normal((2, 5, 5, n)) * np.array([1.0, 2.0, 2.0, 0.2, 0.05])[None, :, None, None]
+    frozen = to_dev(frozen_h, dev)
+    eng = HipEngine(lN, precision="f16x3", device=dev, max_points=n)
+    th = to_dev(fN, dev)
+    tw = (np.array([1.0, 0.7, 1.3, 0.9, 1.1]) * 10.0 / n).tolist()
+    res = {}
+    for fused in (True, False):
+        eng.lib.set_fused(fused)
+        try:
+            l, g = eng.plate_loss_grad(th, *xs, LB, UB, False, frozen, tw)
+            res[fused] = (l.cpu().numpy().astype(np.float64), g.cpu().numpy().astype(np.float64))
+        finally:
+            eng.lib.set_fused(True)
+    assert rel(res[True][0], res[False][0]) < 2e-6 and rel(res[True][1], res[False][1]) < 2e-5
+    m = min(n, 6000)
+    f32 = frozen_h[:, :, :, :m].astype(np.float32).astype(np.float64)
+    ss, go, _ = pl.plate_loss_grad(fN, lN, C[:m, 0], C[:m, 1], C[:m, 2], f32[0], f32[1], term_weights=np.array(tw) * n / m)
+    l, g = eng.plate_loss_grad(th, *(v[:m].contiguous() for v in xs), LB, UB, False, frozen[:, :, :, :m].contiguous(), (np.array(tw) * n / m).tolist())
+    assert rel(l.cpu().numpy(), ss) < 5e-6 and rel(g.cpu().numpy(), go) < 3e-5
+
+
 def test_plate_reference_weights_golden(dev, golden_dir):
     g = np.load(f"{golden_dir}/golden_plate.npz")
     flat, eng = {}, {}
