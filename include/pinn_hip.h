@@ -33,6 +33,8 @@ enum {
     PINN_PREC_F16X3 = 1,  /* fp16 hi + scaled-lo split, three MFMAs per product: fp32-class accuracy */
     PINN_PREC_F16 = 2,    /* fp16 operands, one MFMA per product */
     PINN_PREC_BF16X3 = 3, /* bf16 hi/lo split, three MFMAs per product (16-bit significand) */
+    PINN_PREC_FP32 = 4,   /* plain fp32 FMA arithmetic, no matrix pipe (the reference's own precision, INF:71-92): ~100x slower,
+                             for parity checks; pinn_wave2d_loss_grad, pinn_data_loss_grad(_multi), pinn_wave2d_fields only */
     /* OR this into precision_mode when the PREVIOUS call on the same workspace used the same params_flat contents, layers and
      * mode: the packed MFMA weight fragments are still in the workspace and the repack launch is skipped (the reference feeds
      * one set of variables to every loss term of a step, INF:297-305; a step makes 3-4 calls). */

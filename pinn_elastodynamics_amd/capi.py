@@ -8,7 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-PREC = {"bf16": 0, "f16x3": 1, "f16": 2, "bf16x3": 3}
+PREC = {"bf16": 0, "f16x3": 1, "f16": 2, "bf16x3": 3, "fp32": 4}
 FLAG_WEIGHTS_PACKED = 0x100
 def adjoint_shift(k: int) -> int:
     """PINN_ADJOINT_SHIFT(k) of include/pinn_hip.h"""

@@ -1,6 +1,7 @@
 // extern "C" entry points of libpinn_hip.so (declared in include/pinn_hip.h): argument checking,
 // decoding into pinn::Call, and dispatch to the kernel family for (precision_mode, hidden width).
 #include "pinn_host.hpp"
+#include "pinn_fp32.hpp"
 
 #ifndef PINN_VARIANTS_DEF
 #define PINN_VARIANTS_DEF "pinn_variants.def"     // experiments (tools/exp_build.sh) build a one-variant library
@@ -128,12 +129,13 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     c.weights_packed = (precision_mode & PINN_FLAG_WEIGHTS_PACKED) ? 1 : 0;
     c.adj_shift = (precision_mode >> 16) & 0x1f;
     precision_mode &= ~(PINN_FLAG_WEIGHTS_PACKED | (0x1f << 16));
-    if (precision_mode < 0 || precision_mode > 3) return PINN_ERR_PRECISION;
+    if (precision_mode < 0 || precision_mode > PINN_PREC_FP32) return PINN_ERR_PRECISION;
     int width = 0;
     const int rc = decode_net(layers, n_layers, c.net, width, din);
     if (rc) return rc;
-    impl = find_impl(precision_mode, width);
-    if (!impl) return PINN_ERR_LAYERS;
+    // PINN_PREC_FP32 has no kernel family: impl stays NULL and the entry points that offer the mode branch to fp32_call()
+    impl = precision_mode == PINN_PREC_FP32 ? nullptr : find_impl(precision_mode, width);
+    if (!impl && precision_mode != PINN_PREC_FP32) return PINN_ERR_LAYERS;
     c.params = params;
     c.z = z;
     c.nsets = 0;
@@ -169,6 +171,7 @@ size_t pinn_workspace_bytes(const int* layers, int n_layers, int64_t n, int prec
     NetDesc net;
     int width = 0;
     if (n <= 0 || !layers || decode_net(layers, n_layers, net, width, layers[0] == 4 ? 4 : 3)) return 0;
+    if (mode_only(precision_mode) == PINN_PREC_FP32) return align_up(fp32_bytes_per_point(net, FP32_MAX_NS) * (size_t)(n < 256 ? 256 : (n < 65536 ? n : 65536)), 256);
     const Impl* impl = find_impl(mode_only(precision_mode), width);
     return impl ? impl->ws_bytes(net, (long)n, 0) : 0;
 }
@@ -177,8 +180,56 @@ size_t pinn_min_workspace_bytes(const int* layers, int n_layers, int precision_m
     NetDesc net;
     int width = 0;
     if (!layers || decode_net(layers, n_layers, net, width, layers[0] == 4 ? 4 : 3)) return 0;
+    if (mode_only(precision_mode) == PINN_PREC_FP32) return align_up(fp32_bytes_per_point(net, FP32_MAX_NS) * (size_t)256, 256);
     const Impl* impl = find_impl(mode_only(precision_mode), width);
     return impl ? impl->ws_bytes(net, 1L << 40, 1) : 0;
+}
+
+// PINN_PREC_FP32: plain fp32 arithmetic (pinn_fp32.hpp), the points walked in as many passes as the workspace holds
+static int fp32_call(const Call& c, int head, int nterms) {
+    hipStream_t st = c.stream;
+    const int ns = head == HEAD_DATA ? 1 : 4;
+    const size_t per_point = fp32_bytes_per_point(c.net, ns);
+    if (((uintptr_t)c.ws & 255) != 0 || c.ws_bytes < per_point * 256) return PINN_ERR_WORKSPACE;
+    long mmax = (long)(c.ws_bytes / per_point);
+    if (mmax > (1L << 20)) mmax = 1L << 20;
+    Fp32Args a;
+    a.net = c.net;
+    a.params = c.params;
+    a.x = c.x;
+    a.y = c.y;
+    a.t = c.t;
+    a.n = c.n;
+    for (int k = 0; k < 3; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
+    a.c1 = c.c1;
+    a.c2 = c.c2;
+    a.G = c.G;
+    a.rho = c.rho;
+    for (int i = 0; i < 8; ++i) a.tw[i] = c.tw[i];
+    a.targets = c.targets;
+    a.fields_out = c.fields_out;
+    a.ns = ns;
+    a.hr = c.net.h > 16 ? c.net.h : 16;
+    a.head = head;
+    int pass = 0;
+    for (long p0 = 0; p0 < c.n; p0 += mmax, ++pass) {
+        a.p0 = p0;
+        a.m = c.n - p0 < mmax ? c.n - p0 : mmax;
+        const size_t tensor = (size_t)(c.net.nl + 1) * ns * a.hr * a.m;
+        a.S = static_cast<float*>(c.ws);
+        a.Z = a.S + tensor;
+        a.fsq = a.Z + tensor;
+        int blocks = (int)((a.m + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(fp32_chain_kernel, dim3(blocks), dim3(256), 0, st, a);
+        if (head != HEAD_FIELDS) {
+            hipLaunchKernelGGL(fp32_sum_kernel, dim3(nterms), dim3(256), 0, st, (const float*)a.fsq, a.m, c.loss_out, pass > 0 ? 1 : 0);
+            hipLaunchKernelGGL(fp32_wgrad_kernel, dim3((c.net.nparams + 255) / 256), dim3(256), 0, st, a, c.grad_out, (c.accumulate || pass > 0) ? 1 : 0);
+        }
+        const int rc = (int)hipGetLastError();
+        if (rc) return rc;
+    }
+    return PINN_OK;
 }
 
 static int wave2d_loss_grad_impl(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
@@ -211,6 +262,7 @@ static int wave2d_loss_grad_impl(const float* params_flat, const int* layers, in
     c.accumulate = accumulate;
     if (prof_ms) c.prof_ms = prof_ms;
     if (n == 0) return empty_batch(c, 7);
+    if (!impl) return fp32_call(c, HEAD_WAVE, 7);
     return impl->wave_loss_grad(c);
 }
 
@@ -246,6 +298,7 @@ int pinn_data_loss_grad(const float* params_flat, const int* layers, int n_layer
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, c.net.nout);
+    if (!impl) return fp32_call(c, HEAD_DATA, c.net.nout);
     return impl->data_loss_grad(c);
 }
 
@@ -286,6 +339,25 @@ int pinn_data_loss_grad_multi(const float* params_flat, const int* layers, int n
         if (!accumulate) return (int)hipMemsetAsync(grad_flat_out, 0, (size_t)c.net.nparams * sizeof(float), st);
         return 0;
     }
+    if (!impl) {            // PINN_PREC_FP32: one set after the other into the same gradient
+        bool first_set = true;
+        for (int k = 0; k < n_sets; ++k) {
+            if (sets[k].n <= 0) continue;
+            Call s1 = c;
+            s1.nsets = 0;
+            s1.x = sets[k].x;
+            s1.y = sets[k].y;
+            s1.t = sets[k].t;
+            s1.n = (long)sets[k].n;
+            s1.targets = sets[k].targets;
+            for (int i = 0; i < 8; ++i) s1.tw[i] = c.sets[k].tw[i];
+            s1.loss_out = sets[k].loss_terms_out;
+            s1.accumulate = accumulate || !first_set;
+            if ((rc = fp32_call(s1, HEAD_DATA, c.net.nout))) return rc;
+            first_set = false;
+        }
+        return PINN_OK;
+    }
     return impl->data_loss_grad(c);
 }
 
@@ -299,6 +371,7 @@ int pinn_wave2d_fields(const float* params_flat, const int* layers, int n_layers
     if (n > 0 && !fields_out) return PINN_ERR_NULL;
     c.fields_out = fields_out;
     if (n == 0) return 0;
+    if (!impl) return fp32_call(c, HEAD_FIELDS, 0);
     return impl->fields(c);
 }
 
@@ -312,6 +385,7 @@ int pinn_net_streams(const float* params_flat, const int* layers, int n_layers, 
     if (n > 0 && !streams_out) return PINN_ERR_NULL;
     c.fields_out = streams_out;
     if (n == 0) return 0;
+    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
     return impl->streams(c);
 }
 
@@ -335,6 +409,7 @@ int pinn_plate2d_loss_grad(const float* params_flat, const int* layers, int n_la
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, 5);
+    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
     return impl->plate_loss_grad(c);
 }
 
@@ -356,6 +431,7 @@ int pinn_plate2d_traction_loss_grad(const float* params_flat, const int* layers,
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, 2);
+    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
     return impl->traction_loss_grad(c);
 }
 
@@ -375,6 +451,7 @@ int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_lay
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, c.net.nout);
+    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
     return impl->stream_loss_grad(c);
 }
 
@@ -399,6 +476,7 @@ int pinn_nc3d_loss_grad(const float* params_flat, const int* layers, int n_layer
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, 12);
+    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
     return impl->nc3d_loss_grad(c);
 }
 
@@ -417,6 +495,7 @@ int pinn_nc3d_data_loss_grad(const float* params_flat, const int* layers, int n_
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, c.net.nout);
+    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
     return impl->nc3d_data_loss_grad(c);
 }
 
@@ -430,6 +509,7 @@ int pinn_nc3d_fields(const float* params_flat, const int* layers, int n_layers, 
     if (n > 0 && !fields_out) return PINN_ERR_NULL;
     c.fields_out = fields_out;
     if (n == 0) return 0;
+    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
     return impl->nc3d_fields(c);
 }
 

@@ -118,6 +118,39 @@ def test_data_term_and_fields_emulated(emu):
     assert rel(fo, ref) < 2e-6
 
 
+def test_fp32_mode_emulated(emu):
+    """PINN_PREC_FP32: the same entry points in plain fp32 arithmetic (no matrix pipe, no 16-bit operand) -- the on-device third leg
+    of the parity tests.  Loss sums, gradient (several workspace passes, accumulate flag), data term and fields against the oracle."""
+    layers = [3] + 3 * [20] + [7]
+    e_loss, e_grad = run_wave(emu, layers, 150, "fp32")
+    assert e_loss < 5e-6 and e_grad < 5e-6
+    e_loss, e_grad = run_wave(emu, layers, 700, "fp32", min_ws=True, normalize=False)      # 256-point passes
+    assert e_loss < 5e-6 and e_grad < 5e-6
+    rng = np.random.default_rng(5)
+    Ws, bs = po.xavier_init(layers, rng)
+    flat = po.pack_params(Ws, [0.3 * rng.standard_normal(b.shape) for b in bs])
+    n = 75
+    X = -15 + 30 * rng.random((n, 3))
+    tgt = rng.standard_normal((n, 7))
+    ow = np.array([1, 1, 0, 0, 0, 2, 0.5]) / n
+    ss, g, _ = po.data_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, False, tgt, ow)
+    p32 = flat.astype(np.float32)
+    x, y, t = (X[:, k].astype(np.float32).copy() for k in range(3))
+    tg = np.ascontiguousarray(tgt.T.astype(np.float32))
+    wsb = emu.workspace_bytes(layers, n, "fp32")
+    ws = aligned(wsb)
+    loss = np.zeros(8, np.float32)
+    grad = np.ones(p32.size, np.float32)
+    emu.data_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, False, tg.ctypes.data, ow,
+                       loss.ctypes.data, grad.ctypes.data, True, "fp32", ws.ctypes.data, wsb)          # accumulate onto ones
+    assert rel(loss[:7], ss) < 5e-6 and rel(grad - 1.0, g) < 5e-6
+    out = po.wave2d_fields(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, False)
+    fo = np.zeros((28, n), np.float32)
+    emu.wave2d_fields(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, False, fo.ctypes.data, "fp32",
+                      ws.ctypes.data, wsb)
+    assert rel(fo, np.concatenate([out["Y"].T] + [d.T for d in out["dY"]])) < 5e-6
+
+
 def test_adam_emulated(emu):
     rng = np.random.default_rng(6)
     P = 1000
