@@ -8,7 +8,8 @@ cd /tmp; export TMPDIR=/tmp
 i=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY" "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU" \
-           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_IFETCH"; do
+           "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_IFETCH" \
+           "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
   rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p -- python $GRAFT_REPO_ROOT/tools/exp_run.py $NAME > $OUT/p$i.log 2>&1
 done
@@ -32,6 +33,11 @@ with open('$OUT/summary.txt', 'w') as o:
 if 'FETCH_SIZE_median_per_launch' in js and 'WRITE_SIZE_median_per_launch' in js:
     # FETCH_SIZE / WRITE_SIZE count KB; gfx950: streamed 16-byte reads are under-counted by 2 (MI355X_MICROARCH.md)
     js['hbm_bytes_per_launch'] = 1024.0 * (2.0 * js['FETCH_SIZE_median_per_launch'] + js['WRITE_SIZE_median_per_launch'])
+g = lambda k: js.get(k + '_median_per_launch')
+if g('TCC_EA0_RDREQ_sum') is not None and g('TCC_EA0_WRREQ_sum') is not None:
+    # exact request sizes on the L2 <-> fabric interface: 32-byte and 64-byte requests counted separately
+    js['ea_read_bytes_per_launch'] = 32.0 * g('TCC_EA0_RDREQ_32B_sum') + 64.0 * (g('TCC_EA0_RDREQ_sum') - g('TCC_EA0_RDREQ_32B_sum'))
+    js['ea_write_bytes_per_launch'] = 64.0 * g('TCC_EA0_WRREQ_64B_sum') + 32.0 * (g('TCC_EA0_WRREQ_sum') - g('TCC_EA0_WRREQ_64B_sum'))
 js['note'] = ('fused_wave_kernel<OpF16,3,64,8,4>, 2,000,000 points per launch (tools/pmc_collect.sh on tools/exp_run.py; one rocprofv3 --pmc pass per '
               'group of <= 4 counters, --kernel-trace only). FETCH_SIZE/WRITE_SIZE are in KB; hbm_bytes = 2*FETCH (gfx950 correction) + WRITE. These '
               'L2<->fabric counters include Infinity-Cache hits.')
