@@ -33,6 +33,10 @@
 #pragma once
 #include "pinn_device.hpp"
 
+#ifndef PINN_X_PIPE
+#define PINN_X_PIPE 0
+#endif
+
 namespace pinn {
 
 
@@ -116,19 +120,26 @@ struct Fused {
     static constexpr int CONST_USED = CONST_LDS ? CONST_B : 0;
     static constexpr bool SLDS = 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) + CONST_USED <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
     static constexpr int S_SLOTS = SLDS ? NL + 1 : 2;
+    // PIPE: software pipeline ACROSS workgroup steps.  The weight-gradient wave of a SIMD has nothing to do while the chain wave runs a
+    // forward, and is idle about 40 % of every reverse layer.  So it runs the forward of the NEXT tile itself, one layer per reverse
+    // layer of the current tile (between its hand-off barrier and its weight gradient), parks that tile's states in the other half
+    // of a double-buffered scratch image, and hands S_NL / Z_NL over through the LDS images at the step boundary; the chain wave only
+    // runs reverse chains.  Needs every mid-layer accumulator in memory (registers for the forward state; measured cost: none).
+    static constexpr bool PIPE = PINN_X_PIPE && !SLDS && NS == 4;
     static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * IMG_B;
     static constexpr int CONST_OFF = 4 * WAVE_B;
     static constexpr int LDS_B = CONST_OFF + CONST_USED;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
     static constexpr int TILES = 4;                                           // 16-point tiles per workgroup step (one per chain wave)
-    static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * IMG_B);    // per tile: parked states S_1..S_{NL-1}
+    static constexpr unsigned SCRATCH_HALF = (unsigned)((NL - 1) * IMG_B);     // per tile: parked states S_1..S_{NL-1}
+    static constexpr unsigned SCRATCH_BYTES = PIPE ? 2 * SCRATCH_HALF : SCRATCH_HALF;      // PIPE: two tiles in flight per chain slot
     static __device__ __forceinline__ constexpr int slot_of(int L) { return SLDS ? L : (L & 1); }
 
     // The NG mid weight layers that the reverse sweep reaches first (L = NL-1 .. NL-NG) keep their accumulator blocks in memory
     // (loaded in the layer's hand-off window, stored one layer later so that the write acknowledgement never sits in front of a
     // full drain): with all NL-1 layers in registers the compiler spilled several layers' worth anyway, reloaded and stored them
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
-    static constexpr int NG = NL >= 8 ? 4 : (NL >= 4 ? 2 : 0);
+    static constexpr int NG = PIPE ? NL - 1 : (NL >= 8 ? 4 : (NL >= 4 ? 2 : 0));
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
     static constexpr unsigned WG_ACC_BYTES = (unsigned)((NG > 0 ? NG : 1) * IBW * OBW * 1024);
     static __device__ __forceinline__ constexpr bool in_memory(int L) { return L >= 1 && L <= NL - 1 && L > NREG; }
@@ -460,8 +471,9 @@ struct Fused {
         const float* blast;                        // output-layer bias (constants not in LDS)
         int c, q;
         bool tracer;                               // workgroup 0, chain wave 0, lane 0
-        __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile) {
-            scr = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES, 0x00020000);
+        __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile, int half = 0) {
+            scr = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES + (long)half * SCRATCH_HALF), 0,
+                                                    (int)SCRATCH_HALF, 0x00020000);
         }
         __device__ __forceinline__ void init(const FusedArgs& a, char* lds, int slot, int lane, int c_, int q_) {
             frags = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.frags, 0, (int)a.frags_bytes, 0x00020000);
@@ -683,13 +695,15 @@ struct Fused {
     //   (measured: ~2 k cycles; with a one-block prefetch distance every layer stalled on them).
     //   exit: the same invariant for the next layer.
     static constexpr int KOVL = (WB - 1) / 2;      // k-steps of the next layer's block 0 that can start before this layer's last block
-    template <int MB>
+    // NEXTALL = false (PIPE: the weight-gradient wave's forward, whose registers are needed elsewhere between two layers): only block 0
+    // of the next layer is requested here; its other blocks are requested by the caller right before the layer (load_rest)
+    template <int MB, bool NEXTALL = true>
     static __device__ __forceinline__ void fwd_step(const Ctx& x, int l, int nfrag0, bool next_is_out, const u32x4 (&in)[NS][1][KS][NP],
                                                     u32x4 (&out)[NS][1][KS][NP], u32x4 (&A)[WB][KS][FP], f32x4 (&acca)[NS], f32x4 (&accb)[NS],
                                                     f32x4 (&bb)[WB]) {
         f32x4 (&acur)[NS] = (MB & 1) ? accb : acca;      // block MB, complete
         f32x4 (&anxt)[NS] = (MB & 1) ? acca : accb;      // block MB+1
-        if (MB == 0 || !next_is_out) load_afrags<KS, FP>(x, nfrag0 + MB * KS, A[MB]);
+        if (MB == 0 || (NEXTALL && !next_is_out)) load_afrags<KS, FP>(x, nfrag0 + MB * KS, A[MB]);
         if constexpr (MB == 0) park_state(x, l, in);
         // accumulator start values (LDS table), requested a block step or more ahead of their use.  bb[m], m >= 1: block m of this
         // layer (bb[1] was requested during the previous layer); bb[0]: block 0 of the next layer.
@@ -715,7 +729,7 @@ struct Fused {
             fwd_ksteps<KOVL, KS, KS>(A[0], out, anxt);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MB + 1 < WB) fwd_step<MB + 1>(x, l, nfrag0, next_is_out, in, out, A, acca, accb, bb);
+        if constexpr (MB + 1 < WB) fwd_step<MB + 1, NEXTALL>(x, l, nfrag0, next_is_out, in, out, A, acca, accb, bb);
     }
 
     // reverse: vector part of block MB of weight layer L's transpose -- the activation below it.  acc = WS * (W_L Z_L) for the NS
@@ -881,15 +895,11 @@ struct Fused {
         }
     };
 
-    // forward + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
-    // parks S_1..S_{NL-1} (scratch image or LDS slots), returns S_NL (fragments) and the head's adjoint Z_NL, adds the loss sums
-    static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], bool valid, long pidx, int set, float (&lsum)[8],
-                                                        u32x4 (&B)[NS][1][KS][NP], u32x4 (&ZL)[NS][1][1][NP]) {
-        const int c = x.c, q = x.q;
-        // pipeline prologue: all fragments of layer 1 are requested BEFORE the first layer's vector work (they take a full L2 round
-        // trip), then block 0's MFMAs
-        u32x4 A[WB][KS][FP];
-        f32x4 acca[NS], accb[NS], bb[WB];
+    // ---- the forward in pieces (one call sequence in forward_tile; one piece per reverse layer in the PIPE schedule) ----
+    // first layer + pipeline prologue: all fragments of layer 1 are requested BEFORE the first layer's vector work (they take a full
+    // L2 round trip), then block 0's MFMAs
+    static __device__ __forceinline__ void fwd_first(const FusedArgs& a, const Ctx& x, const float (&xin)[3], u32x4 (&B)[NS][1][KS][NP], u32x4 (&A)[WB][KS][FP],
+                                                     f32x4 (&acca)[NS], f32x4 (&bb)[WB]) {
 #pragma unroll
         for (int mb = 0; mb < WB; ++mb) load_afrags<KS, FP>(x, FI::fwd_mid(1, mb, 0), A[mb]);
         bb[0] = load_bias(x, 1, 0);
@@ -900,21 +910,37 @@ struct Fused {
         for (int kk = 0; kk < KS; ++kk) operands_ready<KS>(B, kk);
         fwd_ksteps<0, KS, KS>(A[0], B, acca);
         __builtin_amdgcn_sched_barrier(0);
+    }
+    // PIPE: blocks 1.. of weight layer l (block 0 was requested during layer l-1)
+    static __device__ __forceinline__ void load_rest(const Ctx& x, int l, u32x4 (&A)[WB][KS][FP]) {
+#pragma unroll
+        for (int mb = 1; mb < WB; ++mb) load_afrags<KS, FP>(x, FI::fwd_mid(l, mb, 0), A[mb]);
+    }
+    template <bool NEXTALL = true>
+    static __device__ __forceinline__ void fwd_layer(const Ctx& x, int l, const u32x4 (&in)[NS][1][KS][NP], u32x4 (&out)[NS][1][KS][NP], u32x4 (&A)[WB][KS][FP],
+                                                     f32x4 (&acca)[NS], f32x4 (&accb)[NS], f32x4 (&bb)[WB]) {
+        const bool last = l + 1 == NL;
+        const int nfrag0 = last ? FI::fwd_last(NL, 0) : FI::fwd_mid(l + 1, 0, 0);
+        fwd_step<0, NEXTALL>(x, l, nfrag0, last, in, out, A, acca, accb, bb);
+    }
+
+    // forward + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
+    // parks S_1..S_{NL-1} (scratch image or LDS slots), returns S_NL (fragments) and the head's adjoint Z_NL, adds the loss sums
+    static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], bool valid, long pidx, int set, float (&lsum)[8],
+                                                        u32x4 (&B)[NS][1][KS][NP], u32x4 (&ZL)[NS][1][1][NP]) {
+        u32x4 A[WB][KS][FP];
+        f32x4 acca[NS], accb[NS], bb[WB];
+        fwd_first(a, x, xin, B, A, acca, bb);
         // two layers per loop trip, ping-ponging between B and B2: a one-buffer loop has to copy the fragment registers
         // back at the end of every layer
         u32x4 B2[NS][1][KS][NP];
-        auto layer = [&](int l, const u32x4 (&in)[NS][1][KS][NP], u32x4 (&out)[NS][1][KS][NP]) {
-            const bool last = l + 1 == NL;
-            const int nfrag0 = last ? FI::fwd_last(NL, 0) : FI::fwd_mid(l + 1, 0, 0);
-            fwd_step<0>(x, l, nfrag0, last, in, out, A, acca, accb, bb);
-        };
         int l = 1;
         for (; l + 1 < NL; l += 2) {
-            layer(l, B, B2);
-            layer(l + 1, B2, B);
+            fwd_layer(x, l, B, B2, A, acca, accb, bb);
+            fwd_layer(x, l + 1, B2, B, A, acca, accb, bb);
         }
         if (l < NL) {
-            layer(l, B, B2);
+            fwd_layer(x, l, B, B2, A, acca, accb, bb);
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -922,6 +948,13 @@ struct Fused {
 #pragma unroll
                     for (int pp = 0; pp < NP; ++pp) B[s][0][kk][pp] = B2[s][0][kk][pp];
         }
+        fwd_head(a, x, valid, pidx, set, lsum, acca, ZL);
+    }
+
+    // output layer's products (acca) -> outputs, residual head, loss sums, adjoint seeds Z_NL
+    static __device__ __forceinline__ void fwd_head(const FusedArgs& a, const Ctx& x, bool valid, long pidx, int set, float (&lsum)[8], const f32x4 (&acca)[NS],
+                                                    u32x4 (&ZL)[NS][1][1][NP]) {
+        const int c = x.c, q = x.q;
         fused_stamp(a, x.tracer, 1);
         // acca = WS * (Y of the 16 padded outputs, bias included): lane holds outputs 4q+r of its point
         float Y[NS][8];
