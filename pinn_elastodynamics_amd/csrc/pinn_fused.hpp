@@ -33,10 +33,6 @@
 #pragma once
 #include "pinn_device.hpp"
 
-#ifndef PINN_X_PIPE
-#define PINN_X_PIPE 0
-#endif
-
 namespace pinn {
 
 
@@ -120,26 +116,19 @@ struct Fused {
     static constexpr int CONST_USED = CONST_LDS ? CONST_B : 0;
     static constexpr bool SLDS = 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) + CONST_USED <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
     static constexpr int S_SLOTS = SLDS ? NL + 1 : 2;
-    // PIPE: software pipeline ACROSS workgroup steps.  The weight-gradient wave of a SIMD has nothing to do while the chain wave runs a
-    // forward, and is idle about 40 % of every reverse layer.  So it runs the forward of the NEXT tile itself, one layer per reverse
-    // layer of the current tile (between its hand-off barrier and its weight gradient), parks that tile's states in the other half
-    // of a double-buffered scratch image, and hands S_NL / Z_NL over through the LDS images at the step boundary; the chain wave only
-    // runs reverse chains.  Needs every mid-layer accumulator in memory (registers for the forward state; measured cost: none).
-    static constexpr bool PIPE = PINN_X_PIPE && !SLDS && NS == 4;
     static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * IMG_B;
     static constexpr int CONST_OFF = 4 * WAVE_B;
     static constexpr int LDS_B = CONST_OFF + CONST_USED;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
     static constexpr int TILES = 4;                                           // 16-point tiles per workgroup step (one per chain wave)
-    static constexpr unsigned SCRATCH_HALF = (unsigned)((NL - 1) * IMG_B);     // per tile: parked states S_1..S_{NL-1}
-    static constexpr unsigned SCRATCH_BYTES = PIPE ? 2 * SCRATCH_HALF : SCRATCH_HALF;      // PIPE: two tiles in flight per chain slot
+    static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * IMG_B);    // per tile: parked states S_1..S_{NL-1}
     static __device__ __forceinline__ constexpr int slot_of(int L) { return SLDS ? L : (L & 1); }
 
     // The NG mid weight layers that the reverse sweep reaches first (L = NL-1 .. NL-NG) keep their accumulator blocks in memory
     // (loaded in the layer's hand-off window, stored one layer later so that the write acknowledgement never sits in front of a
     // full drain): with all NL-1 layers in registers the compiler spilled several layers' worth anyway, reloaded and stored them
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
-    static constexpr int NG = PIPE ? NL - 1 : (NL >= 8 ? 4 : (NL >= 4 ? 2 : 0));
+    static constexpr int NG = NL >= 8 ? 4 : (NL >= 4 ? 2 : 0);
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
     static constexpr unsigned WG_ACC_BYTES = (unsigned)((NG > 0 ? NG : 1) * IBW * OBW * 1024);
     static __device__ __forceinline__ constexpr bool in_memory(int L) { return L >= 1 && L <= NL - 1 && L > NREG; }
@@ -471,9 +460,8 @@ struct Fused {
         const float* blast;                        // output-layer bias (constants not in LDS)
         int c, q;
         bool tracer;                               // workgroup 0, chain wave 0, lane 0
-        __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile, int half = 0) {
-            scr = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES + (long)half * SCRATCH_HALF), 0,
-                                                    (int)SCRATCH_HALF, 0x00020000);
+        __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile) {
+            scr = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES, 0x00020000);
         }
         __device__ __forceinline__ void init(const FusedArgs& a, char* lds, int slot, int lane, int c_, int q_) {
             frags = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.frags, 0, (int)a.frags_bytes, 0x00020000);
@@ -695,15 +683,13 @@ struct Fused {
     //   (measured: ~2 k cycles; with a one-block prefetch distance every layer stalled on them).
     //   exit: the same invariant for the next layer.
     static constexpr int KOVL = (WB - 1) / 2;      // k-steps of the next layer's block 0 that can start before this layer's last block
-    // NEXTALL = false (PIPE: the weight-gradient wave's forward, whose registers are needed elsewhere between two layers): only block 0
-    // of the next layer is requested here; its other blocks are requested by the caller right before the layer (load_rest)
-    template <int MB, bool NEXTALL = true>
+    template <int MB>
     static __device__ __forceinline__ void fwd_step(const Ctx& x, int l, int nfrag0, bool next_is_out, const u32x4 (&in)[NS][1][KS][NP],
                                                     u32x4 (&out)[NS][1][KS][NP], u32x4 (&A)[WB][KS][FP], f32x4 (&acca)[NS], f32x4 (&accb)[NS],
                                                     f32x4 (&bb)[WB]) {
         f32x4 (&acur)[NS] = (MB & 1) ? accb : acca;      // block MB, complete
         f32x4 (&anxt)[NS] = (MB & 1) ? acca : accb;      // block MB+1
-        if (MB == 0 || (NEXTALL && !next_is_out)) load_afrags<KS, FP>(x, nfrag0 + MB * KS, A[MB]);
+        if (MB == 0 || !next_is_out) load_afrags<KS, FP>(x, nfrag0 + MB * KS, A[MB]);
         if constexpr (MB == 0) park_state(x, l, in);
         // accumulator start values (LDS table), requested a block step or more ahead of their use.  bb[m], m >= 1: block m of this
         // layer (bb[1] was requested during the previous layer); bb[0]: block 0 of the next layer.
@@ -729,7 +715,7 @@ struct Fused {
             fwd_ksteps<KOVL, KS, KS>(A[0], out, anxt);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MB + 1 < WB) fwd_step<MB + 1, NEXTALL>(x, l, nfrag0, next_is_out, in, out, A, acca, accb, bb);
+        if constexpr (MB + 1 < WB) fwd_step<MB + 1>(x, l, nfrag0, next_is_out, in, out, A, acca, accb, bb);
     }
 
     // reverse: vector part of block MB of weight layer L's transpose -- the activation below it.  acc = WS * (W_L Z_L) for the NS
@@ -895,7 +881,7 @@ struct Fused {
         }
     };
 
-    // ---- the forward in pieces (one call sequence in forward_tile; one piece per reverse layer in the PIPE schedule) ----
+    // ---- the forward in pieces ----
     // first layer + pipeline prologue: all fragments of layer 1 are requested BEFORE the first layer's vector work (they take a full
     // L2 round trip), then block 0's MFMAs
     static __device__ __forceinline__ void fwd_first(const FusedArgs& a, const Ctx& x, const float (&xin)[3], u32x4 (&B)[NS][1][KS][NP], u32x4 (&A)[WB][KS][FP],
@@ -911,17 +897,11 @@ struct Fused {
         fwd_ksteps<0, KS, KS>(A[0], B, acca);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // PIPE: blocks 1.. of weight layer l (block 0 was requested during layer l-1)
-    static __device__ __forceinline__ void load_rest(const Ctx& x, int l, u32x4 (&A)[WB][KS][FP]) {
-#pragma unroll
-        for (int mb = 1; mb < WB; ++mb) load_afrags<KS, FP>(x, FI::fwd_mid(l, mb, 0), A[mb]);
-    }
-    template <bool NEXTALL = true>
     static __device__ __forceinline__ void fwd_layer(const Ctx& x, int l, const u32x4 (&in)[NS][1][KS][NP], u32x4 (&out)[NS][1][KS][NP], u32x4 (&A)[WB][KS][FP],
                                                      f32x4 (&acca)[NS], f32x4 (&accb)[NS], f32x4 (&bb)[WB]) {
         const bool last = l + 1 == NL;
         const int nfrag0 = last ? FI::fwd_last(NL, 0) : FI::fwd_mid(l + 1, 0, 0);
-        fwd_step<0, NEXTALL>(x, l, nfrag0, last, in, out, A, acca, accb, bb);
+        fwd_step<0>(x, l, nfrag0, last, in, out, A, acca, accb, bb);
     }
 
     // forward + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
