@@ -1,0 +1,45 @@
+"""-m gpu: bench.py's one-line JSON contract on small workloads (what the driver parses), for every --config and a 2-rank gloo run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+            "roofline"}
+
+
+def run_bench(args, env=None, launcher=None):
+    cmd = (launcher or [sys.executable]) + [os.path.join(ROOT, "bench.py")] + args
+    out = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, **(env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("cfg,extra", [("wave", ["--points-per-gpu", "131072", "--extra-modes", "none", "--no-small-config"]),
+                                       ("plate", ["--points-per-gpu", "120000"]),
+                                       ("nc3d", ["--points-per-gpu", "65536"])])
+def test_bench_line(cfg, extra):
+    d = run_bench(["--config", cfg, "--steps", "4", "--warmup", "1", "--ramp-steps", "2", "--no-cpu-baseline"] + extra)
+    assert REQUIRED <= set(d), sorted(REQUIRED - set(d))
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["unit"] == "collocation-points/s" and d["value"] > 0 and d["ms_per_step"] > 0 and d["dtype"] == "f16x3" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    if cfg in ("wave", "plate"):        # the fused kernel's own launch time, measured with HIP events in this run
+        assert r["avg_launch_ms"] > 0 and r["avg_launch_ms"] <= d["ms_per_step"] * 1.05
+
+
+def test_bench_two_ranks_strong_scaling_gloo():
+    """the multi-process path on one GPU: 2 ranks, gloo, fixed total work split over the ranks"""
+    d = run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--ramp-steps", "1", "--scaling", "strong", "--global-points", "200000", "--no-cpu-baseline",
+                   "--extra-modes", "none", "--no-small-config"], env={"PINN_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"},
+                  launcher=[sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                            "--master-port", "29653"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["collocation_points_global"] == 200000 and d["value"] > 0
