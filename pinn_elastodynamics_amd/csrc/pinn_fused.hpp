@@ -89,8 +89,16 @@ struct Fused {
     static constexpr int P3 = NP == 2 ? 3 : 1;
     static constexpr float WS = NP == 2 ? FUSED_WEIGHT_SCALE : 1.0f;
     static constexpr float INV_WS = 1.0f / WS;
-    static_assert(WB == 2 || WB == 4, "fused kernel supports padded widths 32 and 64");
+    static_assert(WB == 2 || WB == 4 || WB == 6, "fused kernel supports padded widths 32, 64 and 96");
     static_assert(NL >= 2, "fused kernel needs at least two hidden layers");
+    // LDSOP (padded width 96, the reference's 70 / 80): a tile's state does not fit the register file next to its successor (2 x 96
+    // registers), so the chain wave keeps it in its LDS image -- the register image IS the MFMA operand layout -- and reads one k-step
+    // at a time (one ds_read_b128 per stream and part); every layer is "all output blocks accumulate, then the vector part block by
+    // block".  The images are 24 KB (hi + lo) per tensor and tile: two tiles per workgroup.
+    static constexpr bool LDSOP = WB > 4;
+    static_assert(!LDSOP || (NS_ == 4 && NP == 2), "the LDS-operand layout is built for the 4-stream split-precision case");
+    static constexpr int TILES = LDSOP ? 2 : 4;               // 16-point tiles per workgroup step (one per chain wave)
+    static constexpr int NJ = TILES / 2;                      // 32-point k-steps of the weight gradient per workgroup step
     static constexpr int IBW = WB / 2, OBW = WB / 2;          // weight-gradient wave (i,o) owns IBW x OBW blocks of every mid Wbar
     static constexpr float INV_LS = 1.0f / Op::LO_SCALE;
     typedef Chain<Op, SPLIT, WIDTH, 1, NS, HEAD> CH;
@@ -102,7 +110,12 @@ struct Fused {
     // The parked state S is kept in the operand type's precision only (no low part): measured in tools/precision_study2.py,
     // rounding S for the reverse pass changes the gradient error by < 10 % of itself as long as adjoints and weights stay split.
     static constexpr int TENSOR_Z_B = NS * KS * NP * 1024;
-    static constexpr int IMG_B = NS * KS * 1024;
+    // LDSOP keeps the state images with BOTH parts (records ((s * KS + kk) * NP + p), the operand layout): the chain wave's reverse
+    // reads its state in full precision.  (At the reference's trained weights the activation reverse amplifies a 2^-12 rounding of
+    // the state ~20x by cancellation -- first-layer gradient blocks 5e-3 off against 2e-4 for fp32 --, while rounding the state
+    // only as the weight gradient's operand costs nothing: tests/test_gpu_parity.py)
+    static constexpr int SP = LDSOP ? NP : 1;                 // parts per state-image record group
+    static constexpr int IMG_B = NS * KS * SP * 1024;
     // "SLDS": where S_0..S_NL of a tile fit in LDS (NL+1 slots: every 1-stream case, and the 4-stream 4x32 net) nothing is parked in
     // scratch and no LDS-DMA round trip sits between the layer phases; otherwise two slots (layer parity), filled by LDS-DMA
     // Net constants the forward reads block by block, staged in LDS once per launch: [(NL-1) x WIDTH hidden biases | 16 output biases]
@@ -112,15 +125,14 @@ struct Fused {
     // trace, 1.6 k cycles for the first block step of a forward layer against 0.8 k for the others.
     static constexpr int CONST_BIAS_F = (NL - 1) * WIDTH + 16, CONST_F = CONST_BIAS_F + WIDTH * 4, CONST_B = CONST_F * 4;
     // (Five streams at width 64 fill the 160 KB with tensors alone: that instantiation reads the constants from memory.)
-    static constexpr bool CONST_LDS = 4 * (TENSOR_Z_B + 2 * IMG_B) + CONST_B <= 160 * 1024;
+    static constexpr bool CONST_LDS = TILES * (TENSOR_Z_B + 2 * IMG_B) + CONST_B <= 160 * 1024;
     static constexpr int CONST_USED = CONST_LDS ? CONST_B : 0;
-    static constexpr bool SLDS = 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) + CONST_USED <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
+    static constexpr bool SLDS = !LDSOP && 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) + CONST_USED <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
     static constexpr int S_SLOTS = SLDS ? NL + 1 : 2;
     static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * IMG_B;
-    static constexpr int CONST_OFF = 4 * WAVE_B;
+    static constexpr int CONST_OFF = TILES * WAVE_B;
     static constexpr int LDS_B = CONST_OFF + CONST_USED;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
-    static constexpr int TILES = 4;                                           // 16-point tiles per workgroup step (one per chain wave)
     static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * IMG_B);    // per tile: parked states S_1..S_{NL-1}
     static __device__ __forceinline__ constexpr int slot_of(int L) { return SLDS ? L : (L & 1); }
 
@@ -128,7 +140,7 @@ struct Fused {
     // (loaded in the layer's hand-off window, stored one layer later so that the write acknowledgement never sits in front of a
     // full drain): with all NL-1 layers in registers the compiler spilled several layers' worth anyway, reloaded and stored them
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
-    static constexpr int NG = NL >= 8 ? 5 : (NL >= 4 ? 2 : 0);      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
+    static constexpr int NG = LDSOP ? NL - 1 : (NL >= 8 ? 5 : (NL >= 4 ? 2 : 0));      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
     static constexpr unsigned WG_ACC_BYTES = (unsigned)((NG > 0 ? NG : 1) * IBW * OBW * 1024);
     static __device__ __forceinline__ constexpr bool in_memory(int L) { return L >= 1 && L <= NL - 1 && L > NREG; }
@@ -137,6 +149,10 @@ struct Fused {
         f32x4 first;                   // Wbar_0 block (in-block 0, out-block = quad) if quad < WB
         f32x4 last;                    // Wbar_NL block (in-block = quad, out-block 0) if quad < WB
         float bias[NL + 1];
+        // LDSOP (six blocks per side over four waves): a second first / last block (out- / in-block quad + 4 for quad < 2), and three bias
+        // blocks per mid layer held by the waves with wi == 0
+        f32x4 first2, last2;
+        float bias0b, biasw[LDSOP ? NL : 1][3];
     };
 
     // ---------------------------------------------------------------------------------------------
@@ -161,7 +177,9 @@ struct Fused {
     // group keeps the compiler from hoisting all transpose-reads of a layer ahead of the MFMAs.
     // s0/s1 (z0/z1): lane bases of the S (Z) image of chain wave 0 (+ the first block's offset); a second block steps 8 bytes (the
     // other half of the record: blocks 2k, 2k+1 share a record).
-    template <int NA, int NBK>
+    // SLO (LDSOP, layers 1..NL): the state image also holds the (unscaled) low parts; a third MFMA per block pair brings the weight
+    // gradient to the two-kernel path's accuracy (without it: a 1/sqrt(points) rounding noise, 7e-5 on 5 k points).
+    template <int NA, int NBK, bool SLO = false>
     static __device__ __forceinline__ void wg_blocks(const char* s0, const char* s1, const char* z0, const char* z1, f32x4 (&acc)[NA][NBK],
                                                      float (&bias_out)[NBK]) {
         static_assert(NA <= 2 && NBK <= 2, "blocks of one call share a fragment record");
@@ -178,11 +196,14 @@ struct Fused {
         // software pipeline over the 2*NS (k-step, stream) groups: the transpose-reads of group g+1 are issued before the MFMAs
         // of group g, so LDS latency hides behind matrix work; the fence after each group bounds how far the compiler may hoist.
         // Two fragment sets used in strict alternation (no copies: a third set would not fit beside the persistent accumulators).
-        struct Frags { u32x4 Ah[NA], Bh[NBK], Bl[NBK]; };
+        struct Frags { u32x4 Ah[NA], Al[SLO ? NA : 1], Bh[NBK], Bl[NBK]; };
         auto fetch = [&](int g, Frags& f) {
             const int j = g / NS, st = g % NS;
 #pragma unroll
-            for (int a = 0; a < NA; ++a) f.Ah[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * KS * 1024 + 8 * a);
+            for (int a = 0; a < NA; ++a) {
+                f.Ah[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * KS * SP * 1024 + 8 * a);
+                if constexpr (SLO) f.Al[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * KS * SP * 1024 + 1024 + 8 * a);
+            }
 #pragma unroll
             for (int b = 0; b < NBK; ++b) {
                 f.Bh[b] = sfrag(z0, z1, 2 * j * WAVE_B + (st * KS * NP) * 1024 + 8 * b);
@@ -196,6 +217,7 @@ struct Fused {
                 for (int b = 0; b < NBK; ++b) {
                     acc[a][b] = Op::mfma(f.Ah[a], f.Bh[b], acc[a][b]);
                     if (NP == 2) cc[a][b] = Op::mfma(f.Ah[a], f.Bl[b], cc[a][b]);
+                    if constexpr (SLO) acc[a][b] = Op::mfma(f.Al[a], f.Bh[b], acc[a][b]);
                 }
             if (g % NS == 0) {                    // bias gradient = ones^T . Z (value stream)
 #pragma unroll
@@ -208,11 +230,11 @@ struct Fused {
         Frags fa, fb;
         fetch(0, fa);
 #pragma unroll
-        for (int g = 0; g < 2 * NS; g += 2) {
+        for (int g = 0; g < NJ * NS; g += 2) {
             fetch(g + 1, fb);
             work(g, fa);
             __builtin_amdgcn_sched_barrier(0);
-            if (g + 2 < 2 * NS) fetch(g + 2, fa);
+            if (g + 2 < NJ * NS) fetch(g + 2, fa);
             work(g + 1, fb);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -235,12 +257,90 @@ struct Fused {
         const char* s1;                // S image slot 0, the +4 points
     };
     // byte offset of 16-feature block mb inside an image: fragment record block (mb >> 1), half (mb & 1) of the 16-byte lane record
-    static __device__ __forceinline__ int img_block(int mb) { return (mb >> 1) * 1024 + 8 * (mb & 1); }
+    static __device__ __forceinline__ int img_block(int mb) { return (mb >> 1) * SP * 1024 + 8 * (mb & 1); }
     static __device__ __forceinline__ int zimg_block(int mb) { return (mb >> 1) * NP * 1024 + 8 * (mb & 1); }
+
+    // LDSOP: six 16-feature blocks per side.  Wave (wi, wo) owns in-blocks {2wi, 2wi+1, 4+wi} x out-blocks {2wo, 2wo+1, 4+wo}: a pair that
+    // shares a fragment record and a single block, the same shape for every wave (offsets at run time, block counts at compile time).
+    static __device__ __forceinline__ int wide_block(int half, int i) { return i < 2 ? 2 * half + i : 4 + half; }
+    template <int L>
+    static __device__ __forceinline__ void wgrad_wide(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW]) {
+        const char* s0 = w.s0 + slot_of(L) * IMG_B;
+        const char* s1 = w.s1 + slot_of(L) * IMG_B;
+        const int wi = quad >> 1, wo = quad & 1;
+        if constexpr (L == 0 || L == NL) {
+            // first layer: in-block 0 x out-blocks {quad, quad + 4}; last layer: in-blocks {quad, quad + 4} x out-block 0
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int blk = quad + 4 * k;
+                if (blk < WB) {
+                    f32x4 t[1][1] = {{L == 0 ? (k ? A.first2 : A.first) : (k ? A.last2 : A.last)}};
+                    float b[1];
+                    if constexpr (L == 0) wg_blocks<1, 1>(s0, s1, w.z0 + zimg_block(blk), w.z1 + zimg_block(blk), t, b);
+                    else wg_blocks<1, 1, true>(s0 + img_block(blk), s1 + img_block(blk), w.z0, w.z1, t, b);
+                    if constexpr (L == 0) {
+                        if (k) { A.first2 = t[0][0]; A.bias0b += b[0]; } else { A.first = t[0][0]; A.bias[0] += b[0]; }
+                    } else {
+                        if (k) A.last2 = t[0][0]; else A.last = t[0][0];
+                        if (quad == 0 && k == 0) A.bias[NL] += b[0];
+                    }
+                }
+            }
+        } else {
+            static_assert(in_memory(L), "LDSOP keeps every mid-layer accumulator in memory");
+            // pend starts from the layer's running sums
+#pragma unroll
+            for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                for (int o = 0; o < OBW; ++o) pend[i][o] = ld[i][o];
+            const char* sp0 = s0 + img_block(2 * wi);
+            const char* sp1 = s1 + img_block(2 * wi);
+            const char* ss0 = s0 + img_block(4 + wi);
+            const char* ss1 = s1 + img_block(4 + wi);
+            const char* zp0 = w.z0 + zimg_block(2 * wo);
+            const char* zp1 = w.z1 + zimg_block(2 * wo);
+            const char* zs0 = w.z0 + zimg_block(4 + wo);
+            const char* zs1 = w.z1 + zimg_block(4 + wo);
+            float bp[2], bs[1], dummy2[2], dummy1[1];
+            {
+                f32x4 t[2][2] = {{pend[0][0], pend[0][1]}, {pend[1][0], pend[1][1]}};
+                wg_blocks<2, 2, true>(sp0, sp1, zp0, zp1, t, bp);
+                pend[0][0] = t[0][0]; pend[0][1] = t[0][1]; pend[1][0] = t[1][0]; pend[1][1] = t[1][1];
+            }
+            {
+                f32x4 t[2][1] = {{pend[0][2]}, {pend[1][2]}};
+                wg_blocks<2, 1, true>(sp0, sp1, zs0, zs1, t, bs);
+                pend[0][2] = t[0][0]; pend[1][2] = t[1][0];
+            }
+            {
+                f32x4 t[1][2] = {{pend[2][0], pend[2][1]}};
+                wg_blocks<1, 2, true>(ss0, ss1, zp0, zp1, t, dummy2);
+                pend[2][0] = t[0][0]; pend[2][1] = t[0][1];
+            }
+            {
+                f32x4 t[1][1] = {{pend[2][2]}};
+                wg_blocks<1, 1, true>(ss0, ss1, zs0, zs1, t, dummy1);
+                pend[2][2] = t[0][0];
+            }
+            if (wi == 0) {                 // the bias blocks of out-half wo
+                A.biasw[L][0] += bp[0];
+                A.biasw[L][1] += bp[1];
+                A.biasw[L][2] += bs[0];
+            }
+        }
+    }
 
     // weight gradient of weight layer L (quad = weight-gradient wave index 0..3)
     template <int L>
     static __device__ __forceinline__ void wgrad(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW]) {
+        if constexpr (LDSOP) {
+            wgrad_wide<L>(w, A, quad, ld, pend);
+        } else {
+            wgrad_narrow<L>(w, A, quad, ld, pend);
+        }
+    }
+    template <int L>
+    static __device__ __forceinline__ void wgrad_narrow(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW]) {
         const char* s0 = w.s0 + slot_of(L) * IMG_B;
         const char* s1 = w.s1 + slot_of(L) * IMG_B;
         const int wi = quad >> 1, wo = quad & 1;
@@ -301,11 +401,14 @@ struct Fused {
 #endif
         }
     };
-    static __device__ __forceinline__ void dma_state(const DmaSrc& src, unsigned lane16, char* tile_lds, int l /*1..NL-1*/) {
+    static __device__ __forceinline__ void dma_state(const DmaSrc& src, unsigned lane16, char* tile_lds, int l /*1..NL-1*/, int quad) {
         if constexpr (SLDS) return;
         char* dst = tile_lds + TENSOR_Z_B + slot_of(l) * IMG_B;
+        // LDSOP: two tiles, four waves: wave quad brings every second record of tile quad & 1 (records quad >> 1, +2, ...)
+        const int i0 = LDSOP ? (quad >> 1) : 0;
 #pragma unroll
-        for (int i = 0; i < IMG_B / 1024; ++i) {
+        for (int ii = 0; ii < (LDSOP ? IMG_B / 2048 : IMG_B / 1024); ++ii) {
+            const int i = LDSOP ? i0 + 2 * ii : ii;
 #if defined(__AMDGCN__)
             const unsigned lds_addr = (unsigned)(uintptr_t)((lds_void*)(dst + i * 1024));
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
@@ -333,7 +436,7 @@ struct Fused {
         // the stores of layer L+1's in-memory sums, the loads of layer L's, the LDS-DMA of S_{L-1}
         static constexpr int N_STORE = in_memory(L + 1) ? IBW * OBW : 0;
         static constexpr int N_LOAD = in_memory(L) ? IBW * OBW : 0;
-        static constexpr int N_DMA = (!SLDS && L >= 2) ? IMG_B / 1024 : 0;
+        static constexpr int N_DMA = (!SLDS && L >= 2) ? (LDSOP ? IMG_B / 2048 : IMG_B / 1024) : 0;      // LDSOP: two waves share a tile's records
         static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const WgCtx& w, const DmaSrc& scr, __amdgpu_buffer_rsrc_t accr,
                                                    unsigned lane16, char* tile_lds, Acc& A, int quad, f32x4 (&pend)[IBW][OBW]) {
             __syncthreads();                                   // (chain waves now overwrite the tensors; everything this wave had in flight is done)
@@ -353,7 +456,7 @@ struct Fused {
 #pragma unroll
                     for (int o = 0; o < OBW; ++o) ld[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), 0));
             }
-            if constexpr (L >= 2) dma_state(scr, lane16, tile_lds, L - 1);      // S_{L-1} streams in while layer L is worked on
+            if constexpr (L >= 2) dma_state(scr, lane16, tile_lds, L - 1, quad);      // S_{L-1} streams in while layer L is worked on
             // Second barrier: the tensors of layer L are complete.  This wave's contribution is the LDS-DMA of S_L, issued one layer
             // ago; everything issued since (the operations above) may stay in flight, so the drain is a COUNTED one.  (A surplus
             // operation the compiler might add only makes the wait more conservative: completion is in issue order.)
@@ -376,10 +479,13 @@ struct Fused {
             for (int i = 0; i < IBW; ++i)
 #pragma unroll
                 for (int o = 0; o < OBW; ++o) A.mid[l][i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-        A.first = f32x4{0.f, 0.f, 0.f, 0.f};
-        A.last = f32x4{0.f, 0.f, 0.f, 0.f};
+        A.first = A.first2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        A.last = A.last2 = f32x4{0.f, 0.f, 0.f, 0.f};
+        A.bias0b = 0.0f;
 #pragma unroll
         for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
+#pragma unroll
+        for (int l = 0; l < (LDSOP ? NL : 1); ++l) A.biasw[l][0] = A.biasw[l][1] = A.biasw[l][2] = 0.0f;
         WgCtx w;
         {
             const char* wave0 = lds + (q >> 1) * WAVE_B;
@@ -389,15 +495,16 @@ struct Fused {
             w.s0 = w.z0 + TENSOR_Z_B;
             w.s1 = w.z1 + TENSOR_Z_B;
         }
-        // this wave feeds chain tile `quad`: descriptor of that tile's scratch image
-        const long gtile = (long)blockIdx.x * TILES + quad;
+        // this wave feeds chain tile `quad` (if there is one: LDSOP has two tiles): descriptor of that tile's scratch image
+        const int ftile = LDSOP ? (quad & 1) : quad;
+        const long gtile = (long)blockIdx.x * TILES + ftile;
         DmaSrc scr;
         scr.init(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES, SCRATCH_BYTES);
         const unsigned lane16 = (unsigned)lane * 16u;
-        char* tile_lds = lds + quad * WAVE_B;
+        char* tile_lds = lds + ftile * WAVE_B;
         // this wave's in-memory accumulator records, zeroed here (same-wave program order makes the first loads see the zeros)
         const __amdgpu_buffer_rsrc_t accr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(reinterpret_cast<char*>(a.wg_acc) + gtile * (long)WG_ACC_BYTES), 0, (int)WG_ACC_BYTES, 0x00020000);
+            (void*)(reinterpret_cast<char*>(a.wg_acc) + ((long)blockIdx.x * 4 + quad) * (long)WG_ACC_BYTES), 0, (int)WG_ACC_BYTES, 0x00020000);
         if constexpr (NG > 0) {
 #pragma unroll
             for (int r = 0; r < NG * IBW * OBW; ++r) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, accr, lane16, r * 1024, 0);
@@ -423,6 +530,40 @@ struct Fused {
             for (int r = 0; r < 4; ++r) lo[r] = __shfl_xor(A.first[r], 16);
 #pragma unroll
             for (int r = 0; r < 4; ++r) A.first[r] += lo[r] * INV_LS;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lo[r] = __shfl_xor(A.first2[r], 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A.first2[r] += lo[r] * INV_LS;
+        }
+        if constexpr (LDSOP) {
+            // wave quad: first / last blocks quad and quad + 4; mid layers: in-blocks wide_block(wi, i) x out-blocks wide_block(wo, o)
+            put_block(A.first, 0, 0, quad, 3, H);
+            put_block(A.last, NL, quad, 0, H, NO);
+            if (q == 0 && 16 * quad + c < H) part[a.net.b_off[0] + 16 * quad + c] = A.bias[0];
+            if (quad + 4 < WB) {
+                put_block(A.first2, 0, 0, quad + 4, 3, H);
+                put_block(A.last2, NL, quad + 4, 0, H, NO);
+                if (q == 0 && 16 * (quad + 4) + c < H) part[a.net.b_off[0] + 16 * (quad + 4) + c] = A.bias0b;
+            }
+            if (quad == 0 && q == 0 && c < NO) part[a.net.b_off[NL] + c] = A.bias[NL];
+#pragma unroll
+            for (int l = 1; l < NL; ++l) {
+#pragma unroll
+                for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                    for (int o = 0; o < OBW; ++o) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(l, i, o), 0));
+                        put_block(v, l, wide_block(wi, i), wide_block(wo, o), H, H);
+                    }
+                if (wi == 0 && q == 0) {
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) {
+                        const int ob = wide_block(wo, o);
+                        if (16 * ob + c < H) part[a.net.b_off[l] + 16 * ob + c] = A.biasw[l][o];
+                    }
+                }
+            }
+            return;
         }
         if (quad < WB) {
             put_block(A.first, 0, 0, quad, 3, H);
@@ -499,7 +640,7 @@ struct Fused {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int kk = 0; kk < KSF; ++kk) *reinterpret_cast<u32x4*>(img + (s * KS + kk) * 1024) = F[s][0][kk][0];
+            for (int kk = 0; kk < KSF; ++kk) *reinterpret_cast<u32x4*>(img + (s * KS + kk) * SP * 1024) = F[s][0][kk][0];
     }
 
     // weight fragments of one feature block (NPARTS = 2: forward parts [V_hi, V_lo]; 3: reverse, plus [w_hi])
@@ -828,6 +969,31 @@ struct Fused {
                 for (int p = 0; p < NP; ++p) asm volatile("" ::"v"(F[s][0][kk][p]));
     }
 
+    // S_0: the inputs as a 16-feature state (rows 0..2 = x', tangent stream k carries sx_k in row k) -> image slot 0
+    static __device__ __forceinline__ void put_input_state(const FusedArgs& a, const Ctx& x, const float (&xin)[3]) {
+        float v0[NS][1][4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                // rows 0..2: hi parts; rows 4..6 (lanes q == 1): the 2^11-scaled low parts of the same numbers, so that the
+                // first layer's weight gradient keeps full input precision (combined at write-out)
+                float v = 0.0f;
+                if (x.q < 2 && r < 3) {
+                    const float full = (s == 0) ? xin[r] : (r == s - 1 ? a.sx[r] : 0.0f);
+                    v = x.q == 0 ? full : (full - round16<Op>(full)) * Op::LO_SCALE;
+                }
+                v0[s][0][r] = v;
+            }
+        u32x4 S0[NS][1][1][NP];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) S0[s][0][0][p] = u32x4{0u, 0u, 0u, 0u};
+        CH::template emit<1, 0>(S0, v0, nullptr, 16, x.c, x.q);
+        put_image<1>(x.imgS(0), S0);
+    }
+
     // Weight layers L = NL-1 .. 1 (hidden-to-hidden) and finally L = 0, fully unrolled (static fragment indices / offsets).
     template <int L>
     struct Down {
@@ -841,30 +1007,7 @@ struct Fused {
             __syncthreads();                                   // previous layer's fragment reads are done
             fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
             put_zimage<KS>(x.imgZ(), Zc);
-            if constexpr (L == 0) {
-                // S_0: the inputs as a 16-feature state (rows 0..2 = x', tangent stream k carries sx_k in row k)
-                float v0[NS][1][4];
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        // rows 0..2: hi parts; rows 4..6 (lanes q == 1): the 2^11-scaled low parts of the same numbers, so that the
-                        // first layer's weight gradient keeps full input precision (combined at write-out)
-                        float v = 0.0f;
-                        if (x.q < 2 && r < 3) {
-                            const float full = (s == 0) ? xin[r] : (r == s - 1 ? a.sx[r] : 0.0f);
-                            v = x.q == 0 ? full : (full - round16<Op>(full)) * Op::LO_SCALE;
-                        }
-                        v0[s][0][r] = v;
-                    }
-                u32x4 S0[NS][1][1][NP];
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-#pragma unroll
-                    for (int p = 0; p < NP; ++p) S0[s][0][0][p] = u32x4{0u, 0u, 0u, 0u};
-                CH::template emit<1, 0>(S0, v0, nullptr, 16, x.c, x.q);
-                put_image<1>(x.imgS(0), S0);
-            }
+            if constexpr (L == 0) put_input_state(a, x, xin);
             __syncthreads();                                   // tensors visible to the weight-gradient waves; S_L has landed
             fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
             if constexpr (L >= 1) {
@@ -902,6 +1045,165 @@ struct Fused {
         const bool last = l + 1 == NL;
         const int nfrag0 = last ? FI::fwd_last(NL, 0) : FI::fwd_mid(l + 1, 0, 0);
         fwd_step<0>(x, l, nfrag0, last, in, out, A, acca, accb, bb);
+    }
+
+
+    // ---------------------------------------------------------------------------------------------
+    // LDSOP chain (padded width 96): state tensors live in the wave's LDS images and are read one k-step at a time
+    // ---------------------------------------------------------------------------------------------
+    static_assert(!LDSOP || (NL & 1) == 0, "LDSOP forward buffer parity: the last hidden layer (odd) writes slot 0 = slot_of(NL)");
+    // operand image = records ((s * KS + kk) * NP + p) of 1 KB; this lane's 16 bytes sit at the (rotated) record offset inside each
+    static __device__ __forceinline__ void op_load(const char* img, int kk, u32x4 (&Bk)[NS][1][1][NP]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) Bk[s][0][0][p] = *reinterpret_cast<const u32x4*>(img + ((s * KS + kk) * NP + p) * 1024);
+    }
+    static __device__ __forceinline__ void op_store(char* img, const u32x4 (&F)[NS][1][KS][NP]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(img + ((s * KS + kk) * NP + p) * 1024) = F[s][0][kk][p];
+    }
+    static __device__ __forceinline__ void park_wide(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][p], x.scr, x.imgoff, (l - 1) * IMG_B + ((s * KS + kk) * NP + p) * 1024, 0);
+    }
+    template <int MB>
+    static __device__ __forceinline__ void wide_fwd_epilogue(const f32x4 (&acc)[WB][NS], u32x4 (&out)[NS][1][KS][NP]) {
+        fwd_valu<MB>(acc[MB], out);
+        if constexpr (MB + 1 < WB) wide_fwd_epilogue<MB + 1>(acc, out);
+    }
+    // one hidden weight layer l (1..NL-1): S_l (image `in`) -> S_{l+1} (image `out`, parked if a reverse layer will DMA it back)
+    static __device__ __forceinline__ void wide_fwd_layer(const Ctx& x, int l, const char* in, char* outimg) {
+        f32x4 acc[WB][NS];
+#pragma unroll
+        for (int mb = 0; mb < WB; ++mb) acc_init(load_bias(x, l, mb), acc[mb]);
+        // flattened (k-step, block) sequence with the weight fragments requested two items ahead
+        constexpr int NIT = KS * WB;
+        u32x4 Af[3][1][FP];
+        load_afrags<1, FP>(x, FI::fwd_mid(l, 0, 0), Af[0]);
+        load_afrags<1, FP>(x, FI::fwd_mid(l, 1, 0), Af[1]);
+        u32x4 Bk[NS][1][1][NP];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            const int kk = t / WB, mb = t % WB;
+            if (mb == 0) op_load(in, kk, Bk);
+            if (t + 2 < NIT) load_afrags<1, FP>(x, FI::fwd_mid(l, (t + 2) % WB, (t + 2) / WB), Af[(t + 2) % 3]);
+            fwd_kstep<0, 1>(Af[t % 3], Bk, acc[mb]);
+        }
+        u32x4 out[NS][1][KS][NP];
+        wide_fwd_epilogue<0>(acc, out);
+        op_store(outimg, out);
+        if (l + 1 <= NL - 1) park_wide(x, l + 1, out);
+    }
+    // forward of one tile: returns the output layer's products (acca) for fwd_head; S_NL ends in the second buffer
+    static __device__ __forceinline__ void wide_forward(const FusedArgs& a, const Ctx& x, const float (&xin)[3], f32x4 (&acca)[NS]) {
+        char* opa = x.tenZ + x.imgoff;                       // Z area
+        char* opb = x.tenZ + TENSOR_Z_B + x.imgoff;          // S slot 0 = slot_of(NL): S_NL ends where the reverse expects it
+        {
+            u32x4 B[NS][1][KS][NP];
+            first_mb<0>(a, x, xin, B);
+            op_store(opa, B);
+            park_wide(x, 1, B);
+        }
+        for (int l = 1; l < NL; ++l) {                       // odd layers: first -> second buffer, even layers back
+            if (l & 1) wide_fwd_layer(x, l, opa, opb);
+            else wide_fwd_layer(x, l, opb, opa);
+        }
+        // output layer (16 padded outputs): one block, operand S_NL from slot 0 (NL - 1 is odd)
+        acc_init(load_bias(x, NL, 0), acca);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            u32x4 Bk[NS][1][1][NP], A1[1][FP];
+            load_afrags<1, FP>(x, FI::fwd_last(NL, kk), A1);
+            op_load(opb, kk, Bk);
+            fwd_kstep<0, 1>(A1, Bk, acca);
+        }
+    }
+    // reverse vector part with the state in full precision (hi + unscaled lo from the operand-layout image)
+    template <int MB>
+    static __device__ __forceinline__ void wide_bwd_epilogue(f32x4 (&acc)[WB][NS], const char* simg, u32x4 (&Zn)[NS][1][KS][NP], int c, int q) {
+        float st[NS][4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const char* rec = simg + ((s * KS + (MB >> 1)) * NP) * 1024 + 8 * (MB & 1);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(rec);
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(rec + 1024);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                st[s][r] = cvt16<Op>((uint16_t)((r & 1) ? (hi[r >> 1] >> 16) : (hi[r >> 1] & 0xffffu))) +
+                           cvt16<Op>((uint16_t)((r & 1) ? (lo[r >> 1] >> 16) : (lo[r >> 1] & 0xffffu)));
+        }
+        float vals[NS][1][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float h = st[0][r];
+            const float sds = (1.0f - h * h) * INV_WS;
+            float dot = 0.0f;
+#pragma unroll
+            for (int s = 1; s <= NT; ++s) {
+                dot += acc[MB][s][r] * st[s][r];
+                vals[s][0][r] = sds * acc[MB][s][r];
+            }
+            vals[0][0][r] = sds * acc[MB][0][r] - (2.0f * INV_WS) * h * dot;
+        }
+        CH::template emit<KS, MB>(Zn, vals, nullptr, WIDTH, c, q);
+        if constexpr (MB + 1 < WB) wide_bwd_epilogue<MB + 1>(acc, simg, Zn, c, q);
+    }
+    // reverse of one tile; on entry the first barrier of the top layer has NOT been passed, S_NL (hi + lo) sits in S slot 0
+    static __device__ __forceinline__ void wide_reverse(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&ZL)[NS][1][1][NP]) {
+        u32x4 Zn[NS][1][KS][NP];
+        {
+            __syncthreads();                                   // A(NL); S_NL already sits in slot_of(NL) in the image layout
+            put_zimage<1>(x.imgZ(), ZL);
+            __syncthreads();                                   // B(NL)
+            f32x4 acc[WB][NS];
+#pragma unroll
+            for (int mb = 0; mb < WB; ++mb) {
+                u32x4 Af[1][RP];
+                load_afrags<1, RP>(x, FI::bwd_last(NL, mb), Af);
+                acc_zero(acc[mb]);
+                bwd_kstep<0, 1>(Af, ZL, acc[mb]);
+            }
+            wide_bwd_epilogue<0>(acc, x.imgS(NL), Zn, x.c, x.q);
+        }
+        wide_down<NL - 1>(a, x, xin, Zn);
+    }
+    // entry: Zc = Z_L in registers (fragment order), first barrier of layer L not yet passed
+    template <int L>
+    static __device__ __forceinline__ void wide_down(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&Zc)[NS][1][KS][NP]) {
+        __syncthreads();                                       // A(L): the weight-gradient waves are done with Z_{L+1}, S_{L+1}
+        put_zimage<KS>(x.imgZ(), Zc);
+        if constexpr (L == 0) put_input_state(a, x, xin);
+        __syncthreads();                                       // B(L)
+        if constexpr (L >= 1) {
+            f32x4 acc[WB][NS];
+#pragma unroll
+            for (int mb = 0; mb < WB; ++mb) acc_zero(acc[mb]);
+            constexpr int NIT = KS * WB;
+            u32x4 Af[3][1][RP];
+            load_afrags<1, RP>(x, FI::bwd_mid(NL, L, 0, 0), Af[0]);
+            load_afrags<1, RP>(x, FI::bwd_mid(NL, L, 1, 0), Af[1]);
+            u32x4 Bk[NS][1][1][NP];
+#pragma unroll
+            for (int t = 0; t < NIT; ++t) {
+                const int kk = t / WB, mb = t % WB;
+                if (mb == 0) op_load(x.imgZ(), kk, Bk);       // this wave's own records of the Z_L image it has just written
+                if (t + 2 < NIT) load_afrags<1, RP>(x, FI::bwd_mid(NL, L, (t + 2) % WB, (t + 2) / WB), Af[(t + 2) % 3]);
+                bwd_kstep<0, 1>(Af[t % 3], Bk, acc[mb]);
+            }
+            u32x4 Zn[NS][1][KS][NP];
+            wide_bwd_epilogue<0>(acc, x.imgS(L), Zn, x.c, x.q);
+            wide_down<L - 1>(a, x, xin, Zn);
+        }
     }
 
     // forward + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
@@ -1130,7 +1432,13 @@ struct Fused {
             }
             x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0 && step == 2 * (long)gridDim.x;      // a steady-state step
             fused_stamp(a, x.tracer, 0);
-            {
+            if constexpr (LDSOP) {
+                u32x4 ZL[NS][1][1][NP];
+                f32x4 acca[NS];
+                wide_forward(a, x, xin, acca);
+                fwd_head(a, x, valid, pidx, set, lsum[0], acca, ZL);
+                wide_reverse(a, x, xin, ZL);
+            } else {
                 u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
                 float ls[8];
 #pragma unroll
@@ -1173,6 +1481,10 @@ struct Fused {
         }
         if (wave8 >= 4) {
             wgrad_role(a, lds, wave8 - 4, lane, c, q);
+        } else if (wave8 >= TILES) {
+            // LDSOP: two tiles per step; these waves only keep the workgroup's barrier count (2 per weight layer and step)
+            for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x)
+                for (int i = 0; i < 2 * (NL + 1); ++i) __syncthreads();
         } else {
             __builtin_amdgcn_s_setprio(2);          // the chain wave is the critical path of its SIMD: issue it first
             chain_role(a, lds, wave8, lane, c, q);

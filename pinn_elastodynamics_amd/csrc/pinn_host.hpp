@@ -92,6 +92,10 @@ struct Host {
     static constexpr int FUSED_PARTS = SPLIT == 3 ? 3 : 1;   // ... of the fused kernel's format (repack_kernel)
     static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
     static constexpr int FUSED_GRID = 256;    // persistent workgroups of the fused kernel (one per MI355X CU)
+    static constexpr int FUSED_MAX_WIDTH = 96;      // widest padded net the fused kernel takes (4 streams; 32 / 64 also 1 and 5 streams)
+    static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? 32 * 1024 : 64 * 1024;     // per weight-gradient wave: in-memory accumulator blocks
+    template <int NS>
+    static constexpr bool fused_has() { return WIDTH <= 64 || (WIDTH <= FUSED_MAX_WIDTH && NS == 4 && SPLIT == 3); }
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
     static constexpr long MIN_TILES = 64;
     typedef FragIndex<WIDTH> FI;
@@ -117,13 +121,13 @@ struct Host {
         p.frags = o;
         o = align_up(o + (size_t)FI::total(net.nl) * NPS * 64 * sizeof(u32x4), 256);
         p.frags_fused = o;      // second copy in the fused kernel's format (narrow nets only)
-        if (WIDTH <= 64) o = align_up(o + (size_t)FI::total(net.nl) * FUSED_PARTS * 64 * sizeof(u32x4), 256);
+        if (WIDTH <= FUSED_MAX_WIDTH) o = align_up(o + (size_t)FI::total(net.nl) * FUSED_PARTS * 64 * sizeof(u32x4), 256);
         p.loss_part = o;
         o = align_up(o + (size_t)MAX_BLOCKS * 4 * LOSS_SLOTS_3D * sizeof(float), 256);
         p.partial = o;
         o = align_up(o + (size_t)(NCHUNK > FUSED_GRID ? NCHUNK : FUSED_GRID) * net.nparams * sizeof(float), 256);
         p.wg_acc = o;           // fused kernel: weight-gradient accumulator blocks kept in memory (<= 2 layers x 4 blocks x 1 KB per wave)
-        if (WIDTH <= 64) o = align_up(o + (size_t)FUSED_GRID * 4 * 32 * 1024, 256);
+        if (WIDTH <= FUSED_MAX_WIDTH) o = align_up(o + (size_t)FUSED_GRID * 4 * FUSED_ACC_BYTES, 256);
         p.panels = o;
         p.fixed_end = o;
         p.s_tile = PG::s_tile(net.nl);
@@ -182,7 +186,7 @@ struct Host {
         ra.bias_mid = reinterpret_cast<float*>(b + p.bias_mid);
         ra.bias_last = reinterpret_cast<float*>(b + p.bias_last);
         ra.frags = reinterpret_cast<u32x4*>(b + p.frags);
-        ra.frags_fused = WIDTH <= 64 ? reinterpret_cast<u32x4*>(b + p.frags_fused) : nullptr;
+        ra.frags_fused = WIDTH <= FUSED_MAX_WIDTH ? reinterpret_cast<u32x4*>(b + p.frags_fused) : nullptr;
         const long items = (long)FI::total(c.net.nl) * 64;
         const int blocks = (int)((items + 255) / 256);
         hipLaunchKernelGGL((repack_kernel<Op, SPLIT, WIDTH>), dim3(blocks), dim3(256), 0, c.stream, ra);
@@ -322,7 +326,7 @@ struct Host {
 
     template <int NL, int NS>
     static int fused_launch(const Call& c, const Plan& p, int grid, int nterms, long nsteps) {
-        if constexpr (WIDTH <= 64) {
+        if constexpr (fused_has<NS>()) {
             typedef Fused<Op, SPLIT, WIDTH, NL, NS> F;
             int rc = repack(c, p);
             if (rc) return rc;
@@ -379,7 +383,7 @@ struct Host {
             a.loss_part = reinterpret_cast<float*>(b + p.loss_part);
             a.partial = reinterpret_cast<float*>(b + p.partial);
             a.wg_acc = reinterpret_cast<u32x4*>(b + p.wg_acc);
-            static_assert(F::WG_ACC_BYTES <= 32 * 1024, "accumulator area of the plan");
+            static_assert(F::WG_ACC_BYTES <= FUSED_ACC_BYTES, "accumulator area of the plan");
             a.dbg = c.dbg_stamps;
             EventPair evp(c.prof_ms != nullptr);
             hipEvent_t (&ev)[2] = evp.ev;
@@ -406,8 +410,9 @@ struct Host {
     // returns 1 if the fused path ran (rc in *out), 0 if it does not apply
     template <int NS>
     static int try_fused(const Call& c, int* out, int nterms) {
-        if constexpr (WIDTH <= 64) {
+        if constexpr (fused_has<NS>()) {
             if (c.net.nl != 4 && c.net.nl != 8) return 0;
+            if (WIDTH > 64 && c.net.nl != 8) return 0;          // padded width 96: the 8-layer instantiation only (INF:645, 8 x 80)
             Plan p;
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
@@ -426,7 +431,8 @@ struct Host {
             }
             if (nsteps == 0) return 0;
             if (grid > nsteps) grid = nsteps;
-            *out = c.net.nl == 4 ? fused_launch<4, NS>(c, p, (int)grid, nterms, nsteps) : fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
+            if constexpr (WIDTH > 64) *out = fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
+            else *out = c.net.nl == 4 ? fused_launch<4, NS>(c, p, (int)grid, nterms, nsteps) : fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
             return 1;
         } else {
             return 0;

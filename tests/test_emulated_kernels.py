@@ -83,6 +83,19 @@ def test_fused_persistent_accumulation_emulated(emu):
     assert e_loss < 2e-6 and e_grad < 2e-5
 
 
+def test_fused_wide_emulated(emu):
+    """Padded width 96 (the reference's 8 x 80 net, INF:645) through the LDS-operand layout of the fused kernel: the tile's state lives
+    in the chain wave's LDS image and is read one k-step at a time; six feature blocks per side in the weight gradient; two tiles per
+    workgroup.  Against the oracle (gradient within the 1/sqrt(points) rounding noise of the fp16-parked state) and the two-kernel path."""
+    layers = [3] + 8 * [80] + [7]
+    e_loss, e_grad = run_wave(emu, layers, 70, "f16x3", fused=True)
+    assert e_loss < 2e-6 and e_grad < 1e-4
+    e_loss, e_grad = run_wave(emu, layers, 70, "f16x3", fused=False)
+    assert e_loss < 2e-6 and e_grad < 2e-6
+    e_loss, e_grad = run_wave(emu, layers, 300, "f16x3", min_ws=True, fused=True, normalize=False, seed=4)      # several steps per workgroup
+    assert e_loss < 2e-6 and e_grad < 5e-5
+
+
 def test_chunked_workspace_emulated(emu):
     """2100 points with the minimum workspace (64 tiles of 32 points) -> two passes of the two-kernel path."""
     e_loss, e_grad = run_wave(emu, [3] + 2 * [32] + [7], 2100, "f16x3", min_ws=True, fused=False)

@@ -519,3 +519,32 @@ def test_fp32_mode_drives_the_model_class(dev):
         rec = m.train(3, 1e-3, 1)
         runs[prec] = np.asarray(rec[-1] if isinstance(rec, (tuple, list)) else rec, dtype=np.float64)
     assert np.all(np.isfinite(runs["fp32"])) and rel(runs["f16x3"], runs["fp32"]) < 1e-4
+
+
+@pytest.mark.parametrize("width,n", [(80, 30000), (70, 9001), (96, 4096)])
+def test_fused_wide_kernel_against_oracle_and_two_kernel_path(dev, width, n):
+    """Padded width 96 (the reference's 8 x 80 INF net, INF:645; 8 x 70 is the plate's width) runs through the LDS-operand layout of the
+    fused kernel.  Same numbers as the two-kernel path for the same call and as the float64 oracle (on a subsample)."""
+    layers = [3] + 8 * [width] + [7]
+    rng = np.random.default_rng(12)
+    Ws, bs = po.xavier_init(layers, rng)
+    flat = po.pack_params(Ws, [0.2 * rng.standard_normal(b.shape) for b in bs])
+    X = rng.random((n, 3)) * np.array([30.0, 30.0, 20.0])
+    lb, ub = [0.0, 0.0, 0.0], [30.0, 30.0, 20.0]
+    theta = to_dev(flat, dev)
+    xs = [to_dev(X[:, k], dev) for k in range(3)]
+    eng = engine(layers, "f16x3", dev, n)
+    tw = np.array([1, 2, 3, 1, 0.5, 1, 2.0]) / n
+    res = {}
+    for fused in (True, False):
+        eng.lib.set_fused(fused)
+        try:
+            l, g = eng.wave_loss_grad(theta, *xs, lb, ub, True, tw)
+            res[fused] = (l.cpu().numpy().astype(np.float64), g.cpu().numpy().astype(np.float64))
+        finally:
+            eng.lib.set_fused(True)
+    assert rel(res[True][0], res[False][0]) < 2e-6 and rel(res[True][1], res[False][1]) < 2e-5
+    m = min(n, 5000)
+    ss, go, _ = po.wave2d_loss_grad(flat, layers, X[:m, 0], X[:m, 1], X[:m, 2], lb, ub, True, term_weights=tw * n / m)
+    l, g = eng.wave_loss_grad(theta, *(v[:m].contiguous() for v in xs), lb, ub, True, tw * n / m)
+    assert rel(l.cpu().numpy(), ss) < 5e-6 and rel(g.cpu().numpy(), go) < 2e-5
