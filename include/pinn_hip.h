@@ -38,7 +38,12 @@ enum {
     /* OR this into precision_mode when the PREVIOUS call on the same workspace used the same params_flat contents, layers and
      * mode: the packed MFMA weight fragments are still in the workspace and the repack launch is skipped (the reference feeds
      * one set of variables to every loss term of a step, INF:297-305; a step makes 3-4 calls). */
-    PINN_FLAG_WEIGHTS_PACKED = 0x100
+    PINN_FLAG_WEIGHTS_PACKED = 0x100,
+    /* OR this into precision_mode to let the fused kernel of the 8-layer, width <= 64 collocation path park its per-layer states as fp16
+     * high parts only (no low parts): 17 % faster, but the activation reverse then sees states rounded to 2^-12, which cancellation at
+     * TRAINED weights amplifies (first-layer gradient blocks 5e-3 off at the reference's trained nets, fp32 itself 2e-4).  Fine far
+     * from an optimum (early Adam steps); not parity-grade.  Ignored where it does not apply. */
+    PINN_FLAG_STATE_FP16 = 0x200
     /* PINN_ADJOINT_SHIFT(k), k = 0..24, may be OR'ed in as well: see below */
 };
 

@@ -10,6 +10,7 @@ import os
 
 PREC = {"bf16": 0, "f16x3": 1, "f16": 2, "bf16x3": 3, "fp32": 4}
 FLAG_WEIGHTS_PACKED = 0x100
+FLAG_STATE_FP16 = 0x200            # PINN_FLAG_STATE_FP16: fused 8-layer collocation kernel parks fp16 states only (faster, not parity-grade)
 def adjoint_shift(k: int) -> int:
     """PINN_ADJOINT_SHIFT(k) of include/pinn_hip.h"""
     return (int(k) & 0x1f) << 16

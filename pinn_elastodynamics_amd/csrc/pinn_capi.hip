@@ -127,8 +127,9 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     if (n > 0 && (!x || !y || !t || (din == 4 && !z))) return PINN_ERR_NULL;          // n == 0 is a valid empty batch (see empty_batch)
     if (normalize && (!lb || !ub)) return PINN_ERR_NULL;
     c.weights_packed = (precision_mode & PINN_FLAG_WEIGHTS_PACKED) ? 1 : 0;
+    c.fast_state = (precision_mode & PINN_FLAG_STATE_FP16) ? 1 : 0;
     c.adj_shift = (precision_mode >> 16) & 0x1f;
-    precision_mode &= ~(PINN_FLAG_WEIGHTS_PACKED | (0x1f << 16));
+    precision_mode &= ~(PINN_FLAG_WEIGHTS_PACKED | PINN_FLAG_STATE_FP16 | (0x1f << 16));
     if (precision_mode < 0 || precision_mode > PINN_PREC_FP32) return PINN_ERR_PRECISION;
     int width = 0;
     const int rc = decode_net(layers, n_layers, c.net, width, din);
@@ -165,7 +166,7 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
 }
 
 // the sizing entry points accept the same precision_mode word as the calls (flag and shift bits are ignored) and both input counts
-static int mode_only(int precision_mode) { return precision_mode & ~(PINN_FLAG_WEIGHTS_PACKED | (0x1f << 16)); }
+static int mode_only(int precision_mode) { return precision_mode & ~(PINN_FLAG_WEIGHTS_PACKED | PINN_FLAG_STATE_FP16 | (0x1f << 16)); }
 
 size_t pinn_workspace_bytes(const int* layers, int n_layers, int64_t n, int precision_mode) {
     NetDesc net;

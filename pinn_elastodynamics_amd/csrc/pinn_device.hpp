@@ -123,7 +123,7 @@ __device__ __forceinline__ void split2u<OpF16>(float a, float b, uint32_t& hi, u
 }
 #endif
 // fp16 operands read straight out of a packed dword by the mixed-precision FMA (HALF = 0 / 1 selects the low / high half):
-//   fma<HALF>(w, b, c) = float(half(w)) * b + c        one_minus_sq<HALF>(w) = 1 - float(half(w))^2
+//   fma<HALF>(w, b, c) = float(half(w)) * b + c        one_minus_sq<HALF>(w) = 1 - float(half(w))^2        sum2<HALF>(hi, lo)
 // Only the gfx950 build of the fp16 operand type has it; everything else converts first.
 template <class Op>
 struct MixF16 { static constexpr bool value = false; };
@@ -143,6 +143,14 @@ struct MixF16<OpF16> {
         float d;
         if (HALF) asm("v_fma_mix_f32 %0, -%1, %1, 1.0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(w));
         else asm("v_fma_mix_f32 %0, -%1, %1, 1.0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "=v"(d) : "v"(w));
+        return d;
+    }
+    // float(half(whi)) + float(half(wlo)): a value from its high and (unscaled) low part in one instruction
+    template <int HALF>
+    static __device__ __forceinline__ float sum2(uint32_t whi, uint32_t wlo) {
+        float d;
+        if (HALF) asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(whi), "v"(wlo));
+        else asm("v_fma_mix_f32 %0, %1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(whi), "v"(wlo));
         return d;
     }
 };

@@ -75,7 +75,9 @@ __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int sl
 
 // NS = 4: value + three tangent streams, residual head of net_f_sig (the collocation set).  NS = 1: value stream only, head
 // sum_o w_o (Y_o - target_o)^2 -- the side sets loss_IC / loss_SRC / loss_NB / loss_FIX (INF:111-118, CONF:145-146).
-template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4>
+// FASTSTATE (PINN_FLAG_STATE_FP16): the parked states keep their fp16 high parts only -- 17 % faster for the 8x64 net, at the price of
+// a 2^-12 state rounding that cancellation amplifies at trained weights (see STATE_LO below).  Not the default.
+template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4, bool FASTSTATE = false>
 struct Fused {
     static constexpr int NS = NS_, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1;
     static_assert(NS == 4 || NS == 1 || NS == 5, "wave residual head (4 streams), value-only data head (1 stream) or plate head (5 streams)");
@@ -133,7 +135,13 @@ struct Fused {
     static constexpr int CONST_OFF = TILES * WAVE_B;
     static constexpr int LDS_B = CONST_OFF + CONST_USED;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
-    static constexpr unsigned SCRATCH_BYTES = (unsigned)((NL - 1) * IMG_B);    // per tile: parked states S_1..S_{NL-1}
+    // per tile: parked states S_1..S_{NL-1}.  Narrow layouts: [high-part images | low-part images]: the high parts return to LDS by
+    // LDS-DMA (they are also the weight gradient's operand), the (unscaled) low parts are read back by the chain wave itself, block by
+    // block, so that the activation reverse sees the state in full precision.  (With fp16-rounded states the gradient at the
+    // reference's trained weights is 5e-3 off in the first-layer blocks -- fp32: 2e-4 --, amplified by cancellation)
+    static constexpr bool STATE_LO = !LDSOP && NP == 2 && !FASTSTATE;
+    static constexpr unsigned SCRATCH_LO = (unsigned)((NL - 1) * IMG_B);          // byte offset of the low-part images
+    static constexpr unsigned SCRATCH_BYTES = (unsigned)((STATE_LO ? 2 : 1) * (NL - 1) * IMG_B);
     static __device__ __forceinline__ constexpr int slot_of(int L) { return SLDS ? L : (L & 1); }
 
     // The NG mid weight layers that the reverse sweep reaches first (L = NL-1 .. NL-NG) keep their accumulator blocks in memory
@@ -812,6 +820,13 @@ struct Fused {
                 for (int kk = 0; kk < KS; ++kk)
                     __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][0], x.scr, x.imgoff, (l - 1) * IMG_B + (s * KS + kk) * 1024, 0);
         }
+        if constexpr (STATE_LO) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk)
+                    __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][NP - 1], x.scr, x.imgoff, SCRATCH_LO + (l - 1) * IMG_B + (s * KS + kk) * 1024, 0);
+        }
     }
 
     // One hidden layer of the forward pipeline (weight layer l: `in` = S_l -> `out` = S_{l+1}).
@@ -862,55 +877,36 @@ struct Fused {
     // reverse: vector part of block MB of weight layer L's transpose -- the activation below it.  acc = WS * (W_L Z_L) for the NS
     // streams; state (h, hdot_k) of this lane's point as packed 16-bit pairs sp[s] (fp16: consumed in place by mixed-precision FMAs)
     //   zbar = sd hbar - 2 h sum_k hdotbar_k hdot_k ,  zdotbar_k = sd hdotbar_k          (INF:131-133, gradient of TanhGrad)
-    // The reverse vector part reads the accumulators inside inline assembly (mixed-precision FMAs).  hipcc pads MFMA-result
-    // hazards only for instructions it knows, not for an asm statement that consumes the registers, and its scheduler is free to
-    // put such a statement right behind the block's last MFMA -- seen on the GPU as a timing-dependent wrong first element of one
-    // layer's adjoint.  This fence makes every later reader depend on a statement that opens with the wait states an MFMA result
-    // needs before a vector instruction may read it.
-    static __device__ __forceinline__ void mfma_results_ready(f32x4 (&acc)[NS]) {
-#if defined(__AMDGCN__)
-        if constexpr (NS == 5) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]));
-        else if constexpr (NS == 4) asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-        else asm volatile("s_nop 7\n\ts_nop 7" : "+v"(acc[0]));
-#endif
-    }
-
+    // sp: the state's high parts as packed 16-bit pairs; sl: its (unscaled) low parts where the layout carries them (STATE_LO).  The state
+    // enters in full precision: v = hi + lo (one mixed-precision FMA per value on the fp16 path).
     template <int MB>
-    static __device__ __forceinline__ void bwd_valu(f32x4 (&acc)[NS], const u32x2 (&sp)[NS], u32x4 (&Zn)[NS][1][KS][NP], int c, int q) {
-        if constexpr (MixF16<Op>::value) mfma_results_ready(acc);
+    static __device__ __forceinline__ void bwd_valu(f32x4 (&acc)[NS], const u32x2 (&sp)[NS], const u32x2 (&sl)[NS], u32x4 (&Zn)[NS][1][KS][NP], int c, int q) {
         float vals[NS][1][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            float sds, hd = 0.0f;
-            if constexpr (MixF16<Op>::value) {
-                const uint32_t hw = sp[0][r >> 1];
-                const float sd = (r & 1) ? MixF16<Op>::template one_minus_sq<1>(hw) : MixF16<Op>::template one_minus_sq<0>(hw);
-                sds = sd * INV_WS;
-                if constexpr (NS > 1) {
-                    float dot = 0.0f;
+            float st[NS];
 #pragma unroll
-                    for (int s = 1; s <= NT; ++s)
-                        dot = (r & 1) ? MixF16<Op>::template fma<1>(sp[s][r >> 1], acc[s][r], dot) : MixF16<Op>::template fma<0>(sp[s][r >> 1], acc[s][r], dot);
-                    hd = (r & 1) ? MixF16<Op>::template fma<1>(hw, dot, 0.0f) : MixF16<Op>::template fma<0>(hw, dot, 0.0f);
+            for (int s = 0; s < NS; ++s) {
+                if constexpr (STATE_LO && MixF16<Op>::value) {
+                    st[s] = (r & 1) ? MixF16<Op>::template sum2<1>(sp[s][r >> 1], sl[s][r >> 1]) : MixF16<Op>::template sum2<0>(sp[s][r >> 1], sl[s][r >> 1]);
+                } else {
+                    st[s] = cvt16<Op>((uint16_t)((r & 1) ? (sp[s][r >> 1] >> 16) : (sp[s][r >> 1] & 0xffffu)));
+                    if constexpr (STATE_LO) st[s] += cvt16<Op>((uint16_t)((r & 1) ? (sl[s][r >> 1] >> 16) : (sl[s][r >> 1] & 0xffffu)));
                 }
-            } else {
-                const float h = cvt16<Op>((uint16_t)((r & 1) ? (sp[0][r >> 1] >> 16) : (sp[0][r >> 1] & 0xffffu)));
-                sds = (1.0f - h * h) * INV_WS;
-                float dot = 0.0f;
-#pragma unroll
-                for (int s = 1; s <= NT; ++s)
-                    dot += acc[s][r] * cvt16<Op>((uint16_t)((r & 1) ? (sp[s][r >> 1] >> 16) : (sp[s][r >> 1] & 0xffffu)));
-                hd = h * dot;
             }
+            const float h = st[0];
+            const float sds = (1.0f - h * h) * INV_WS;
+            float dot = 0.0f;
 #pragma unroll
-            for (int s = 1; s <= NT; ++s) vals[s][0][r] = sds * acc[s][r];
-            float zb = NS > 1 ? sds * acc[0][r] - (2.0f * INV_WS) * hd : sds * acc[0][r];
+            for (int s = 1; s <= NT; ++s) {
+                dot += acc[s][r] * st[s];
+                vals[s][0][r] = sds * acc[s][r];
+            }
+            float zb = NS > 1 ? sds * acc[0][r] - (2.0f * INV_WS) * h * dot : sds * acc[0][r];
             if constexpr (SECOND) {
                 // adjoint of h_tt = (1-h^2) z_tt - 2 h h_t z_t from post-activation state only:
                 //   d h_tt / d z = -2 h h_tt - 2 h_t^2,   d h_tt / d z_t = -4 h h_t,   d h_tt / d z_tt = 1 - h^2        (PLATE:417-419)
-                const float h = cvt16<Op>((uint16_t)((r & 1) ? (sp[0][r >> 1] >> 16) : (sp[0][r >> 1] & 0xffffu)));
-                const float ht = cvt16<Op>((uint16_t)((r & 1) ? (sp[3][r >> 1] >> 16) : (sp[3][r >> 1] & 0xffffu)));
-                const float htt = cvt16<Op>((uint16_t)((r & 1) ? (sp[4][r >> 1] >> 16) : (sp[4][r >> 1] & 0xffffu)));
+                const float ht = st[3], htt = st[4];
                 const float httb = acc[4][r] * INV_WS;
                 vals[4][0][r] = sds * acc[4][r];
                 vals[3][0][r] -= 4.0f * h * ht * httb;
@@ -933,28 +929,53 @@ struct Fused {
         for (int s = 0; s < NS; ++s) sp[s] = u32x2{B[s][0][MB >> 1][0][(MB & 1) * 2 + 0], B[s][0][MB >> 1][0][(MB & 1) * 2 + 1]};
     }
 
+    // the low parts of the same values: from the forward's registers (S_NL) or from the tile's parked low-part image (plain loads)
+    template <int MB>
+    static __device__ __forceinline__ void lo_from_frags(const u32x4 (&B)[NS][1][KS][NP], u32x2 (&sl)[NS]) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) sl[s] = u32x2{B[s][0][MB >> 1][NP - 1][(MB & 1) * 2 + 0], B[s][0][MB >> 1][NP - 1][(MB & 1) * 2 + 1]};
+    }
+    template <int MB>
+    static __device__ __forceinline__ void lo_from_scratch(const Ctx& x, int L /*1..NL-1*/, u32x2 (&sl)[NS]) {
+        if constexpr (STATE_LO) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                sl[s] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(x.scr, x.imgoff + 8u * (MB & 1),
+                                                                                      SCRATCH_LO + (L - 1) * IMG_B + (s * KS + (MB >> 1)) * 1024, 0));
+        }
+    }
+
     // Reverse through weight layer L (KSB k-steps of its outputs; fragments frag0 + MB*KSB) and the activation that produced S_L:
     // Zf = Z_L  ->  Zn = Z_{L-1}.  Same software pipeline as the forward: MFMAs of block MB+1 between the vector part of block MB.
     // TOP: the state comes from the forward's registers (S_NL), otherwise from the wave's LDS image of S_L.
     //   entry: Aa = fragments of block 0, Ab = fragments of block 1, both loaded (issued before the hand-off barriers)
     template <int MB, int KSB, bool TOP>
-    static __device__ __forceinline__ void bwd_step(const Ctx& x, int frag0, const char* img, const u32x4 (&Sreg)[NS][1][KS][NP], const u32x4 (&Zf)[NS][1][KSB][NP],
-                                                    u32x4 (&Zn)[NS][1][KS][NP], u32x4 (&Aa)[KSB][RP], u32x4 (&Ab)[KSB][RP], f32x4 (&acca)[NS], f32x4 (&accb)[NS]) {
+    //   sla = low parts of the state for block 0 (requested with the first fragments); block MB+1's are requested in step MB
+    static __device__ __forceinline__ void bwd_step(const Ctx& x, int frag0, int L, const char* img, const u32x4 (&Sreg)[NS][1][KS][NP], const u32x4 (&Zf)[NS][1][KSB][NP],
+                                                    u32x4 (&Zn)[NS][1][KS][NP], u32x4 (&Aa)[KSB][RP], u32x4 (&Ab)[KSB][RP], f32x4 (&acca)[NS], f32x4 (&accb)[NS],
+                                                    u32x2 (&sla)[NS], u32x2 (&slb)[NS]) {
+        u32x2 (&slcur)[NS] = (MB & 1) ? slb : sla;
+        u32x2 (&slnxt)[NS] = (MB & 1) ? sla : slb;
         u32x4 (&Acur)[KSB][RP] = (MB & 1) ? Ab : Aa;
         u32x4 (&Anxt)[KSB][RP] = (MB & 1) ? Aa : Ab;
         f32x4 (&acur)[NS] = (MB & 1) ? accb : acca;
         f32x4 (&anxt)[NS] = (MB & 1) ? acca : accb;
         if constexpr (MB + 2 < WB) load_afrags<KSB, RP>(x, frag0 + (MB + 2) * KSB, Acur);
         u32x2 sp[NS];
-        if constexpr (TOP) state_from_frags<MB>(Sreg, sp);
-        else state_from_image<MB>(img, sp);
+        if constexpr (TOP) {
+            state_from_frags<MB>(Sreg, sp);
+            if constexpr (STATE_LO) lo_from_frags<MB>(Sreg, slcur);
+        } else {
+            state_from_image<MB>(img, sp);
+            if constexpr (MB + 1 < WB) lo_from_scratch<MB + 1>(x, L, slnxt);
+        }
         if constexpr (MB + 1 < WB) {
             acc_zero(anxt);
             bwd_ksteps<0, KSB, KSB>(Anxt, Zf, anxt);
         }
-        bwd_valu<MB>(acur, sp, Zn, x.c, x.q);
+        bwd_valu<MB>(acur, sp, slcur, Zn, x.c, x.q);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MB + 1 < WB) bwd_step<MB + 1, KSB, TOP>(x, frag0, img, Sreg, Zf, Zn, Aa, Ab, acca, accb);
+        if constexpr (MB + 1 < WB) bwd_step<MB + 1, KSB, TOP>(x, frag0, L, img, Sreg, Zf, Zn, Aa, Ab, acca, accb, sla, slb);
     }
 
     // Force the fragments to be fully computed at this point: without it the compiler sinks the reverse elementwise work past
@@ -1000,9 +1021,11 @@ struct Fused {
         // entry: Zc = Z_L (adjoint of weight layer L's pre-activation) in chain fragment order; S_L is (being) DMA'd into its slot
         static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&Zc)[NS][1][KS][NP]) {
             u32x4 Aa[KS][RP], Ab[KS][RP];
+            u32x2 sla[NS], slb[NS];
             if constexpr (L >= 1) {                            // this layer's first fragments travel during the hand-off
                 load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 0, 0), Aa);
                 load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 1, 0), Ab);
+                lo_from_scratch<0>(x, L, sla);
             }
             __syncthreads();                                   // previous layer's fragment reads are done
             fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
@@ -1016,7 +1039,7 @@ struct Fused {
                 f32x4 acca[NS], accb[NS];
                 acc_zero(acca);
                 bwd_ksteps<0, KS, KS>(Aa, Zc, acca);
-                bwd_step<0, KS, false>(x, FI::bwd_mid(NL, L, 0, 0), x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb);
+                bwd_step<0, KS, false>(x, FI::bwd_mid(NL, L, 0, 0), L, x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb, sla, slb);
                 pin<KS>(Zn);
                 fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
                 Down<L - 1>::run(a, x, xin, Zn);
@@ -1387,7 +1410,8 @@ struct Fused {
             f32x4 acca[NS], accb[NS];
             acc_zero(acca);
             bwd_ksteps<0, 1, 1>(Aa, ZL, acca);
-            bwd_step<0, 1, true>(x, FI::bwd_last(NL, 0), nullptr, B, ZL, Zn, Aa, Ab, acca, accb);
+            u32x2 sla[NS], slb[NS];
+            bwd_step<0, 1, true>(x, FI::bwd_last(NL, 0), NL, nullptr, B, ZL, Zn, Aa, Ab, acca, accb, sla, slb);
             pin<KS>(Zn);
         }
         fused_stamp(a, x.tracer, 5);
@@ -1492,9 +1516,9 @@ struct Fused {
     }
 };
 
-template <class Op, int SPLIT, int WIDTH, int NL, int NS>
+template <class Op, int SPLIT, int WIDTH, int NL, int NS, bool FASTSTATE>
 __global__ __launch_bounds__(512) void fused_wave_kernel(const FusedArgs a) {
-    Fused<Op, SPLIT, WIDTH, NL, NS>::run(a);
+    Fused<Op, SPLIT, WIDTH, NL, NS, FASTSTATE>::run(a);
 }
 
 }  // namespace pinn

@@ -52,6 +52,7 @@ struct Call {
     int adj_shift;             // PINN_ADJOINT_SHIFT(k): adjoint seeds scaled by 2^-k inside the kernels, the gradient by 2^k at the reduction
     int weights_packed;        // skip the repack: the workspace already holds the packed form of `params` (same net / precision mode)
     int use_fused;             // 1: prefer the fused kernel where it applies (default), 0: force the two-kernel path
+    int fast_state;            // PINN_FLAG_STATE_FP16: fused kernel parks its states as fp16 high parts only (faster, less accurate at trained weights)
 };
 
 struct Impl {
@@ -324,10 +325,10 @@ struct Host {
         return 1;
     }
 
-    template <int NL, int NS>
+    template <int NL, int NS, bool FS = false>
     static int fused_launch(const Call& c, const Plan& p, int grid, int nterms, long nsteps) {
         if constexpr (fused_has<NS>()) {
-            typedef Fused<Op, SPLIT, WIDTH, NL, NS> F;
+            typedef Fused<Op, SPLIT, WIDTH, NL, NS, FS> F;
             int rc = repack(c, p);
             if (rc) return rc;
             char* b = static_cast<char*>(c.ws);
@@ -388,7 +389,7 @@ struct Host {
             EventPair evp(c.prof_ms != nullptr);
             hipEvent_t (&ev)[2] = evp.ev;
             if (c.prof_ms) hipEventRecord(ev[0], c.stream);
-            hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL, NS>), dim3(grid), dim3(512), 0, c.stream, a);
+            hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL, NS, FS>), dim3(grid), dim3(512), 0, c.stream, a);
             if ((rc = (int)hipGetLastError())) return rc;
             if (c.prof_ms) {
                 hipEventRecord(ev[1], c.stream);
@@ -417,6 +418,7 @@ struct Host {
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
             constexpr int TILES = Fused<Op, SPLIT, WIDTH, 4, NS>::TILES;
+            // (sized for the default layout, which parks more than the fp16-state one)
             const size_t per_wg = (size_t)TILES * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NS>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NS>::SCRATCH_BYTES);
             if (c.ws_bytes < p.fixed_end + per_wg) return 0;
             long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
@@ -432,6 +434,7 @@ struct Host {
             if (nsteps == 0) return 0;
             if (grid > nsteps) grid = nsteps;
             if constexpr (WIDTH > 64) *out = fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
+            else if (c.fast_state && SPLIT == 3 && NS == 4 && c.net.nl == 8) *out = fused_launch<8, NS, true>(c, p, (int)grid, nterms, nsteps);   // the collocation kernel of the 8-layer nets
             else *out = c.net.nl == 4 ? fused_launch<4, NS>(c, p, (int)grid, nterms, nsteps) : fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
             return 1;
         } else {

@@ -9,7 +9,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from .capi import DEFAULT_LIB, FLAG_WEIGHTS_PACKED, PREC, PinnLib, PinnLibError, adjoint_shift
+from .capi import DEFAULT_LIB, FLAG_STATE_FP16, FLAG_WEIGHTS_PACKED, PREC, PinnLib, PinnLibError, adjoint_shift
 
 
 def param_count(layers: Sequence[int]) -> int:
@@ -25,12 +25,15 @@ class HipEngine:
 
     def __init__(self, layers: Sequence[int], precision: str = "f16x3", device: Optional[torch.device] = None,
                  max_points: int = 1 << 18, lib_path: str = DEFAULT_LIB, workspace_bytes: Optional[int] = None,
-                 workspace_cap_bytes: int = 8 << 30):
+                 workspace_cap_bytes: int = 8 << 30, fast_state: bool = False):
         if not torch.cuda.is_available():
             raise PinnLibError("HipEngine needs a GPU (torch.cuda.is_available() is False); there is no CPU fallback")
         self.lib = PinnLib(lib_path)
         self.layers = [int(v) for v in layers]
         self.precision = precision
+        # fast_state: PINN_FLAG_STATE_FP16 -- the fused 8-layer collocation kernel parks its states as fp16 only: 17 % faster, but the
+        # gradient at trained weights loses accuracy by cancellation.  Off by default.
+        self.fast_state = bool(fast_state)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.n_params = param_count(self.layers)
         self.adjoint_shift = 0
@@ -54,7 +57,8 @@ class HipEngine:
         """precision_mode argument of the loss / gradient calls: the precision, PINN_FLAG_WEIGHTS_PACKED when the previous call of this
         engine used the same parameter values (skip the repack launch), and the current adjoint shift (``self.adjoint_shift``, see
         PINN_ADJOINT_SHIFT in include/pinn_hip.h; the model classes adapt it when a gradient comes back non-finite)."""
-        return PREC[self.precision] | (FLAG_WEIGHTS_PACKED if packed else 0) | adjoint_shift(self.adjoint_shift)
+        return (PREC[self.precision] | (FLAG_WEIGHTS_PACKED if packed else 0) | (FLAG_STATE_FP16 if self.fast_state else 0)
+                | adjoint_shift(self.adjoint_shift))
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream

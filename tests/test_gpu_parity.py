@@ -548,3 +548,31 @@ def test_fused_wide_kernel_against_oracle_and_two_kernel_path(dev, width, n):
     ss, go, _ = po.wave2d_loss_grad(flat, layers, X[:m, 0], X[:m, 1], X[:m, 2], lb, ub, True, term_weights=tw * n / m)
     l, g = eng.wave_loss_grad(theta, *(v[:m].contiguous() for v in xs), lb, ub, True, tw * n / m)
     assert rel(l.cpu().numpy(), ss) < 5e-6 and rel(g.cpu().numpy(), go) < 2e-5
+
+
+def test_fp16_state_flag_is_opt_in_and_close_at_fresh_weights(dev):
+    """PINN_FLAG_STATE_FP16 (HipEngine(fast_state=True)): the fused 8-layer collocation kernel parks fp16 states only.  Off by default; at
+    fresh weights (no cancellation) it agrees with the default to the rounding noise of the parked state, and with the oracle to 2e-5."""
+    layers = [3] + 8 * [64] + [7]
+    rng = np.random.default_rng(2)
+    Ws, bs = po.xavier_init(layers, rng)
+    flat = po.pack_params(Ws, bs)
+    n = 20000
+    X = rng.random((n, 3)) * np.array([30.0, 30.0, 20.0])
+    lb, ub = [0.0, 0.0, 0.0], [30.0, 30.0, 20.0]
+    theta = to_dev(flat, dev)
+    xs = [to_dev(X[:, k], dev) for k in range(3)]
+    from pinn_elastodynamics_amd.hip_engine import HipEngine
+    tw = np.ones(7) / n
+    out = {}
+    for fast in (False, True):
+        e = HipEngine(layers, precision="f16x3", device=dev, max_points=n, fast_state=fast)
+        assert e.fast_state is fast
+        l, g = e.wave_loss_grad(theta, *xs, lb, ub, True, tw)
+        out[fast] = (l.cpu().numpy().astype(np.float64), g.cpu().numpy().astype(np.float64))
+    assert rel(out[True][0], out[False][0]) < 1e-6 and 0 < rel(out[True][1], out[False][1]) < 2e-5
+    m = 4096
+    ss, go, _ = po.wave2d_loss_grad(flat, layers, X[:m, 0], X[:m, 1], X[:m, 2], lb, ub, True, term_weights=np.ones(7) / m)
+    e = HipEngine(layers, precision="f16x3", device=dev, max_points=m)
+    l, g = e.wave_loss_grad(theta, *(v[:m].contiguous() for v in xs), lb, ub, True, np.ones(7) / m)
+    assert rel(l.cpu().numpy(), ss) < 5e-6 and rel(g.cpu().numpy(), go) < 2e-5

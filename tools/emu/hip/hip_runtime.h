@@ -201,6 +201,13 @@ inline emu_u32x4 __builtin_amdgcn_raw_buffer_load_b128(emu_buffer_rsrc r, unsign
     memcpy(&v, r.base + voff + soff, 16);
     return v;
 }
+typedef unsigned int emu_u32x2 __attribute__((ext_vector_type(2)));
+inline emu_u32x2 __builtin_amdgcn_raw_buffer_load_b64(emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
+    if (voff + soff + 8u > r.bytes) { fprintf(stderr, "emu: buffer load out of range (%u + %u > %u)\n", voff, soff, r.bytes); abort(); }
+    emu_u32x2 v;
+    memcpy(&v, r.base + voff + soff, 8);
+    return v;
+}
 inline void __builtin_amdgcn_raw_buffer_store_b128(emu_u32x4 v, emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
     if (voff + soff + 16u > r.bytes) { fprintf(stderr, "emu: buffer store out of range (%u + %u > %u)\n", voff, soff, r.bytes); abort(); }
     memcpy(r.base + voff + soff, &v, 16);
