@@ -118,8 +118,8 @@ def traffic_from_profiles(name):
             return {"bytes_per_launch": pm.get("hbm_bytes_per_launch"), "source": f"profiles/{rnd}_{name}_pmc_summary.json",
                     "ea_read_bytes": pm.get("ea_read_bytes_per_launch"), "ea_write_bytes": pm.get("ea_write_bytes_per_launch"),
                     "note": "L2<->fabric request bytes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE; ea_*: TCC_EA0 request counters of the same "
-                            "passes at 64 B per request -- a read request fetches a 128-byte line); parked fp16 state 14.4 GB + in-memory accumulators "
-                            "4 GB + weights / inputs / partials; MALL vs HBM is not observable from the L2 (profiles/README.md)"}
+                            "passes at 64 B per request -- a read request fetches a 128-byte line); parked states (high and low parts) 28.7 GB + "
+                            "in-memory accumulators 5 GB + weights / inputs / partials; MALL vs HBM is not observable from the L2 (profiles/README.md)"}
         except Exception:
             continue
     return None
