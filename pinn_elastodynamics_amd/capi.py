@@ -21,6 +21,7 @@ def mode_bits(prec) -> int:
     return PREC[prec] if isinstance(prec, str) else int(prec)
 
 
+PREC["f16x3+fp16state"] = PREC["f16x3"] | FLAG_STATE_FP16       # the opt-in fp16-state variant of the fused 8-layer collocation kernel
 for _k in list(PREC):                      # "<mode>+packed": the workspace still holds this call's packed weights (PINN_FLAG_WEIGHTS_PACKED)
     PREC[_k + "+packed"] = PREC[_k] | FLAG_WEIGHTS_PACKED
 

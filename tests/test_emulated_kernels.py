@@ -83,6 +83,15 @@ def test_fused_persistent_accumulation_emulated(emu):
     assert e_loss < 2e-6 and e_grad < 2e-5
 
 
+def test_fp16_state_flag_emulated(emu):
+    """PINN_FLAG_STATE_FP16: the 8-layer collocation kernel with fp16-only parked states (opt-in; the default parks the low parts as well).
+    At fresh weights both agree with the oracle; the default is the closer one."""
+    layers = [3] + 8 * [64] + [7]
+    e_loss, e_fast = run_wave(emu, layers, 70, "f16x3+fp16state", fused=True)
+    e_loss2, e_acc = run_wave(emu, layers, 70, "f16x3", fused=True)
+    assert e_loss < 2e-6 and e_loss2 < 2e-6 and e_acc < e_fast < 1e-4
+
+
 def test_fused_wide_emulated(emu):
     """Padded width 96 (the reference's 8 x 80 net, INF:645) through the LDS-operand layout of the fused kernel: the tile's state lives
     in the chain wave's LDS image and is read one k-step at a time; six feature blocks per side in the weight gradient; two tiles per
