@@ -519,6 +519,7 @@ struct Fused {
         }
         f32x4 pend[IBW][OBW];
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
+            if constexpr (LDSOP) __syncthreads();         // step barrier (see the chain role): this wave's reads of the previous step are done
             WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend);
         }
         // ---- write this workgroup's partial gradient
@@ -1459,6 +1460,10 @@ struct Fused {
             if constexpr (LDSOP) {
                 u32x4 ZL[NS][1][1][NP];
                 f32x4 acca[NS];
+                // step barrier: this layout's forward writes the LDS images (Z area, S slot 0) that the previous step's last weight
+                // gradient still reads (the narrow layouts' forward does not touch them).  Without it: a race that the x86 emulator cannot
+                // show and that happened not to bite with two tiles.
+                __syncthreads();
                 wide_forward(a, x, xin, acca);
                 fwd_head(a, x, valid, pidx, set, lsum[0], acca, ZL);
                 wide_reverse(a, x, xin, ZL);
@@ -1508,7 +1513,7 @@ struct Fused {
         } else if (wave8 >= TILES) {
             // LDSOP: two tiles per step; these waves only keep the workgroup's barrier count (2 per weight layer and step)
             for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x)
-                for (int i = 0; i < 2 * (NL + 1); ++i) __syncthreads();
+                for (int i = 0; i < 2 * (NL + 1) + 1; ++i) __syncthreads();          // + the step barrier
         } else {
             __builtin_amdgcn_s_setprio(2);          // the chain wave is the critical path of its SIMD: issue it first
             chain_role(a, lds, wave8, lane, c, q);
