@@ -1,5 +1,6 @@
-// Fused loss+gradient kernel for narrow nets (padded width <= 64): forward chain, residual head,
-// reverse chain AND the weight gradient in one persistent launch.
+// Fused loss+gradient kernel: forward chain, residual head, reverse chain AND the weight gradient in one persistent launch.
+// Layouts: padded width <= 64 with the tile's state in registers (1, 4 or 5 streams: value-only sets, the wave head, the plate head),
+// described first; padded width 96 (the reference's 8x80 net) with the state in the chain wave's LDS images ("LDSOP", further down).
 //
 // Versus chain_kernel + wgrad_kernel (pinn_device.hpp) nothing per-point ever goes to HBM as a
 // [feature][point] panel:
@@ -14,12 +15,14 @@
 //     lets the forward activations use an unscaled low part (1.5 instead of 2.5 instructions per value);
 //   * and for OVERLAP INSIDE the wave: the MFMAs of feature block m+1 are issued between the vector instructions of block m
 //     (software pipeline over the blocks of a layer and, in the forward, across layers);
-//   * forward state S_l (fp16 high parts, see below) is parked per tile as its REGISTER IMAGE: one fully coalesced 1 KB store per
-//     (stream, k-step) fragment, issued behind the next weight-fragment loads (CDNA4 returns loads and stores in order on one
-//     counter, so a store in front of a load is waited for with it).  In the reverse pass the weight-gradient wave that shares
-//     the SIMD brings the image back by LDS-DMA (no registers, and off the chain wave's instruction stream); the chain wave reads
-//     its own lanes' records back from LDS and the weight-gradient waves rebuild MFMA fragments from the same image with
-//     ds_read_b64_tr_b16 (the record order is rotated per 16-lane group so that those reads are at most 2-way bank conflicted);
+//   * forward state S_l is parked per tile as its REGISTER IMAGE: one fully coalesced 1 KB store per (stream, k-step) fragment for
+//     the fp16 high parts and one for the low parts (STATE_LO), issued behind the next weight-fragment loads (CDNA4 returns loads
+//     and stores in order on one counter, so a store in front of a load is waited for with it).  In the reverse pass the
+//     weight-gradient wave that shares the SIMD brings the high-part image back by LDS-DMA (no registers, and off the chain wave's
+//     instruction stream); the chain wave reads its own lanes' records back from LDS -- and the low parts with plain loads, so that
+//     the activation reverse sees the state in full precision -- and the weight-gradient waves rebuild MFMA fragments from the
+//     same image with ds_read_b64_tr_b16 (the record order is rotated per 16-lane group so that those reads are at most 2-way
+//     bank conflicted);
 //   * for the weight gradient  Wbar_l = sum_points S_l^T Z_l  the contraction runs over points, so
 //     both operands are needed "feature per lane, points in registers" -- the transpose of the
 //     chain layout.  Every chain wave drops its Z_l tile into LDS as the same kind of register image (ds_write_b128);
