@@ -468,11 +468,17 @@ struct Fused {
                     for (int o = 0; o < OBW; ++o) ld[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), 0));
             }
             if constexpr (L >= 2) dma_state(scr, lane16, tile_lds, L - 1, quad);      // S_{L-1} streams in while layer L is worked on
+#ifdef PINN_X_WSTAMP
+            fused_stamp(a, tracer, 96 + 2 * (NL - L));
+#endif
             // Second barrier: the tensors of layer L are complete.  This wave's contribution is the LDS-DMA of S_L, issued one layer
             // ago; everything issued since (the operations above) may stay in flight, so the drain is a COUNTED one.  (A surplus
             // operation the compiler might add only makes the wait more conservative: completion is in issue order.)
             __builtin_amdgcn_sched_barrier(0);
             wait_vmcnt<N_STORE + N_LOAD + N_DMA>();
+#ifdef PINN_X_WSTAMP
+            fused_stamp(a, tracer, 97 + 2 * (NL - L));
+#endif
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             fused_stamp(a, tracer, 65 + 3 * (NL - L));
@@ -522,7 +528,10 @@ struct Fused {
         }
         f32x4 pend[IBW][OBW];
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
-            if constexpr (LDSOP) __syncthreads();         // step barrier (see the chain role): this wave's reads of the previous step are done
+            if constexpr (LDSOP) {
+                __syncthreads();                          // step barrier (see the chain role): this wave's reads of the previous step are done
+                for (int l = 0; l < NL; ++l) lds_barrier();      // the forward's exchange barriers between the two halves of a tile
+            }
             WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend);
         }
         // ---- write this workgroup's partial gradient
@@ -726,8 +735,8 @@ struct Fused {
     }
 
     // state fragments (hi, unscaled lo) of feature block MB from per-point values
-    template <int MB>
-    static __device__ __forceinline__ void emit_state(u32x4 (&Bn)[NS][1][KS][NP], const float (&vals)[NS][4]) {
+    template <int MB, int KSF = KS>
+    static __device__ __forceinline__ void emit_state(u32x4 (&Bn)[NS][1][KSF][NP], const float (&vals)[NS][4]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             uint32_t h0, h1, l0 = 0, l1 = 0;
@@ -777,8 +786,8 @@ struct Fused {
     }
 
     // vector part of a forward block: activation of the value stream, tangent streams, split into the next layer's operand
-    template <int MB>
-    static __device__ __forceinline__ void fwd_valu(const f32x4 (&acc)[NS], u32x4 (&Bn)[NS][1][KS][NP]) {
+    template <int MB, int KSF = KS>
+    static __device__ __forceinline__ void fwd_valu(const f32x4 (&acc)[NS], u32x4 (&Bn)[NS][1][KSF][NP]) {
         float vals[NS][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -790,7 +799,7 @@ struct Fused {
             if constexpr (SECOND)                        // h_tt = (1-h^2) z_tt - 2 h h_t z_t   (z_t = acc[3] / WS)
                 vals[4][r] = sds * acc[4][r] - (2.0f * INV_WS) * h * vals[3][r] * acc[3][r];
         }
-        emit_state<MB>(Bn, vals);
+        emit_state<MB, KSF>(Bn, vals);
     }
 
     // forward first layer (K = 3, VALU): INF:191-195 with the tangent seeds e_k * sx_k
@@ -1086,64 +1095,111 @@ struct Fused {
 #pragma unroll
             for (int p = 0; p < NP; ++p) Bk[s][0][0][p] = *reinterpret_cast<const u32x4*>(img + ((s * KS + kk) * NP + p) * 1024);
     }
-    static __device__ __forceinline__ void op_store(char* img, const u32x4 (&F)[NS][1][KS][NP]) {
+    // A tile's chain is shared by two waves (tile = wave & 1, half = wave >> 1), three of the six feature blocks each: half 0 owns
+    // blocks (0, 1 | 2), half 1 blocks (4, 5 | 3) -- a pair that fills one fragment record and a single block that fills half of
+    // record 1.  The wave's results are local fragments Fl[s][0][0][p] = the pair's record, Fl[s][0][1][p].xy = the single block's
+    // 8 bytes; block numbers enter as run-time offsets only, so both halves run the same code.
+    static constexpr int HB = WB / 2;
+    static __device__ __forceinline__ int half_block(int h, int j) { return h ? (j < 2 ? 4 + j : 3) : j; }
+    // workgroup barrier that orders LDS traffic only: the chain waves' park stores and fragment loads stay in flight across it
+    static __device__ __forceinline__ void lds_barrier() {
+#if defined(__AMDGCN__)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        __syncthreads();
+#endif
+    }
+    static __device__ __forceinline__ void half_store(char* img, int h, const u32x4 (&Fl)[NS][1][2][NP]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(img + ((s * KS + kk) * NP + p) * 1024) = F[s][0][kk][p];
+            for (int p = 0; p < NP; ++p) {
+                *reinterpret_cast<u32x4*>(img + ((s * KS + 2 * h) * NP + p) * 1024) = Fl[s][0][0][p];
+                *reinterpret_cast<u32x2*>(img + ((s * KS + 1) * NP + p) * 1024 + 8 * h) = u32x2{Fl[s][0][1][p][0], Fl[s][0][1][p][1]};
+            }
     }
-    static __device__ __forceinline__ void park_wide(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
+    static __device__ __forceinline__ void half_park(const Ctx& x, int l, int h, const u32x4 (&Fl)[NS][1][2][NP]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int kk = 0; kk < KS; ++kk)
-#pragma unroll
-                for (int p = 0; p < NP; ++p)
-                    __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][p], x.scr, x.imgoff, (l - 1) * IMG_B + ((s * KS + kk) * NP + p) * 1024, 0);
+            for (int p = 0; p < NP; ++p) {
+                __builtin_amdgcn_raw_buffer_store_b128(Fl[s][0][0][p], x.scr, x.imgoff, (l - 1) * IMG_B + ((s * KS + 2 * h) * NP + p) * 1024, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(u32x2{Fl[s][0][1][p][0], Fl[s][0][1][p][1]}, x.scr, x.imgoff + 8u * h,
+                                                      (l - 1) * IMG_B + ((s * KS + 1) * NP + p) * 1024, 0);
+            }
     }
-    template <int MB>
-    static __device__ __forceinline__ void wide_fwd_epilogue(const f32x4 (&acc)[WB][NS], u32x4 (&out)[NS][1][KS][NP]) {
-        fwd_valu<MB>(acc[MB], out);
-        if constexpr (MB + 1 < WB) wide_fwd_epilogue<MB + 1>(acc, out);
-    }
-    // one hidden weight layer l (1..NL-1): S_l (image `in`) -> S_{l+1} (image `out`, parked if a reverse layer will DMA it back)
-    static __device__ __forceinline__ void wide_fwd_layer(const Ctx& x, int l, const char* in, char* outimg) {
-        f32x4 acc[WB][NS];
-#pragma unroll
-        for (int mb = 0; mb < WB; ++mb) acc_init(load_bias(x, l, mb), acc[mb]);
-        // flattened (k-step, block) sequence with the weight fragments requested two items ahead
-        constexpr int NIT = KS * WB;
-        u32x4 Af[3][1][FP];
-        load_afrags<1, FP>(x, FI::fwd_mid(l, 0, 0), Af[0]);
-        load_afrags<1, FP>(x, FI::fwd_mid(l, 1, 0), Af[1]);
+    // the GEMM of a half: its HB blocks accumulate over the KS k-steps of the operand image; weight fragments requested two items ahead
+    template <bool FWD>
+    static __device__ __forceinline__ void half_gemm(const Ctx& x, int frag_l0 /*fragment index of (block 0, k-step 0) of the layer*/, int h, const char* in,
+                                                     f32x4 (&acc)[HB][NS]) {
+        constexpr int NIT = KS * HB, PARTS = FWD ? FP : RP;
+        auto frag = [&](int t) { return frag_l0 + half_block(h, t % HB) * KS + t / HB; };
+        u32x4 Af[3][1][PARTS];
+        load_afrags<1, PARTS>(x, frag(0), Af[0]);
+        load_afrags<1, PARTS>(x, frag(1), Af[1]);
         u32x4 Bk[NS][1][1][NP];
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
-            const int kk = t / WB, mb = t % WB;
-            if (mb == 0) op_load(in, kk, Bk);
-            if (t + 2 < NIT) load_afrags<1, FP>(x, FI::fwd_mid(l, (t + 2) % WB, (t + 2) / WB), Af[(t + 2) % 3]);
-            fwd_kstep<0, 1>(Af[t % 3], Bk, acc[mb]);
+            if (t % HB == 0) op_load(in, t / HB, Bk);
+            if (t + 2 < NIT) load_afrags<1, PARTS>(x, frag(t + 2), Af[(t + 2) % 3]);
+            if constexpr (FWD) fwd_kstep<0, 1>(Af[t % 3], Bk, acc[t % HB]);
+            else bwd_kstep<0, 1>(Af[t % 3], Bk, acc[t % HB]);
         }
-        u32x4 out[NS][1][KS][NP];
-        wide_fwd_epilogue<0>(acc, out);
-        op_store(outimg, out);
-        if (l + 1 <= NL - 1) park_wide(x, l + 1, out);
     }
-    // forward of one tile: returns the output layer's products (acca) for fwd_head; S_NL ends in the second buffer
-    static __device__ __forceinline__ void wide_forward(const FusedArgs& a, const Ctx& x, const float (&xin)[3], f32x4 (&acca)[NS]) {
+    template <int J>
+    static __device__ __forceinline__ void wide_fwd_epilogue(const f32x4 (&acc)[HB][NS], u32x4 (&out)[NS][1][2][NP]) {
+        fwd_valu<J, 2>(acc[J], out);
+        if constexpr (J + 1 < HB) wide_fwd_epilogue<J + 1>(acc, out);
+    }
+    // one hidden weight layer l (1..NL-1): S_l (image `in`) -> this half's blocks of S_{l+1} (image `out`, parked if a reverse layer will DMA it back)
+    static __device__ __forceinline__ void wide_fwd_layer(const Ctx& x, int l, int h, const char* in, char* outimg) {
+        f32x4 acc[HB][NS];
+#pragma unroll
+        for (int j = 0; j < HB; ++j) acc_init(load_bias(x, l, half_block(h, j)), acc[j]);
+        half_gemm<true>(x, FI::fwd_mid(l, 0, 0), h, in, acc);
+        u32x4 out[NS][1][2][NP];
+        wide_fwd_epilogue<0>(acc, out);
+        half_store(outimg, h, out);
+        if (l + 1 <= NL - 1) half_park(x, l + 1, h, out);
+    }
+    template <int J>
+    static __device__ __forceinline__ void wide_first(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, u32x4 (&Bn)[NS][1][2][NP]) {
+        const int mb = half_block(h, J);
+        float vals[NS][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(x.cw0 + (16 * mb + r) * 16);
+            float hh, sd;
+            tanh_act(w[3] + w[0] * xin[0] + w[1] * xin[1] + w[2] * xin[2], hh, sd);
+            vals[0][r] = hh;
+#pragma unroll
+            for (int s = 1; s <= NT; ++s) vals[s][r] = sd * (a.sx[s - 1] * w[s - 1]);
+        }
+        emit_state<J, 2>(Bn, vals);
+        if constexpr (J + 1 < HB) wide_first<J + 1>(a, x, xin, h, Bn);
+    }
+    // forward of one tile (this wave's half): returns the output layer's products (acca, both halves compute them) for fwd_head; S_NL
+    // ends in the second buffer.  One LDS barrier behind every layer: the halves exchange their blocks through the image.
+    static __device__ __forceinline__ void wide_forward(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, f32x4 (&acca)[NS]) {
+        static_assert(!LDSOP || CONST_LDS, "the LDS-operand layout reads the first layer's rows from the LDS constants");
         char* opa = x.tenZ + x.imgoff;                       // Z area
         char* opb = x.tenZ + TENSOR_Z_B + x.imgoff;          // S slot 0 = slot_of(NL): S_NL ends where the reverse expects it
         {
-            u32x4 B[NS][1][KS][NP];
-            first_mb<0>(a, x, xin, B);
-            op_store(opa, B);
-            park_wide(x, 1, B);
+            u32x4 B[NS][1][2][NP];
+            wide_first<0>(a, x, xin, h, B);
+            half_store(opa, h, B);
+            half_park(x, 1, h, B);
         }
+        lds_barrier();
+        fused_stamp(a, x.tracer, 32);
         for (int l = 1; l < NL; ++l) {                       // odd layers: first -> second buffer, even layers back
-            if (l & 1) wide_fwd_layer(x, l, opa, opb);
-            else wide_fwd_layer(x, l, opb, opa);
+            if (l & 1) wide_fwd_layer(x, l, h, opa, opb);
+            else wide_fwd_layer(x, l, h, opb, opa);
+            lds_barrier();
+            fused_stamp(a, x.tracer, 32 + l);
         }
         // output layer (16 padded outputs): one block, operand S_NL from slot 0 (NL - 1 is odd)
         acc_init(load_bias(x, NL, 0), acca);
@@ -1156,12 +1212,13 @@ struct Fused {
         }
     }
     // reverse vector part with the state in full precision (hi + unscaled lo from the operand-layout image)
-    template <int MB>
-    static __device__ __forceinline__ void wide_bwd_epilogue(f32x4 (&acc)[WB][NS], const char* simg, u32x4 (&Zn)[NS][1][KS][NP], int c, int q) {
+    template <int J>
+    static __device__ __forceinline__ void wide_bwd_epilogue(f32x4 (&acc)[HB][NS], const char* simg, int h, u32x4 (&Zn)[NS][1][2][NP], int c, int q) {
+        const int mb = half_block(h, J);
         float st[NS][4];
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
-            const char* rec = simg + ((s * KS + (MB >> 1)) * NP) * 1024 + 8 * (MB & 1);
+            const char* rec = simg + ((s * KS + (mb >> 1)) * NP) * 1024 + 8 * (mb & 1);
             const u32x2 hi = *reinterpret_cast<const u32x2*>(rec);
             const u32x2 lo = *reinterpret_cast<const u32x2*>(rec + 1024);
 #pragma unroll
@@ -1172,64 +1229,65 @@ struct Fused {
         float vals[NS][1][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float h = st[0][r];
-            const float sds = (1.0f - h * h) * INV_WS;
+            const float hh = st[0][r];
+            const float sds = (1.0f - hh * hh) * INV_WS;
             float dot = 0.0f;
 #pragma unroll
             for (int s = 1; s <= NT; ++s) {
-                dot += acc[MB][s][r] * st[s][r];
-                vals[s][0][r] = sds * acc[MB][s][r];
+                dot += acc[J][s][r] * st[s][r];
+                vals[s][0][r] = sds * acc[J][s][r];
             }
-            vals[0][0][r] = sds * acc[MB][0][r] - (2.0f * INV_WS) * h * dot;
+            vals[0][0][r] = sds * acc[J][0][r] - (2.0f * INV_WS) * hh * dot;
         }
-        CH::template emit<KS, MB>(Zn, vals, nullptr, WIDTH, c, q);
-        if constexpr (MB + 1 < WB) wide_bwd_epilogue<MB + 1>(acc, simg, Zn, c, q);
+        CH::template emit<2, J>(Zn, vals, nullptr, WIDTH, c, q);
+        if constexpr (J + 1 < HB) wide_bwd_epilogue<J + 1>(acc, simg, h, Zn, c, q);
     }
     // reverse of one tile; on entry the first barrier of the top layer has NOT been passed, S_NL (hi + lo) sits in S slot 0
-    static __device__ __forceinline__ void wide_reverse(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&ZL)[NS][1][1][NP]) {
-        u32x4 Zn[NS][1][KS][NP];
+    static __device__ __forceinline__ void wide_reverse(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, const u32x4 (&ZL)[NS][1][1][NP]) {
+        u32x4 Zn[NS][1][2][NP];
         {
+            fused_stamp(a, x.tracer, 2);
             __syncthreads();                                   // A(NL); S_NL already sits in slot_of(NL) in the image layout
-            put_zimage<1>(x.imgZ(), ZL);
+            fused_stamp(a, x.tracer, 3);
+            if (h == 0) put_zimage<1>(x.imgZ(), ZL);           // (both halves hold the same Z_NL)
             __syncthreads();                                   // B(NL)
-            f32x4 acc[WB][NS];
+            fused_stamp(a, x.tracer, 4);
+            f32x4 acc[HB][NS];
 #pragma unroll
-            for (int mb = 0; mb < WB; ++mb) {
+            for (int j = 0; j < HB; ++j) {
                 u32x4 Af[1][RP];
-                load_afrags<1, RP>(x, FI::bwd_last(NL, mb), Af);
-                acc_zero(acc[mb]);
-                bwd_kstep<0, 1>(Af, ZL, acc[mb]);
+                load_afrags<1, RP>(x, FI::bwd_last(NL, half_block(h, j)), Af);
+                acc_zero(acc[j]);
+                bwd_kstep<0, 1>(Af, ZL, acc[j]);
             }
-            wide_bwd_epilogue<0>(acc, x.imgS(NL), Zn, x.c, x.q);
+            wide_bwd_epilogue<0>(acc, x.imgS(NL), h, Zn, x.c, x.q);
+            fused_stamp(a, x.tracer, 5);
         }
-        wide_down<NL - 1>(a, x, xin, Zn);
+        wide_down<NL - 1>(a, x, xin, h, Zn);
     }
-    // entry: Zc = Z_L in registers (fragment order), first barrier of layer L not yet passed
+    // entry: Zc = this half's blocks of Z_L in registers, first barrier of layer L not yet passed
     template <int L>
-    static __device__ __forceinline__ void wide_down(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&Zc)[NS][1][KS][NP]) {
+    static __device__ __forceinline__ void wide_down(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, const u32x4 (&Zc)[NS][1][2][NP]) {
         __syncthreads();                                       // A(L): the weight-gradient waves are done with Z_{L+1}, S_{L+1}
-        put_zimage<KS>(x.imgZ(), Zc);
-        if constexpr (L == 0) put_input_state(a, x, xin);
+        fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
+        half_store(x.imgZ(), h, Zc);
+        if constexpr (L == 0) {
+            if (h == 0) put_input_state(a, x, xin);
+        }
+#ifdef PINN_X_WSTAMP
+        fused_stamp(a, x.tracer, 44 + (NL - L));
+#endif
         __syncthreads();                                       // B(L)
+        fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
         if constexpr (L >= 1) {
-            f32x4 acc[WB][NS];
+            f32x4 acc[HB][NS];
 #pragma unroll
-            for (int mb = 0; mb < WB; ++mb) acc_zero(acc[mb]);
-            constexpr int NIT = KS * WB;
-            u32x4 Af[3][1][RP];
-            load_afrags<1, RP>(x, FI::bwd_mid(NL, L, 0, 0), Af[0]);
-            load_afrags<1, RP>(x, FI::bwd_mid(NL, L, 1, 0), Af[1]);
-            u32x4 Bk[NS][1][1][NP];
-#pragma unroll
-            for (int t = 0; t < NIT; ++t) {
-                const int kk = t / WB, mb = t % WB;
-                if (mb == 0) op_load(x.imgZ(), kk, Bk);       // this wave's own records of the Z_L image it has just written
-                if (t + 2 < NIT) load_afrags<1, RP>(x, FI::bwd_mid(NL, L, (t + 2) % WB, (t + 2) / WB), Af[(t + 2) % 3]);
-                bwd_kstep<0, 1>(Af[t % 3], Bk, acc[mb]);
-            }
-            u32x4 Zn[NS][1][KS][NP];
-            wide_bwd_epilogue<0>(acc, x.imgS(L), Zn, x.c, x.q);
-            wide_down<L - 1>(a, x, xin, Zn);
+            for (int j = 0; j < HB; ++j) acc_zero(acc[j]);
+            half_gemm<false>(x, FI::bwd_mid(NL, L, 0, 0), h, x.imgZ(), acc);      // the Z_L image both halves have just written
+            u32x4 Zn[NS][1][2][NP];
+            wide_bwd_epilogue<0>(acc, x.imgS(L), h, Zn, x.c, x.q);
+            fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
+            wide_down<L - 1>(a, x, xin, h, Zn);
         }
     }
 
@@ -1432,12 +1490,14 @@ struct Fused {
         xin[2] = pt[pidx] * a.sx[2] + a.ox[2];
     }
 
-    static __device__ __forceinline__ void chain_role(const FusedArgs& a, char* lds, int wave, int lane, int c, int q) {
+    static __device__ __forceinline__ void chain_role(const FusedArgs& a, char* lds, int wave4, int lane, int c, int q) {
+        // LDSOP: two waves per tile (tile = wave & 1, half = wave >> 1); otherwise one wave per tile
+        const int wave = LDSOP ? (wave4 & 1) : wave4, half = LDSOP ? (wave4 >> 1) : 0;
         const long gwave = (long)blockIdx.x * TILES + wave;
         Ctx x;
         x.init(a, lds, wave, lane, c, q);
         x.set_tile(a, gwave);
-        x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0;
+        x.tracer = blockIdx.x == 0 && wave4 == 0 && lane == 0;
         constexpr int NSETS = NS == 1 ? FUSED_MAX_SETS : 1;
         float lsum[NSETS][8];
 #pragma unroll
@@ -1458,7 +1518,7 @@ struct Fused {
             } else {
                 load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + wave, c, xin, valid, pidx);
             }
-            x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0 && step == 2 * (long)gridDim.x;      // a steady-state step
+            x.tracer = blockIdx.x == 0 && wave4 == 0 && lane == 0 && step == 2 * (long)gridDim.x;      // a steady-state step
             fused_stamp(a, x.tracer, 0);
             if constexpr (LDSOP) {
                 u32x4 ZL[NS][1][1][NP];
@@ -1467,9 +1527,14 @@ struct Fused {
                 // gradient still reads (the narrow layouts' forward does not touch them).  Without it: a race that the x86 emulator cannot
                 // show and that happened not to bite with two tiles.
                 __syncthreads();
-                wide_forward(a, x, xin, acca);
-                fwd_head(a, x, valid, pidx, set, lsum[0], acca, ZL);
-                wide_reverse(a, x, xin, ZL);
+                wide_forward(a, x, xin, half, acca);
+                float ls[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) ls[i] = 0.0f;
+                fwd_head(a, x, valid, pidx, set, ls, acca, ZL);          // both halves: the same Z_NL; the loss sums count once
+#pragma unroll
+                for (int i = 0; i < 8; ++i) lsum[0][i] += half == 0 ? ls[i] : 0.0f;
+                wide_reverse(a, x, xin, half, ZL);
             } else {
                 u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
                 float ls[8];
@@ -1492,7 +1557,7 @@ struct Fused {
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 4);
                 v += __shfl_xor(v, 8);
-                if (lane == 0) a.loss_part[(gwave * NSETS + k) * 8 + i] = v;
+                if (lane == 0 && half == 0) a.loss_part[(gwave * NSETS + k) * 8 + i] = v;
             }
     }
 
@@ -1513,10 +1578,6 @@ struct Fused {
         }
         if (wave8 >= 4) {
             wgrad_role(a, lds, wave8 - 4, lane, c, q);
-        } else if (wave8 >= TILES) {
-            // LDSOP: two tiles per step; these waves only keep the workgroup's barrier count (2 per weight layer and step)
-            for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x)
-                for (int i = 0; i < 2 * (NL + 1) + 1; ++i) __syncthreads();          // + the step barrier
         } else {
             __builtin_amdgcn_s_setprio(2);          // the chain wave is the critical path of its SIMD: issue it first
             chain_role(a, lds, wave8, lane, c, q);

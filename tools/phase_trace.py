@@ -7,7 +7,8 @@ prec = 'f16x3'
 import os
 libp = os.path.join('build/exp', sys.argv[1], 'libpinn_hip.so') if len(sys.argv) > 1 else None
 dev = torch.device('cuda:0'); NL = 8
-layers = [3] + NL * [64] + [7]
+width = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+layers = [3] + NL * [width] + [7]
 rng = np.random.default_rng(0); Ws, bs = po.xavier_init(layers, rng); flat = po.pack_params(Ws, bs)
 n = 2_000_000
 X = np.random.default_rng(1).random((n, 3)) * np.array([30, 30, 20.])
@@ -26,6 +27,8 @@ t = stamps.cpu().numpy()
 c = t[:64]; w = t[64:]
 print('chain wave (cycles, last step of WG0):')
 print(f'  forward {c[1]-c[0]}  head {c[2]-c[1]}')
+if width > 64:
+    print('  forward layer ends rel. step start:', [int(c[32 + l] - c[0]) for l in range(NL)])
 tot = 0
 for i, L in enumerate(range(NL, -1, -1)):
     a, b, e = c[3 + 3 * i], c[4 + 3 * i], c[5 + 3 * i]
@@ -39,3 +42,7 @@ for i, L in enumerate(range(NL, -1, -1)):
     a, b, e = w[3 * i], w[1 + 3 * i], w[2 + 3 * i]
     prev_end = w[2 + 3 * (i - 1)] if i > 0 else a
     print(f'  L={L}: wait@A {a-prev_end:6d}  wait@B {b-a:6d}  wgrad {e-b:6d}')
+if len(sys.argv) > 3:
+    print('window detail (cycles after barrier A): chain half_store done | wgrad ops issued, counted wait done')
+    for i, L in enumerate(range(NL, -1, -1)):
+        print(f'  L={L}: chain {c[44 + i] - c[3 + 3 * i]:6d} | wgrad issued {t[96 + 2 * i] - w[3 * i]:6d}  waited {t[97 + 2 * i] - w[3 * i]:6d}  barrier {w[1 + 3 * i] - w[3 * i]:6d}')

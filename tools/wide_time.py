@@ -12,14 +12,16 @@ n = 1_000_000
 X = np.random.default_rng(1).random((n, 3)) * np.array([30, 30, 20.])
 theta = torch.from_numpy(flat.astype(np.float32)).to(dev)
 xs = [torch.from_numpy(np.ascontiguousarray(X[:, k], dtype=np.float32)).to(dev) for k in range(3)]
-eng = HipEngine(layers, precision='f16x3', device=dev, max_points=1 << 18)
+libp = os.path.join(ROOT, 'build/exp', sys.argv[2], 'libpinn_hip.so') if len(sys.argv) > 2 else None
+eng = HipEngine(layers, precision='f16x3', device=dev, max_points=1 << 18, **({'lib_path': libp} if libp else {}))
+modes = (True, False, True) if libp is None else (True, True)
 m = 20000
 ss, g, _ = po.wave2d_loss_grad(flat, layers, X[:m, 0], X[:m, 1], X[:m, 2], [0, 0, 0], [30, 30, 20], True, term_weights=np.ones(7) / m)
 rel = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / np.linalg.norm(b))
 tw = np.ones(7) / n
 for _ in range(30):       # clock ramp
     eng.wave_loss_grad(theta, *xs, [0, 0, 0], [30, 30, 20], True, tw)
-for fused in (True, False, True):
+for fused in modes:
     eng.lib.set_fused(fused)
     l, gr = eng.wave_loss_grad(theta, *(v[:m].contiguous() for v in xs), [0, 0, 0], [30, 30, 20], True, np.ones(7) / m)
     e = (rel(l.cpu().numpy(), ss), rel(gr.cpu().numpy(), g))
