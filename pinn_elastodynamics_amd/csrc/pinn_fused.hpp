@@ -72,6 +72,16 @@ struct FusedArgs {
     unsigned long long* dbg;   // optional phase timestamps (s_memtime) of workgroup 0, chain wave 0 / weight-gradient wave 0; nullptr = off
 };
 
+// A launch constant, made opaque at its point of use inside the step loop.  Otherwise the compiler hoists whatever is computed from
+// such constants alone (2 * term weight, the packed tangent seeds of the input state ...) out of the loop into registers it then has
+// to spill -- and a spill reload in the step is a full memory round trip (round-2 phase stamps: 3.5 k cycles in the residual head).
+__device__ __forceinline__ float in_loop(float v) {
+#if defined(__AMDGCN__) && !defined(PINN_X_NOINLOOP)
+    asm volatile("" : "+s"(v));
+#endif
+    return v;
+}
+
 __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int slot) {
     if (a.dbg != nullptr && who) a.dbg[slot] = __builtin_readcyclecounter();
 }
@@ -261,6 +271,106 @@ struct Fused {
         }
     }
 
+    // LDSOP mid layers: the wave's 3 x 3 blocks in ONE pass -- in-blocks (pair sp | single ss) x out-blocks (pair zp | single zs), both
+    // state parts -- so that every operand fragment of a (k-step, stream) group is transpose-read once: 24 reads per group where four
+    // calls of wg_blocks (2x2, 2x1, 1x2, 1x1) issue 48.  The round-2 phase trace had this role bound by its LDS reads (786 KB per
+    // layer and workgroup).
+    // The LDS-DMA of S_{L-1} rides along, a slice behind every group: issued as one burst in the hand-off window, the 21 KB of reads
+    // per wave (running sums + state image) took 3-7 k cycles to ISSUE (phase stamps: a compute unit's outstanding-request capacity
+    // against the memory latency), with every wave of the workgroup waiting at the barrier behind it.
+    struct DmaSrc;
+    struct DmaJob {
+        const DmaSrc* scr;
+        unsigned lane16;
+        char* tile_lds;
+        int quad;
+    };
+    template <int L>
+    static __device__ __forceinline__ void wg_blocks33(const char* sp0, const char* sp1, const char* ss0, const char* ss1, const char* zp0, const char* zp1,
+                                                       const char* zs0, const char* zs1, f32x4 (&acc)[3][3], const DmaJob& job) {
+        constexpr int NGRP = NJ * NS;
+        auto dma_slice = [&](int g) {
+            if constexpr (L >= 2) dma_state(*job.scr, job.lane16, job.tile_lds, L - 1, job.quad, g * N_DMA_ALL / NGRP, (g + 1) * N_DMA_ALL / NGRP);
+        };
+        static_assert(NP == 2 || !LDSOP, "split-precision layout");
+        f32x4 cc[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) cc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        struct Frags { u32x4 Ah[3], Al[3], Bh[3], Bl[3]; };
+        auto fetch = [&](int g, Frags& f) {
+            const int j = g / NS, st = g % NS;
+            const int os = 2 * j * WAVE_B + st * KS * SP * 1024, oz = 2 * j * WAVE_B + st * KS * NP * 1024;
+            f.Ah[0] = sfrag(sp0, sp1, os);
+            f.Ah[1] = sfrag(sp0, sp1, os + 8);
+            f.Ah[2] = sfrag(ss0, ss1, os);
+            f.Bh[0] = sfrag(zp0, zp1, oz);
+            f.Bh[1] = sfrag(zp0, zp1, oz + 8);
+            f.Bh[2] = sfrag(zs0, zs1, oz);
+            f.Bl[0] = sfrag(zp0, zp1, oz + 1024);
+            f.Bl[1] = sfrag(zp0, zp1, oz + 1024 + 8);
+            f.Bl[2] = sfrag(zs0, zs1, oz + 1024);
+            f.Al[0] = sfrag(sp0, sp1, os + 1024);
+            f.Al[1] = sfrag(sp0, sp1, os + 1024 + 8);
+            f.Al[2] = sfrag(ss0, ss1, os + 1024);
+        };
+        auto work = [&](const Frags& f) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc[a][b] = Op::mfma(f.Ah[a], f.Bh[b], acc[a][b]);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) cc[a][b] = Op::mfma(f.Ah[a], f.Bl[b], cc[a][b]);
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) acc[a][b] = Op::mfma(f.Al[a], f.Bh[b], acc[a][b]);
+        };
+        static_assert((NJ * NS) % 2 == 0, "two fragment sets in strict alternation");
+        Frags fa, fb;
+        fetch(0, fa);
+#pragma unroll
+        for (int g = 0; g < NJ * NS; g += 2) {
+            fetch(g + 1, fb);
+            work(fa);
+            dma_slice(g);
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 2 < NJ * NS) fetch(g + 2, fa);
+            work(fb);
+            dma_slice(g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[a][b][r] += cc[a][b][r] * INV_LS;
+    }
+    // bias gradient of three out-blocks (pair zp | single zs):  ones^T . Z of the value stream, both parts
+    static __device__ __forceinline__ void wg_bias3(const char* zp0, const char* zp1, const char* zs0, const char* zs1, float (&bias_out)[3]) {
+        const uint32_t one2 = pack2<Op>(1.0f, 1.0f);
+        const u32x4 ones = {one2, one2, one2, one2};
+        f32x4 bm[3], bc[3];
+#pragma unroll
+        for (int b = 0; b < 3; ++b) bm[b] = bc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int oz = 2 * j * WAVE_B;
+            bm[0] = Op::mfma(ones, sfrag(zp0, zp1, oz), bm[0]);
+            bm[1] = Op::mfma(ones, sfrag(zp0, zp1, oz + 8), bm[1]);
+            bm[2] = Op::mfma(ones, sfrag(zs0, zs1, oz), bm[2]);
+            bc[0] = Op::mfma(ones, sfrag(zp0, zp1, oz + 1024), bc[0]);
+            bc[1] = Op::mfma(ones, sfrag(zp0, zp1, oz + 1024 + 8), bc[1]);
+            bc[2] = Op::mfma(ones, sfrag(zs0, zs1, oz + 1024), bc[2]);
+        }
+#pragma unroll
+        for (int b = 0; b < 3; ++b) bias_out[b] = bm[b][0] + bc[b][0] * INV_LS;
+    }
+
     struct WgCtx {                     // lane bases of a weight-gradient wave (chain wave 0's tensors + the lane part)
         const char* z0;                // Z image, first four points of the k-slots
         const char* z1;                // Z image, the +4 points
@@ -275,7 +385,7 @@ struct Fused {
     // shares a fragment record and a single block, the same shape for every wave (offsets at run time, block counts at compile time).
     static __device__ __forceinline__ int wide_block(int half, int i) { return i < 2 ? 2 * half + i : 4 + half; }
     template <int L>
-    static __device__ __forceinline__ void wgrad_wide(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW]) {
+    static __device__ __forceinline__ void wgrad_wide(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW], const DmaJob& job) {
         const char* s0 = w.s0 + slot_of(L) * IMG_B;
         const char* s1 = w.s1 + slot_of(L) * IMG_B;
         const int wi = quad >> 1, wo = quad & 1;
@@ -312,40 +422,22 @@ struct Fused {
             const char* zp1 = w.z1 + zimg_block(2 * wo);
             const char* zs0 = w.z0 + zimg_block(4 + wo);
             const char* zs1 = w.z1 + zimg_block(4 + wo);
-            float bp[2], bs[1], dummy2[2], dummy1[1];
-            {
-                f32x4 t[2][2] = {{pend[0][0], pend[0][1]}, {pend[1][0], pend[1][1]}};
-                wg_blocks<2, 2, true>(sp0, sp1, zp0, zp1, t, bp);
-                pend[0][0] = t[0][0]; pend[0][1] = t[0][1]; pend[1][0] = t[1][0]; pend[1][1] = t[1][1];
-            }
-            {
-                f32x4 t[2][1] = {{pend[0][2]}, {pend[1][2]}};
-                wg_blocks<2, 1, true>(sp0, sp1, zs0, zs1, t, bs);
-                pend[0][2] = t[0][0]; pend[1][2] = t[1][0];
-            }
-            {
-                f32x4 t[1][2] = {{pend[2][0], pend[2][1]}};
-                wg_blocks<1, 2, true>(ss0, ss1, zp0, zp1, t, dummy2);
-                pend[2][0] = t[0][0]; pend[2][1] = t[0][1];
-            }
-            {
-                f32x4 t[1][1] = {{pend[2][2]}};
-                wg_blocks<1, 1, true>(ss0, ss1, zs0, zs1, t, dummy1);
-                pend[2][2] = t[0][0];
-            }
+            wg_blocks33<L>(sp0, sp1, ss0, ss1, zp0, zp1, zs0, zs1, pend, job);
             if (wi == 0) {                 // the bias blocks of out-half wo
-                A.biasw[L][0] += bp[0];
-                A.biasw[L][1] += bp[1];
-                A.biasw[L][2] += bs[0];
+                float b3[3];
+                wg_bias3(zp0, zp1, zs0, zs1, b3);
+                A.biasw[L][0] += b3[0];
+                A.biasw[L][1] += b3[1];
+                A.biasw[L][2] += b3[2];
             }
         }
     }
 
     // weight gradient of weight layer L (quad = weight-gradient wave index 0..3)
     template <int L>
-    static __device__ __forceinline__ void wgrad(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW]) {
+    static __device__ __forceinline__ void wgrad(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW], const DmaJob& job) {
         if constexpr (LDSOP) {
-            wgrad_wide<L>(w, A, quad, ld, pend);
+            wgrad_wide<L>(w, A, quad, ld, pend, job);
         } else {
             wgrad_narrow<L>(w, A, quad, ld, pend);
         }
@@ -412,13 +504,16 @@ struct Fused {
 #endif
         }
     };
-    static __device__ __forceinline__ void dma_state(const DmaSrc& src, unsigned lane16, char* tile_lds, int l /*1..NL-1*/, int quad) {
+    static constexpr int N_DMA_ALL = LDSOP ? IMG_B / 2048 : IMG_B / 1024;       // LDSOP: two waves share a tile's records
+    static __device__ __forceinline__ void dma_state(const DmaSrc& src, unsigned lane16, char* tile_lds, int l /*1..NL-1*/, int quad, int ii0 = 0,
+                                                     int ii1 = N_DMA_ALL) {
         if constexpr (SLDS) return;
         char* dst = tile_lds + TENSOR_Z_B + slot_of(l) * IMG_B;
         // LDSOP: two tiles, four waves: wave quad brings every second record of tile quad & 1 (records quad >> 1, +2, ...)
         const int i0 = LDSOP ? (quad >> 1) : 0;
 #pragma unroll
-        for (int ii = 0; ii < (LDSOP ? IMG_B / 2048 : IMG_B / 1024); ++ii) {
+        for (int ii = 0; ii < N_DMA_ALL; ++ii) {
+            if (ii < ii0 || ii >= ii1) continue;
             const int i = LDSOP ? i0 + 2 * ii : ii;
 #if defined(__AMDGCN__)
             const unsigned lds_addr = (unsigned)(uintptr_t)((lds_void*)(dst + i * 1024));
@@ -428,6 +523,18 @@ struct Fused {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_void*)(dst + i * 1024), 16, lane16, (l - 1) * IMG_B + i * 1024, 0, 0);
 #endif
         }
+    }
+
+    // LDSOP forward: S_k (k = 1..NL-1) sits in the tile's Z area (k odd) or S slot 0 (k even), complete behind the layer's barrier; copy
+    // this wave's records (the ones dma_state brings back) to the scratch image.  The LDS reads are drained by the next lds_barrier.
+    static __device__ __forceinline__ void park_image(__amdgpu_buffer_rsrc_t scr, unsigned lane16, const char* tile_lds, int k, int quad) {
+        const char* src = tile_lds + ((k & 1) ? 0 : TENSOR_Z_B) + lane16;
+        const int i0 = quad >> 1;
+        u32x4 v[N_DMA_ALL];
+#pragma unroll
+        for (int ii = 0; ii < N_DMA_ALL; ++ii) v[ii] = *reinterpret_cast<const u32x4*>(src + (i0 + 2 * ii) * 1024);
+#pragma unroll
+        for (int ii = 0; ii < N_DMA_ALL; ++ii) __builtin_amdgcn_raw_buffer_store_b128(v[ii], scr, lane16, (k - 1) * IMG_B + (i0 + 2 * ii) * 1024, 0);
     }
 
     // accumulator blocks of an in-memory layer: record (L - NREG - 1, i, o) of this wave's 1 KB-record area
@@ -447,7 +554,9 @@ struct Fused {
         // the stores of layer L+1's in-memory sums, the loads of layer L's, the LDS-DMA of S_{L-1}
         static constexpr int N_STORE = in_memory(L + 1) ? IBW * OBW : 0;
         static constexpr int N_LOAD = in_memory(L) ? IBW * OBW : 0;
-        static constexpr int N_DMA = (!SLDS && L >= 2) ? (LDSOP ? IMG_B / 2048 : IMG_B / 1024) : 0;      // LDSOP: two waves share a tile's records
+        // LDSOP mid layers: the DMA of S_{L-1} is issued inside the weight gradient of layer L (wg_blocks33), not in the window
+        static constexpr bool DMA_IN_WINDOW = !SLDS && L >= 2 && (!LDSOP || L == NL);
+        static constexpr int N_DMA = DMA_IN_WINDOW ? N_DMA_ALL : 0;
         static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const WgCtx& w, const DmaSrc& scr, __amdgpu_buffer_rsrc_t accr,
                                                    unsigned lane16, char* tile_lds, Acc& A, int quad, f32x4 (&pend)[IBW][OBW]) {
             __syncthreads();                                   // (chain waves now overwrite the tensors; everything this wave had in flight is done)
@@ -467,7 +576,7 @@ struct Fused {
 #pragma unroll
                     for (int o = 0; o < OBW; ++o) ld[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), 0));
             }
-            if constexpr (L >= 2) dma_state(scr, lane16, tile_lds, L - 1, quad);      // S_{L-1} streams in while layer L is worked on
+            if constexpr (DMA_IN_WINDOW) dma_state(scr, lane16, tile_lds, L - 1, quad);      // S_{L-1} streams in while layer L is worked on
 #ifdef PINN_X_WSTAMP
             fused_stamp(a, tracer, 96 + 2 * (NL - L));
 #endif
@@ -482,7 +591,7 @@ struct Fused {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             fused_stamp(a, tracer, 65 + 3 * (NL - L));
-            wgrad<L>(w, A, quad, ld, pend);
+            wgrad<L>(w, A, quad, ld, pend, DmaJob{&scr, lane16, tile_lds, quad});
             fused_stamp(a, tracer, 66 + 3 * (NL - L));
             if constexpr (L >= 1) WgDown<L - 1>::run(a, tracer, w, scr, accr, lane16, tile_lds, A, quad, pend);
         }
@@ -519,6 +628,8 @@ struct Fused {
         scr.init(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES, SCRATCH_BYTES);
         const unsigned lane16 = (unsigned)lane * 16u;
         char* tile_lds = lds + ftile * WAVE_B;
+        const __amdgpu_buffer_rsrc_t scr_st =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES, 0x00020000);
         // this wave's in-memory accumulator records, zeroed here (same-wave program order makes the first loads see the zeros)
         const __amdgpu_buffer_rsrc_t accr = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(reinterpret_cast<char*>(a.wg_acc) + ((long)blockIdx.x * 4 + quad) * (long)WG_ACC_BYTES), 0, (int)WG_ACC_BYTES, 0x00020000);
@@ -530,7 +641,12 @@ struct Fused {
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
             if constexpr (LDSOP) {
                 __syncthreads();                          // step barrier (see the chain role): this wave's reads of the previous step are done
-                for (int l = 0; l < NL; ++l) lds_barrier();      // the forward's exchange barriers between the two halves of a tile
+                // the forward's exchange barriers between the two halves of a tile; behind barrier l the image of S_{l+1} is complete and
+                // this wave parks its share of it (the records it will bring back by LDS-DMA: same wave, same addresses, program order)
+                for (int l = 0; l < NL; ++l) {
+                    lds_barrier();
+                    if (l + 1 <= NL - 1) park_image(scr_st, lane16, tile_lds, l + 1, quad);
+                }
             }
             WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend);
         }
@@ -1014,7 +1130,7 @@ struct Fused {
                 // first layer's weight gradient keeps full input precision (combined at write-out)
                 float v = 0.0f;
                 if (x.q < 2 && r < 3) {
-                    const float full = (s == 0) ? xin[r] : (r == s - 1 ? a.sx[r] : 0.0f);
+                    const float full = (s == 0) ? xin[r] : (r == s - 1 ? in_loop(a.sx[r]) : 0.0f);
                     v = x.q == 0 ? full : (full - round16<Op>(full)) * Op::LO_SCALE;
                 }
                 v0[s][0][r] = v;
@@ -1121,32 +1237,59 @@ struct Fused {
                 *reinterpret_cast<u32x2*>(img + ((s * KS + 1) * NP + p) * 1024 + 8 * h) = u32x2{Fl[s][0][1][p][0], Fl[s][0][1][p][1]};
             }
     }
-    static __device__ __forceinline__ void half_park(const Ctx& x, int l, int h, const u32x4 (&Fl)[NS][1][2][NP]) {
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                __builtin_amdgcn_raw_buffer_store_b128(Fl[s][0][0][p], x.scr, x.imgoff, (l - 1) * IMG_B + ((s * KS + 2 * h) * NP + p) * 1024, 0);
-                __builtin_amdgcn_raw_buffer_store_b64(u32x2{Fl[s][0][1][p][0], Fl[s][0][1][p][1]}, x.scr, x.imgoff + 8u * h,
-                                                      (l - 1) * IMG_B + ((s * KS + 1) * NP + p) * 1024, 0);
-            }
+    // The GEMM of a half: its HB blocks accumulate over the KS k-steps of the operand image, NIT = KS * HB items of (k-step, block).
+    // Weight fragments come from memory (L2) and are requested far ahead: with a two-item distance every item stalled on its load
+    // (round-2 phase stamps: 10 k cycles per forward layer for 3.5 k of matrix work).
+    static constexpr int NIT = KS * HB;
+    static __device__ __forceinline__ int item_frag(int frag_l0 /*fragment (block 0, k-step 0) of the layer*/, int h, int t) {
+        return frag_l0 + half_block(h, t % HB) * KS + t / HB;
     }
-    // the GEMM of a half: its HB blocks accumulate over the KS k-steps of the operand image; weight fragments requested two items ahead
-    template <bool FWD>
-    static __device__ __forceinline__ void half_gemm(const Ctx& x, int frag_l0 /*fragment index of (block 0, k-step 0) of the layer*/, int h, const char* in,
-                                                     f32x4 (&acc)[HB][NS]) {
-        constexpr int NIT = KS * HB, PARTS = FWD ? FP : RP;
-        auto frag = [&](int t) { return frag_l0 + half_block(h, t % HB) * KS + t / HB; };
-        u32x4 Af[3][1][PARTS];
-        load_afrags<1, PARTS>(x, frag(0), Af[0]);
-        load_afrags<1, PARTS>(x, frag(1), Af[1]);
+    // A ring of RING slots runs over the items of all layers in sequence; the slot an item leaves is reloaded with the item RING places
+    // ahead -- of this layer or the next.  (A whole layer of fragments in registers made the compiler spill them: a spill store waits
+    // for its load, i.e. drains the queue.)  Forward: layer l's item 0 sits in slot ((l - 1) * NIT) % RING = 0 (l odd) or 3 (l even).
+    // The chain waves issue no stores in the forward: vector-memory operations complete in order on one counter, and a park store in
+    // the queue puts its write acknowledgement -- ~2 k cycles -- in front of the next fragment wait.  The weight-gradient waves, idle in
+    // the forward, copy every finished state image from LDS to the scratch image instead (park_image).
+    static constexpr int RING = 6;
+    static_assert(!LDSOP || (2 * NIT) % RING == 0, "ring phase repeats every two layers");
+    template <int PAR /* l & 1 */>
+    static __device__ __forceinline__ void fwd_request(const Ctx& x, int l, int h, int t /*item of layer l, may run past NIT*/, u32x4 (&Ar)[RING][1][FP]) {
+        constexpr int T0 = PAR ? 0 : NIT % RING;
+        if (t < NIT) load_afrags<1, FP>(x, item_frag(FI::fwd_mid(l, 0, 0), h, t), Ar[(T0 + t) % RING]);
+        else if (l + 1 < NL) load_afrags<1, FP>(x, item_frag(FI::fwd_mid(l + 1, 0, 0), h, t - NIT), Ar[(T0 + t) % RING]);
+        else if (t - NIT < KS) load_afrags<1, FP>(x, FI::fwd_last(NL, t - NIT), Ar[(T0 + t) % RING]);      // the output layer's k-steps
+    }
+    template <int PAR>
+    static __device__ __forceinline__ void half_gemm_fwd(const Ctx& x, int l, int h, const char* in, u32x4 (&Ar)[RING][1][FP], f32x4 (&acc)[HB][NS]) {
+        constexpr int T0 = PAR ? 0 : NIT % RING;
         u32x4 Bk[NS][1][1][NP];
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
             if (t % HB == 0) op_load(in, t / HB, Bk);
-            if (t + 2 < NIT) load_afrags<1, PARTS>(x, frag(t + 2), Af[(t + 2) % 3]);
-            if constexpr (FWD) fwd_kstep<0, 1>(Af[t % 3], Bk, acc[t % HB]);
-            else bwd_kstep<0, 1>(Af[t % 3], Bk, acc[t % HB]);
+            fwd_kstep<0, 1>(Ar[(T0 + t) % RING], Bk, acc[t % HB]);
+            fwd_request<PAR>(x, l, h, t + RING, Ar);
+        }
+    }
+    // reverse: the same kind of ring over the items of layers NL-1 .. 1 (T0 = global index of this layer's item 0)
+#ifndef PINN_X_RINGB
+#define PINN_X_RINGB 6
+#endif
+    static constexpr int RINGB = PINN_X_RINGB;
+    template <int L>
+    static __device__ __forceinline__ void ring_request(const Ctx& x, int h, int t /*item of layer L, may run past NIT*/, u32x4 (&Ar)[RINGB][1][RP]) {
+        constexpr int T0 = (NL - 1 - L) * NIT;
+        if (t < NIT) load_afrags<1, RP>(x, item_frag(FI::bwd_mid(NL, L, 0, 0), h, t), Ar[(T0 + t) % RINGB]);
+        else if (L >= 2) load_afrags<1, RP>(x, item_frag(FI::bwd_mid(NL, L >= 2 ? L - 1 : 1, 0, 0), h, t - NIT), Ar[(T0 + t) % RINGB]);
+    }
+    template <int L>
+    static __device__ __forceinline__ void half_gemm_bwd(const Ctx& x, int h, const char* in, u32x4 (&Ar)[RINGB][1][RP], f32x4 (&acc)[HB][NS]) {
+        constexpr int T0 = (NL - 1 - L) * NIT;
+        u32x4 Bk[NS][1][1][NP];
+#pragma unroll
+        for (int t = 0; t < NIT; ++t) {
+            if (t % HB == 0) op_load(in, t / HB, Bk);
+            bwd_kstep<0, 1>(Ar[(T0 + t) % RINGB], Bk, acc[t % HB]);
+            ring_request<L>(x, h, t + RINGB, Ar);
         }
     }
     template <int J>
@@ -1155,15 +1298,15 @@ struct Fused {
         if constexpr (J + 1 < HB) wide_fwd_epilogue<J + 1>(acc, out);
     }
     // one hidden weight layer l (1..NL-1): S_l (image `in`) -> this half's blocks of S_{l+1} (image `out`, parked if a reverse layer will DMA it back)
-    static __device__ __forceinline__ void wide_fwd_layer(const Ctx& x, int l, int h, const char* in, char* outimg) {
+    template <int PAR>
+    static __device__ __forceinline__ void wide_fwd_layer(const Ctx& x, int l, int h, const char* in, char* outimg, u32x4 (&Af)[RING][1][FP]) {
         f32x4 acc[HB][NS];
 #pragma unroll
         for (int j = 0; j < HB; ++j) acc_init(load_bias(x, l, half_block(h, j)), acc[j]);
-        half_gemm<true>(x, FI::fwd_mid(l, 0, 0), h, in, acc);
+        half_gemm_fwd<PAR>(x, l, h, in, Af, acc);
         u32x4 out[NS][1][2][NP];
         wide_fwd_epilogue<0>(acc, out);
         half_store(outimg, h, out);
-        if (l + 1 <= NL - 1) half_park(x, l + 1, h, out);
     }
     template <int J>
     static __device__ __forceinline__ void wide_first(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, u32x4 (&Bn)[NS][1][2][NP]) {
@@ -1187,17 +1330,19 @@ struct Fused {
         static_assert(!LDSOP || CONST_LDS, "the LDS-operand layout reads the first layer's rows from the LDS constants");
         char* opa = x.tenZ + x.imgoff;                       // Z area
         char* opb = x.tenZ + TENSOR_Z_B + x.imgoff;          // S slot 0 = slot_of(NL): S_NL ends where the reverse expects it
+        u32x4 Af[RING][1][FP];
+#pragma unroll
+        for (int t = 0; t < RING; ++t) fwd_request<1>(x, 1, h, t, Af);
         {
-            u32x4 B[NS][1][2][NP];
-            wide_first<0>(a, x, xin, h, B);
-            half_store(opa, h, B);
-            half_park(x, 1, h, B);
+            u32x4 S1[NS][1][2][NP];
+            wide_first<0>(a, x, xin, h, S1);
+            half_store(opa, h, S1);
         }
         lds_barrier();
         fused_stamp(a, x.tracer, 32);
         for (int l = 1; l < NL; ++l) {                       // odd layers: first -> second buffer, even layers back
-            if (l & 1) wide_fwd_layer(x, l, h, opa, opb);
-            else wide_fwd_layer(x, l, h, opb, opa);
+            if (l & 1) wide_fwd_layer<1>(x, l, h, opa, opb, Af);
+            else wide_fwd_layer<0>(x, l, h, opb, opa, Af);
             lds_barrier();
             fused_stamp(a, x.tracer, 32 + l);
         }
@@ -1205,10 +1350,9 @@ struct Fused {
         acc_init(load_bias(x, NL, 0), acca);
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
-            u32x4 Bk[NS][1][1][NP], A1[1][FP];
-            load_afrags<1, FP>(x, FI::fwd_last(NL, kk), A1);
+            u32x4 Bk[NS][1][1][NP];
             op_load(opb, kk, Bk);
-            fwd_kstep<0, 1>(A1, Bk, acca);
+            fwd_kstep<0, 1>(Af[(((NL - 1) * NIT) % RING + kk) % RING], Bk, acca);       // requested during the last hidden layer
         }
     }
     // reverse vector part with the state in full precision (hi + unscaled lo from the operand-layout image)
@@ -1222,9 +1366,13 @@ struct Fused {
             const u32x2 hi = *reinterpret_cast<const u32x2*>(rec);
             const u32x2 lo = *reinterpret_cast<const u32x2*>(rec + 1024);
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                st[s][r] = cvt16<Op>((uint16_t)((r & 1) ? (hi[r >> 1] >> 16) : (hi[r >> 1] & 0xffffu))) +
-                           cvt16<Op>((uint16_t)((r & 1) ? (lo[r >> 1] >> 16) : (lo[r >> 1] & 0xffffu)));
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (MixF16<Op>::value)
+                    st[s][r] = (r & 1) ? MixF16<Op>::template sum2<1>(hi[r >> 1], lo[r >> 1]) : MixF16<Op>::template sum2<0>(hi[r >> 1], lo[r >> 1]);
+                else
+                    st[s][r] = cvt16<Op>((uint16_t)((r & 1) ? (hi[r >> 1] >> 16) : (hi[r >> 1] & 0xffffu))) +
+                               cvt16<Op>((uint16_t)((r & 1) ? (lo[r >> 1] >> 16) : (lo[r >> 1] & 0xffffu)));
+            }
         }
         float vals[NS][1][4];
 #pragma unroll
@@ -1245,30 +1393,37 @@ struct Fused {
     // reverse of one tile; on entry the first barrier of the top layer has NOT been passed, S_NL (hi + lo) sits in S slot 0
     static __device__ __forceinline__ void wide_reverse(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, const u32x4 (&ZL)[NS][1][1][NP]) {
         u32x4 Zn[NS][1][2][NP];
+        u32x4 Ar[RINGB][1][RP];
+        u32x4 At[HB][1][RP];
+        // (the fence keeps these requests behind the head's vector work: a spill reload in there would otherwise wait for all of them)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < HB; ++j) load_afrags<1, RP>(x, FI::bwd_last(NL, half_block(h, j)), At[j]);
+#pragma unroll
+        for (int t = 0; t < RINGB; ++t) ring_request<NL - 1>(x, h, t, Ar);
         {
             fused_stamp(a, x.tracer, 2);
-            __syncthreads();                                   // A(NL); S_NL already sits in slot_of(NL) in the image layout
+            lds_barrier();                                      // A(NL); S_NL already sits in slot_of(NL) in the image layout
             fused_stamp(a, x.tracer, 3);
             if (h == 0) put_zimage<1>(x.imgZ(), ZL);           // (both halves hold the same Z_NL)
-            __syncthreads();                                   // B(NL)
+            lds_barrier();                                      // B(NL)
             fused_stamp(a, x.tracer, 4);
             f32x4 acc[HB][NS];
 #pragma unroll
             for (int j = 0; j < HB; ++j) {
-                u32x4 Af[1][RP];
-                load_afrags<1, RP>(x, FI::bwd_last(NL, half_block(h, j)), Af);
                 acc_zero(acc[j]);
-                bwd_kstep<0, 1>(Af, ZL, acc[j]);
+                bwd_kstep<0, 1>(At[j], ZL, acc[j]);
             }
             wide_bwd_epilogue<0>(acc, x.imgS(NL), h, Zn, x.c, x.q);
             fused_stamp(a, x.tracer, 5);
         }
-        wide_down<NL - 1>(a, x, xin, h, Zn);
+        wide_down<NL - 1>(a, x, xin, h, Zn, Ar);
     }
     // entry: Zc = this half's blocks of Z_L in registers, first barrier of layer L not yet passed
     template <int L>
-    static __device__ __forceinline__ void wide_down(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, const u32x4 (&Zc)[NS][1][2][NP]) {
-        __syncthreads();                                       // A(L): the weight-gradient waves are done with Z_{L+1}, S_{L+1}
+    static __device__ __forceinline__ void wide_down(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, const u32x4 (&Zc)[NS][1][2][NP],
+                                                     u32x4 (&Ar)[RINGB][1][RP]) {
+        lds_barrier();                                          // A(L): the weight-gradient waves are done with Z_{L+1}, S_{L+1}
         fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
         half_store(x.imgZ(), h, Zc);
         if constexpr (L == 0) {
@@ -1277,17 +1432,17 @@ struct Fused {
 #ifdef PINN_X_WSTAMP
         fused_stamp(a, x.tracer, 44 + (NL - L));
 #endif
-        __syncthreads();                                       // B(L)
+        lds_barrier();                                          // B(L)
         fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
         if constexpr (L >= 1) {
             f32x4 acc[HB][NS];
 #pragma unroll
             for (int j = 0; j < HB; ++j) acc_zero(acc[j]);
-            half_gemm<false>(x, FI::bwd_mid(NL, L, 0, 0), h, x.imgZ(), acc);      // the Z_L image both halves have just written
+            half_gemm_bwd<L>(x, h, x.imgZ(), Ar, acc);           // operand: the Z_L image both halves have just written
             u32x4 Zn[NS][1][2][NP];
             wide_bwd_epilogue<0>(acc, x.imgS(L), h, Zn, x.c, x.q);
             fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
-            wide_down<L - 1>(a, x, xin, h, Zn);
+            wide_down<L - 1>(a, x, xin, h, Zn, Ar);
         }
     }
 
@@ -1370,7 +1525,7 @@ struct Fused {
 #pragma unroll
             for (int i = 0; i < 5; ++i) {
                 if (q == 0) lsum[i] += vm * f[i] * f[i];
-                g[i] = 2.0f * a.tw[i] * f[i] * vm;
+                g[i] = 2.0f * in_loop(a.tw[i]) * f[i] * vm;
             }
             float Fb[5][5];
 #pragma unroll
@@ -1412,7 +1567,7 @@ struct Fused {
 #pragma unroll
             for (int i = 0; i < 7; ++i) {
                 if (q == 0) lsum[i] += vm * f[i] * f[i];
-                g[i] = 2.0f * a.tw[i] * f[i] * vm;
+                g[i] = 2.0f * in_loop(a.tw[i]) * f[i] * vm;
             }
             adj[0][2] = -g[2];
             adj[0][3] = -g[3];
@@ -1438,7 +1593,7 @@ struct Fused {
                 const float* tg = a.set_targets[set];
                 if (o < a.net.nout) d = Y[0][o] - (tg ? tg[(long)o * a.set_n[set] + pidx] : 0.0f);
                 if (q == 0) lsum[o] += vm * d * d;
-                adj[0][o] = 2.0f * a.set_tw[set][o] * d * vm;
+                adj[0][o] = 2.0f * in_loop(a.set_tw[set][o]) * d * vm;
             }
         }
         float vals[NS][1][4];

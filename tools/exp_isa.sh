@@ -5,4 +5,4 @@ NAME=$1; shift
 D=$ROOT/build/exp/$NAME
 mkdir -p $D
 CS=${CS:-$ROOT/pinn_elastodynamics_amd/csrc}
-/opt/rocm/bin/hipcc --offload-arch=gfx950 ${OPT:--O3} -std=c++17 -I$CS -Wno-unused-value --cuda-device-only -S "$@" -DPINN_INST_OP=F16 -DPINN_INST_SPLIT=3 -DPINN_INST_WIDTH=64 $CS/pinn_inst.hip -o $D/inst.s
+/opt/rocm/bin/hipcc --offload-arch=gfx950 ${OPT:--O3} -std=c++17 -I$CS -Wno-unused-value --cuda-device-only -S "$@" -DPINN_INST_OP=F16 -DPINN_INST_SPLIT=3 -DPINN_INST_WIDTH=${W:-64} $CS/pinn_inst.hip -o $D/inst.s

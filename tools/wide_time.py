@@ -25,9 +25,12 @@ for fused in modes:
     eng.lib.set_fused(fused)
     l, gr = eng.wave_loss_grad(theta, *(v[:m].contiguous() for v in xs), [0, 0, 0], [30, 30, 20], True, np.ones(7) / m)
     e = (rel(l.cpu().numpy(), ss), rel(gr.cpu().numpy(), g))
-    for _ in range(3): eng.wave_loss_grad(theta, *xs, [0, 0, 0], [30, 30, 20], True, tw)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(10): eng.wave_loss_grad(theta, *xs, [0, 0, 0], [30, 30, 20], True, tw)
-    torch.cuda.synchronize()
-    print(f"8x{width} {'fused' if fused else 'two-kernel'}: {(time.perf_counter() - t0) * 100:.2f} ms per 1 M points; loss err {e[0]:.1e} grad err {e[1]:.1e} ({m} points vs oracle)", flush=True)
+    prof = eng.lib.set_profile_buffer(True)
+    ms = []
+    for _ in range(40):
+        eng.wave_loss_grad(theta, *xs, [0, 0, 0], [30, 30, 20], True, tw)
+        ms.append(float(prof[:3].sum()))
+    eng.lib.set_profile_buffer(False)
+    ms = np.sort(np.array(ms))
+    print(f"8x{width} {'fused' if fused else 'two-kernel'}: kernel ms per 1 M points: min {ms[0]:.2f} median {ms[20]:.2f} max {ms[-1]:.2f}; loss err {e[0]:.1e} grad err {e[1]:.1e} ({m} points vs oracle)", flush=True)
 eng.lib.set_fused(True)
