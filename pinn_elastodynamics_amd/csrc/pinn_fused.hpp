@@ -1156,11 +1156,11 @@ struct Fused {
                 load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 1, 0), Ab);
                 lo_from_scratch<0>(x, L, sla);
             }
-            __syncthreads();                                   // previous layer's fragment reads are done
+            hand_barrier();                                    // previous layer's fragment reads are done
             fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
             put_zimage<KS>(x.imgZ(), Zc);
             if constexpr (L == 0) put_input_state(a, x, xin);
-            __syncthreads();                                   // tensors visible to the weight-gradient waves; S_L has landed
+            hand_barrier();                                    // tensors visible to the weight-gradient waves; S_L has landed
             fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
             if constexpr (L >= 1) {
                 // reverse through W_L and the activation that produced S_L -> Z_{L-1}
@@ -1218,6 +1218,14 @@ struct Fused {
     static constexpr int HB = WB / 2;
     static __device__ __forceinline__ int half_block(int h, int j) { return h ? (j < 2 ? 4 + j : 3) : j; }
     // workgroup barrier that orders LDS traffic only: the chain waves' park stores and fragment loads stay in flight across it
+    // hand-off barriers of the chain waves: LDS traffic only, the fragment / low-part loads requested in front of them stay in flight
+    static __device__ __forceinline__ void hand_barrier() {
+#ifdef PINN_X_FULLBAR
+        __syncthreads();
+#else
+        lds_barrier();
+#endif
+    }
     static __device__ __forceinline__ void lds_barrier() {
 #if defined(__AMDGCN__)
         __builtin_amdgcn_sched_barrier(0);
@@ -1616,11 +1624,11 @@ struct Fused {
         u32x4 Aa[1][RP], Ab[1][RP];
         load_afrags<1, RP>(x, FI::bwd_last(NL, 0), Aa);
         load_afrags<1, RP>(x, FI::bwd_last(NL, 1), Ab);
-        __syncthreads();
+        __syncthreads();              // the one full drain of the reverse: every park store of this forward has landed before an LDS-DMA reads it
         fused_stamp(a, x.tracer, 3);
         put_zimage<1>(x.imgZ(), ZL);
         put_image<KS>(x.imgS(NL), B);
-        __syncthreads();
+        hand_barrier();
         fused_stamp(a, x.tracer, 4);
         u32x4 Zn[NS][1][KS][NP];
         {
