@@ -111,7 +111,11 @@ struct Fused {
     // at a time (one ds_read_b128 per stream and part); every layer is "all output blocks accumulate, then the vector part block by
     // block".  The images are 24 KB (hi + lo) per tensor and tile: two tiles per workgroup.
     static constexpr bool LDSOP = WB > 4;
-    static_assert(!LDSOP || (NS_ == 4 && NP == 2), "the LDS-operand layout is built for the 4-stream split-precision case");
+    static_assert(!LDSOP || ((NS_ == 4 || NS_ == 5) && NP == 2), "the LDS-operand layout is built for the 4- / 5-stream split-precision cases");
+    // Five streams at padded width 96 (the reference's plate net, 8 x 70: PLATE:885-887): images of 30 KB, and two tiles have room for
+    // ONE state slot each beside the Z area (2 x 60 KB).  The LDS-DMA of S_L can then only start when the readers of S_{L+1} are done
+    // -- in the hand-off window of layer L itself -- and that window waits for it.
+    static constexpr bool ONE_SLOT = LDSOP && NS_ == 5;
     static constexpr int TILES = LDSOP ? 2 : 4;               // 16-point tiles per workgroup step (one per chain wave)
     static constexpr int NJ = TILES / 2;                      // 32-point k-steps of the weight gradient per workgroup step
     static constexpr int IBW = WB / 2, OBW = WB / 2;          // weight-gradient wave (i,o) owns IBW x OBW blocks of every mid Wbar
@@ -140,10 +144,10 @@ struct Fused {
     // trace, 1.6 k cycles for the first block step of a forward layer against 0.8 k for the others.
     static constexpr int CONST_BIAS_F = (NL - 1) * WIDTH + 16, CONST_F = CONST_BIAS_F + WIDTH * 4, CONST_B = CONST_F * 4;
     // (Five streams at width 64 fill the 160 KB with tensors alone: that instantiation reads the constants from memory.)
-    static constexpr bool CONST_LDS = TILES * (TENSOR_Z_B + 2 * IMG_B) + CONST_B <= 160 * 1024;
+    static constexpr bool CONST_LDS = TILES * (TENSOR_Z_B + (ONE_SLOT ? 1 : 2) * IMG_B) + CONST_B <= 160 * 1024;
     static constexpr int CONST_USED = CONST_LDS ? CONST_B : 0;
     static constexpr bool SLDS = !LDSOP && 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) + CONST_USED <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
-    static constexpr int S_SLOTS = SLDS ? NL + 1 : 2;
+    static constexpr int S_SLOTS = SLDS ? NL + 1 : (ONE_SLOT ? 1 : 2);
     static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * IMG_B;
     static constexpr int CONST_OFF = TILES * WAVE_B;
     static constexpr int LDS_B = CONST_OFF + CONST_USED;
@@ -155,7 +159,7 @@ struct Fused {
     static constexpr bool STATE_LO = !LDSOP && NP == 2 && !FASTSTATE;
     static constexpr unsigned SCRATCH_LO = (unsigned)((NL - 1) * IMG_B);          // byte offset of the low-part images
     static constexpr unsigned SCRATCH_BYTES = (unsigned)((STATE_LO ? 2 : 1) * (NL - 1) * IMG_B);
-    static __device__ __forceinline__ constexpr int slot_of(int L) { return SLDS ? L : (L & 1); }
+    static __device__ __forceinline__ constexpr int slot_of(int L) { return SLDS ? L : (ONE_SLOT ? 0 : (L & 1)); }
 
     // The NG mid weight layers that the reverse sweep reaches first (L = NL-1 .. NL-NG) keep their accumulator blocks in memory
     // (loaded in the layer's hand-off window, stored one layer later so that the write acknowledgement never sits in front of a
@@ -252,12 +256,14 @@ struct Fused {
         fetch(0, fa);
 #pragma unroll
         for (int g = 0; g < NJ * NS; g += 2) {
-            fetch(g + 1, fb);
+            if (g + 1 < NJ * NS) fetch(g + 1, fb);
             work(g, fa);
             __builtin_amdgcn_sched_barrier(0);
-            if (g + 2 < NJ * NS) fetch(g + 2, fa);
-            work(g + 1, fb);
-            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NJ * NS) {
+                if (g + 2 < NJ * NS) fetch(g + 2, fa);
+                work(g + 1, fb);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int b = 0; b < NBK; ++b) {
@@ -290,7 +296,7 @@ struct Fused {
                                                        const char* zs0, const char* zs1, f32x4 (&acc)[3][3], const DmaJob& job) {
         constexpr int NGRP = NJ * NS;
         auto dma_slice = [&](int g) {
-            if constexpr (L >= 2) dma_state(*job.scr, job.lane16, job.tile_lds, L - 1, job.quad, g * N_DMA_ALL / NGRP, (g + 1) * N_DMA_ALL / NGRP);
+            if constexpr (L >= 2 && !ONE_SLOT) dma_state(*job.scr, job.lane16, job.tile_lds, L - 1, job.quad, g * N_DMA_ALL / NGRP, (g + 1) * N_DMA_ALL / NGRP);
         };
         static_assert(NP == 2 || !LDSOP, "split-precision layout");
         f32x4 cc[3][3];
@@ -329,19 +335,20 @@ struct Fused {
 #pragma unroll
                 for (int b = 0; b < 3; ++b) acc[a][b] = Op::mfma(f.Al[a], f.Bh[b], acc[a][b]);
         };
-        static_assert((NJ * NS) % 2 == 0, "two fragment sets in strict alternation");
         Frags fa, fb;
         fetch(0, fa);
 #pragma unroll
-        for (int g = 0; g < NJ * NS; g += 2) {
-            fetch(g + 1, fb);
+        for (int g = 0; g < NGRP; g += 2) {
+            if (g + 1 < NGRP) fetch(g + 1, fb);
             work(fa);
             dma_slice(g);
             __builtin_amdgcn_sched_barrier(0);
-            if (g + 2 < NJ * NS) fetch(g + 2, fa);
-            work(fb);
-            dma_slice(g + 1);
-            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < NGRP) {
+                if (g + 2 < NGRP) fetch(g + 2, fa);
+                work(fb);
+                dma_slice(g + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -555,7 +562,9 @@ struct Fused {
         static constexpr int N_STORE = in_memory(L + 1) ? IBW * OBW : 0;
         static constexpr int N_LOAD = in_memory(L) ? IBW * OBW : 0;
         // LDSOP mid layers: the DMA of S_{L-1} is issued inside the weight gradient of layer L (wg_blocks33), not in the window
-        static constexpr bool DMA_IN_WINDOW = !SLDS && L >= 2 && (!LDSOP || L == NL);
+        // ONE_SLOT: the DMA of S_L itself, in layer L's own window, and the window waits for all of it
+        static constexpr bool DMA_IN_WINDOW = !SLDS && !ONE_SLOT && L >= 2 && (!LDSOP || L == NL);
+        static constexpr bool DMA_OWN = ONE_SLOT && L >= 1 && L <= NL - 1;
         static constexpr int N_DMA = DMA_IN_WINDOW ? N_DMA_ALL : 0;
         static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const WgCtx& w, const DmaSrc& scr, __amdgpu_buffer_rsrc_t accr,
                                                    unsigned lane16, char* tile_lds, Acc& A, int quad, f32x4 (&pend)[IBW][OBW]) {
@@ -577,6 +586,7 @@ struct Fused {
                     for (int o = 0; o < OBW; ++o) ld[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), 0));
             }
             if constexpr (DMA_IN_WINDOW) dma_state(scr, lane16, tile_lds, L - 1, quad);      // S_{L-1} streams in while layer L is worked on
+            if constexpr (DMA_OWN) dma_state(scr, lane16, tile_lds, L, quad);
 #ifdef PINN_X_WSTAMP
             fused_stamp(a, tracer, 96 + 2 * (NL - L));
 #endif
@@ -584,7 +594,7 @@ struct Fused {
             // ago; everything issued since (the operations above) may stay in flight, so the drain is a COUNTED one.  (A surplus
             // operation the compiler might add only makes the wait more conservative: completion is in issue order.)
             __builtin_amdgcn_sched_barrier(0);
-            wait_vmcnt<N_STORE + N_LOAD + N_DMA>();
+            wait_vmcnt<DMA_OWN ? 0 : N_STORE + N_LOAD + N_DMA>();
 #ifdef PINN_X_WSTAMP
             fused_stamp(a, tracer, 97 + 2 * (NL - L));
 #endif
@@ -1328,6 +1338,7 @@ struct Fused {
             vals[0][r] = hh;
 #pragma unroll
             for (int s = 1; s <= NT; ++s) vals[s][r] = sd * (a.sx[s - 1] * w[s - 1]);
+            if constexpr (SECOND) vals[4][r] = -2.0f * hh * vals[3][r] * (a.sx[2] * w[2]);      // z_tt = 0 at the first layer
         }
         emit_state<J, 2>(Bn, vals);
         if constexpr (J + 1 < HB) wide_first<J + 1>(a, x, xin, h, Bn);
@@ -1393,7 +1404,15 @@ struct Fused {
                 dot += acc[J][s][r] * st[s][r];
                 vals[s][0][r] = sds * acc[J][s][r];
             }
-            vals[0][0][r] = sds * acc[J][0][r] - (2.0f * INV_WS) * hh * dot;
+            float zb = sds * acc[J][0][r] - (2.0f * INV_WS) * hh * dot;
+            if constexpr (SECOND) {                      // adjoint of h_tt = (1-h^2) z_tt - 2 h h_t z_t, as in bwd_valu (PLATE:417-419)
+                const float ht = st[3][r], htt = st[4][r];
+                const float httb = acc[J][4][r] * INV_WS;
+                vals[4][0][r] = sds * acc[J][4][r];
+                vals[3][0][r] -= 4.0f * hh * ht * httb;
+                zb += httb * (-2.0f * hh * htt - 2.0f * ht * ht);
+            }
+            vals[0][0][r] = zb;
         }
         CH::template emit<2, J>(Zn, vals, nullptr, WIDTH, c, q);
         if constexpr (J + 1 < HB) wide_bwd_epilogue<J + 1>(acc, simg, h, Zn, c, q);

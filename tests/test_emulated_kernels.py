@@ -240,7 +240,8 @@ def test_emulated_plate_entry_points(emu, lN, lD, n):
 
 @pytest.mark.parametrize("lN,n", [([3] + 4 * [24] + [5], 70),       # five streams, all layer states in LDS
                                   ([3] + 8 * [30] + [5], 130),      # parked states + LDS-DMA, several workgroup steps
-                                  ([3] + 4 * [40] + [5], 40)])      # padded width 64: constants from memory (LDS is full)
+                                  ([3] + 4 * [40] + [5], 40),       # padded width 64: constants from memory (LDS is full)
+                                  ([3] + 8 * [70] + [5], 75)])      # the reference's plate net (PLATE:885): padded width 96, LDS-operand layout
 def test_emulated_plate_fused(emu, lN, n):
     """The plate's loss + gradient through the five-stream instantiation of the fused kernel (second time derivative carried as a
     fifth stream, composite head PLATE:358-439) against the float64 oracle, and the two-kernel path for the same call."""
@@ -272,7 +273,8 @@ def test_emulated_plate_fused(emu, lN, n):
         res[fused] = (loss[:5].copy(), grad.copy())
         # the fused kernel parks the layer states as fp16 high parts: a 2^-12 rounding noise per state element
         # that averages out as 1/sqrt(points) in the gradient -- 3e-5 at ~100 points, 5e-6 at 4096 (GPU tests use real sizes)
-        assert rel(loss[:5], ss) < 3e-6 and rel(grad, g) < (1e-4 if fused else 2e-6), fused
+        # (the width-96 layout keeps both state parts in LDS: the two-kernel path's accuracy)
+        assert rel(loss[:5], ss) < 3e-6 and rel(grad, g) < (1e-4 if fused and lN[1] <= 64 else 2e-6), fused
     emu.set_fused(True)
     assert rel(res[True][1], res[False][1].astype(np.float64)) < 1e-4
 

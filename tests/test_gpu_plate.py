@@ -79,10 +79,11 @@ def test_plate_entry_points_xavier(dev, lN, lD, n):
     assert rel(s3.cpu().numpy(), ((w / w.max()) * s3_o).sum(0)) < 5e-5 and rel(g3.cpu().numpy(), g3_o) < 5e-5
 
 
-@pytest.mark.parametrize("lN,n", [([3] + 8 * [64] + [5], 50000), ([3] + 4 * [40] + [5], 8192), ([3] + 8 * [30] + [5], 8192), ([3] + 4 * [24] + [5], 4099)])
+@pytest.mark.parametrize("lN,n", [([3] + 8 * [64] + [5], 50000), ([3] + 4 * [40] + [5], 8192), ([3] + 8 * [30] + [5], 8192), ([3] + 4 * [24] + [5], 4099),
+                                  ([3] + 8 * [70] + [5], 30011)])      # the reference's own plate net (PLATE:885-887): padded width 96
 def test_plate_fused_kernel_against_oracle_and_two_kernel_path(dev, lN, n):
-    """pinn_plate2d_loss_grad takes the five-stream instantiation of the fused kernel for padded width <= 64 and 4 / 8 hidden layers
-    (second time derivative as a fifth stream, composite head PLATE:358-439 in the kernel).  Same numbers as the float64 oracle (on a
+    """pinn_plate2d_loss_grad takes the five-stream instantiation of the fused kernel for padded width <= 64 and 4 / 8 hidden layers, and
+    for padded width 96 with 8 (second time derivative as a fifth stream, composite head PLATE:358-439 in the kernel).  Same numbers as the float64 oracle (on a
     subsample: the whole set would take the CPU minutes) and as the two-kernel path for the same call, within the rounding noise of
     the fused kernel's fp16-parked state (it averages out as 1/sqrt(points))."""
     from pinn_elastodynamics_amd.hip_engine import HipEngine
