@@ -204,9 +204,23 @@ struct Fused {
     // other half of the record: blocks 2k, 2k+1 share a record).
     // SLO (LDSOP, layers 1..NL): the state image also holds the (unscaled) low parts; a third MFMA per block pair brings the weight
     // gradient to the two-kernel path's accuracy (without it: a 1/sqrt(points) rounding noise, 7e-5 on 5 k points).
-    template <int NA, int NBK, bool SLO = false>
+    // The LDS-DMA of S_{L-1} rides along, a slice behind every group: issued as one burst in the hand-off window, the 21 KB of reads
+    // per wave (running sums + state image) took 3-7 k cycles to ISSUE (phase stamps: a compute unit's outstanding-request capacity
+    // against the memory latency), with every wave of the workgroup waiting at the barrier behind it.
+    struct DmaSrc;
+    struct DmaJob {
+        const DmaSrc* scr;
+        unsigned lane16;
+        char* tile_lds;
+        int quad;
+    };
+    // DL >= 2: the LDS-DMA of S_{DL-1} rides along, a slice behind every group (see DmaJob)
+    template <int NA, int NBK, bool SLO = false, int DL = 0>
     static __device__ __forceinline__ void wg_blocks(const char* s0, const char* s1, const char* z0, const char* z1, f32x4 (&acc)[NA][NBK],
-                                                     float (&bias_out)[NBK]) {
+                                                     float (&bias_out)[NBK], const DmaJob* job = nullptr) {
+        auto dma_slice = [&](int g) {
+            if constexpr (DL >= 2) dma_state(*job->scr, job->lane16, job->tile_lds, DL - 1, job->quad, g * N_DMA_ALL / (NJ * NS), (g + 1) * N_DMA_ALL / (NJ * NS));
+        };
         static_assert(NA <= 2 && NBK <= 2, "blocks of one call share a fragment record");
         f32x4 cc[NA][NBK], bm[NBK], bc[NBK];
 #pragma unroll
@@ -258,10 +272,12 @@ struct Fused {
         for (int g = 0; g < NJ * NS; g += 2) {
             if (g + 1 < NJ * NS) fetch(g + 1, fb);
             work(g, fa);
+            dma_slice(g);
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < NJ * NS) {
                 if (g + 2 < NJ * NS) fetch(g + 2, fa);
                 work(g + 1, fb);
+                dma_slice(g + 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -281,16 +297,6 @@ struct Fused {
     // state parts -- so that every operand fragment of a (k-step, stream) group is transpose-read once: 24 reads per group where four
     // calls of wg_blocks (2x2, 2x1, 1x2, 1x1) issue 48.  The round-2 phase trace had this role bound by its LDS reads (786 KB per
     // layer and workgroup).
-    // The LDS-DMA of S_{L-1} rides along, a slice behind every group: issued as one burst in the hand-off window, the 21 KB of reads
-    // per wave (running sums + state image) took 3-7 k cycles to ISSUE (phase stamps: a compute unit's outstanding-request capacity
-    // against the memory latency), with every wave of the workgroup waiting at the barrier behind it.
-    struct DmaSrc;
-    struct DmaJob {
-        const DmaSrc* scr;
-        unsigned lane16;
-        char* tile_lds;
-        int quad;
-    };
     template <int L>
     static __device__ __forceinline__ void wg_blocks33(const char* sp0, const char* sp1, const char* ss0, const char* ss1, const char* zp0, const char* zp1,
                                                        const char* zs0, const char* zs1, f32x4 (&acc)[3][3], const DmaJob& job) {
@@ -446,11 +452,12 @@ struct Fused {
         if constexpr (LDSOP) {
             wgrad_wide<L>(w, A, quad, ld, pend, job);
         } else {
-            wgrad_narrow<L>(w, A, quad, ld, pend);
+            wgrad_narrow<L>(w, A, quad, ld, pend, job);
         }
     }
     template <int L>
-    static __device__ __forceinline__ void wgrad_narrow(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW]) {
+    static __device__ __forceinline__ void wgrad_narrow(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW], const DmaJob& job) {
+        constexpr int DMA_L = DMA_IN_WGRAD && L >= 2 && L <= NL - 1 ? L : 0;
         const char* s0 = w.s0 + slot_of(L) * IMG_B;
         const char* s1 = w.s1 + slot_of(L) * IMG_B;
         const int wi = quad >> 1, wo = quad & 1;
@@ -477,13 +484,13 @@ struct Fused {
                 for (int i = 0; i < IBW; ++i)
 #pragma unroll
                     for (int o = 0; o < OBW; ++o) pend[i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-                wg_blocks<IBW, OBW>(s0 + img_block(wi * IBW), s1 + img_block(wi * IBW), w.z0 + zimg_block(wo * OBW), w.z1 + zimg_block(wo * OBW), pend, b);
+                wg_blocks<IBW, OBW, false, DMA_L>(s0 + img_block(wi * IBW), s1 + img_block(wi * IBW), w.z0 + zimg_block(wo * OBW), w.z1 + zimg_block(wo * OBW), pend, b, &job);
 #pragma unroll
                 for (int i = 0; i < IBW; ++i)
 #pragma unroll
                     for (int o = 0; o < OBW; ++o) pend[i][o] += ld[i][o];
             } else {
-                wg_blocks<IBW, OBW>(s0 + img_block(wi * IBW), s1 + img_block(wi * IBW), w.z0 + zimg_block(wo * OBW), w.z1 + zimg_block(wo * OBW), A.mid[L - 1], b);
+                wg_blocks<IBW, OBW, false, DMA_L>(s0 + img_block(wi * IBW), s1 + img_block(wi * IBW), w.z0 + zimg_block(wo * OBW), w.z1 + zimg_block(wo * OBW), A.mid[L - 1], b, &job);
             }
             // one bias block per wave per layer: out-block wo*OBW + wi (OBW == 2) or wo (OBW == 1, waves with wi == 0)
             if (OBW == 1) { if (wi == 0) A.bias[L] += b[0]; }
@@ -512,6 +519,12 @@ struct Fused {
         }
     };
     static constexpr int N_DMA_ALL = LDSOP ? IMG_B / 2048 : IMG_B / 1024;       // LDSOP: two waves share a tile's records
+    // mid layers: the LDS-DMA of S_{L-1} is issued in slices inside the weight gradient of layer L, not as a burst in the hand-off window
+#ifdef PINN_X_DMAWIN
+    static constexpr bool DMA_IN_WGRAD = LDSOP && !ONE_SLOT;
+#else
+    static constexpr bool DMA_IN_WGRAD = !SLDS && !ONE_SLOT;
+#endif
     static __device__ __forceinline__ void dma_state(const DmaSrc& src, unsigned lane16, char* tile_lds, int l /*1..NL-1*/, int quad, int ii0 = 0,
                                                      int ii1 = N_DMA_ALL) {
         if constexpr (SLDS) return;
@@ -563,7 +576,7 @@ struct Fused {
         static constexpr int N_LOAD = in_memory(L) ? IBW * OBW : 0;
         // LDSOP mid layers: the DMA of S_{L-1} is issued inside the weight gradient of layer L (wg_blocks33), not in the window
         // ONE_SLOT: the DMA of S_L itself, in layer L's own window, and the window waits for all of it
-        static constexpr bool DMA_IN_WINDOW = !SLDS && !ONE_SLOT && L >= 2 && (!LDSOP || L == NL);
+        static constexpr bool DMA_IN_WINDOW = !SLDS && !ONE_SLOT && L >= 2 && (!DMA_IN_WGRAD || L == NL);
         static constexpr bool DMA_OWN = ONE_SLOT && L >= 1 && L <= NL - 1;
         static constexpr int N_DMA = DMA_IN_WINDOW ? N_DMA_ALL : 0;
         static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const WgCtx& w, const DmaSrc& scr, __amdgpu_buffer_rsrc_t accr,
