@@ -77,7 +77,7 @@ struct FusedArgs {
 // to spill -- and a spill reload in the step is a full memory round trip (round-2 phase stamps: 3.5 k cycles in the residual head).
 __device__ __forceinline__ float in_loop(float v) {
 #if defined(__AMDGCN__) && !defined(PINN_X_NOINLOOP)
-    asm volatile("" : "+s"(v));
+    asm volatile("" : "+v"(v));      // (a vector register: a scalar constraint is refused where the compiler holds the value in one)
 #endif
     return v;
 }
@@ -104,7 +104,7 @@ struct Fused {
     static constexpr int P3 = NP == 2 ? 3 : 1;
     static constexpr float WS = NP == 2 ? FUSED_WEIGHT_SCALE : 1.0f;
     static constexpr float INV_WS = 1.0f / WS;
-    static_assert(WB == 2 || WB == 4 || WB == 6, "fused kernel supports padded widths 32, 64 and 96");
+    static_assert(WB == 2 || WB == 4 || WB == 6 || WB == 8, "fused kernel supports padded widths 32, 64, 96 and 128");
     static_assert(NL >= 2, "fused kernel needs at least two hidden layers");
     // LDSOP (padded width 96, the reference's 70 / 80): a tile's state does not fit the register file next to its successor (2 x 96
     // registers), so the chain wave keeps it in its LDS image -- the register image IS the MFMA operand layout -- and reads one k-step
@@ -115,7 +115,9 @@ struct Fused {
     // Five streams at padded width 96 (the reference's plate net, 8 x 70: PLATE:885-887): images of 30 KB, and two tiles have room for
     // ONE state slot each beside the Z area (2 x 60 KB).  The LDS-DMA of S_L can then only start when the readers of S_{L+1} are done
     // -- in the hand-off window of layer L itself -- and that window waits for it.
-    static constexpr bool ONE_SLOT = LDSOP && NS_ == 5;
+    // Padded width 128 (the reference's semi-infinite net, 8 x 100: SEMI:679) with four streams: images of 32 KB, the same budget.
+    static constexpr bool ONE_SLOT = LDSOP && (NS_ == 5 || WB == 8);
+    static_assert(!(NS_ == 5 && WB == 8), "five streams at padded width 128: 40 KB images, no room for two tiles");
     static constexpr int TILES = LDSOP ? 2 : 4;               // 16-point tiles per workgroup step (one per chain wave)
     static constexpr int NJ = TILES / 2;                      // 32-point k-steps of the weight gradient per workgroup step
     static constexpr int IBW = WB / 2, OBW = WB / 2;          // weight-gradient wave (i,o) owns IBW x OBW blocks of every mid Wbar
@@ -167,8 +169,13 @@ struct Fused {
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
     static constexpr int NG = LDSOP ? NL - 1 : (NL >= 8 ? 5 : (NL >= 4 ? 2 : 0));      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
-    static constexpr unsigned WG_ACC_BYTES = (unsigned)((NG > 0 ? NG : 1) * IBW * OBW * 1024);
+    static constexpr int NSUM = IBW * OBW + (LDSOP ? 1 : 0);                   // in-memory records per layer: the blocks (+ LDSOP: the bias blocks' lane record)
+    static constexpr unsigned WG_ACC_BYTES = (unsigned)((NG > 0 ? NG : 1) * NSUM * 1024);
     static __device__ __forceinline__ constexpr bool in_memory(int L) { return L >= 1 && L <= NL - 1 && L > NREG; }
+    struct Sums {                      // running sums of one in-memory layer: this wave's blocks (+ LDSOP: its bias blocks, one float per lane and block)
+        f32x4 blk[IBW][OBW];
+        f32x4 bias;
+    };
     struct Acc {                       // persistent across the whole launch, all statically indexed
         f32x4 mid[NREG > 0 ? NREG : 1][IBW][OBW];
         f32x4 first;                   // Wbar_0 block (in-block 0, out-block = quad) if quad < WB
@@ -177,7 +184,7 @@ struct Fused {
         // LDSOP (six blocks per side over four waves): a second first / last block (out- / in-block quad + 4 for quad < 2), and three bias
         // blocks per mid layer held by the waves with wi == 0
         f32x4 first2, last2;
-        float bias0b, biasw[LDSOP ? NL : 1][3];
+        float bias0b;                  // (LDSOP mid-layer bias blocks: one more in-memory record per layer, bias_record)
     };
 
     // ---------------------------------------------------------------------------------------------
@@ -396,9 +403,12 @@ struct Fused {
 
     // LDSOP: six 16-feature blocks per side.  Wave (wi, wo) owns in-blocks {2wi, 2wi+1, 4+wi} x out-blocks {2wo, 2wo+1, 4+wo}: a pair that
     // shares a fragment record and a single block, the same shape for every wave (offsets at run time, block counts at compile time).
-    static __device__ __forceinline__ int wide_block(int half, int i) { return i < 2 ? 2 * half + i : 4 + half; }
+    // (Eight blocks per side, padded width 128: wave (wi, wo) owns in-blocks 4wi..4wi+3 x out-blocks 4wo..4wo+3, two record pairs each.)
+    static __device__ __forceinline__ int wide_block(int half, int i) { return WB == 8 ? 4 * half + i : (i < 2 ? 2 * half + i : 4 + half); }
     template <int L>
-    static __device__ __forceinline__ void wgrad_wide(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW], const DmaJob& job) {
+    static __device__ __forceinline__ void wgrad_wide(const WgCtx& w, Acc& A, int quad, const Sums& lds_, Sums& pends_, const DmaJob& job) {
+        const f32x4 (&ld)[IBW][OBW] = lds_.blk;
+        f32x4 (&pend)[IBW][OBW] = pends_.blk;
         const char* s0 = w.s0 + slot_of(L) * IMG_B;
         const char* s1 = w.s1 + slot_of(L) * IMG_B;
         const int wi = quad >> 1, wo = quad & 1;
@@ -422,11 +432,30 @@ struct Fused {
             }
         } else {
             static_assert(in_memory(L), "LDSOP keeps every mid-layer accumulator in memory");
+            pends_.bias = lds_.bias;
             // pend starts from the layer's running sums
 #pragma unroll
             for (int i = 0; i < IBW; ++i)
 #pragma unroll
                 for (int o = 0; o < OBW; ++o) pend[i][o] = ld[i][o];
+            if constexpr (WB == 8) {
+                // 4 x 4 blocks as four 2 x 2 passes (pairs share a fragment record); bias blocks from the passes of in-pair 0
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                    for (int op = 0; op < 2; ++op) {
+                        f32x4 t[2][2] = {{pend[2 * ip][2 * op], pend[2 * ip][2 * op + 1]}, {pend[2 * ip + 1][2 * op], pend[2 * ip + 1][2 * op + 1]}};
+                        float b2[2];
+                        wg_blocks<2, 2, true>(s0 + img_block(4 * wi + 2 * ip), s1 + img_block(4 * wi + 2 * ip), w.z0 + zimg_block(4 * wo + 2 * op),
+                                              w.z1 + zimg_block(4 * wo + 2 * op), t, b2);
+                        pend[2 * ip][2 * op] = t[0][0]; pend[2 * ip][2 * op + 1] = t[0][1];
+                        pend[2 * ip + 1][2 * op] = t[1][0]; pend[2 * ip + 1][2 * op + 1] = t[1][1];
+                        if (ip == 0 && wi == 0) {
+                            pends_.bias[2 * op] += b2[0];
+                            pends_.bias[2 * op + 1] += b2[1];
+                        }
+                    }
+            } else {
             const char* sp0 = s0 + img_block(2 * wi);
             const char* sp1 = s1 + img_block(2 * wi);
             const char* ss0 = s0 + img_block(4 + wi);
@@ -439,20 +468,21 @@ struct Fused {
             if (wi == 0) {                 // the bias blocks of out-half wo
                 float b3[3];
                 wg_bias3(zp0, zp1, zs0, zs1, b3);
-                A.biasw[L][0] += b3[0];
-                A.biasw[L][1] += b3[1];
-                A.biasw[L][2] += b3[2];
+                pends_.bias[0] += b3[0];
+                pends_.bias[1] += b3[1];
+                pends_.bias[2] += b3[2];
+            }
             }
         }
     }
 
     // weight gradient of weight layer L (quad = weight-gradient wave index 0..3)
     template <int L>
-    static __device__ __forceinline__ void wgrad(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW], const DmaJob& job) {
+    static __device__ __forceinline__ void wgrad(const WgCtx& w, Acc& A, int quad, const Sums& ld, Sums& pend, const DmaJob& job) {
         if constexpr (LDSOP) {
             wgrad_wide<L>(w, A, quad, ld, pend, job);
         } else {
-            wgrad_narrow<L>(w, A, quad, ld, pend, job);
+            wgrad_narrow<L>(w, A, quad, ld.blk, pend.blk, job);
         }
     }
     template <int L>
@@ -558,7 +588,30 @@ struct Fused {
     }
 
     // accumulator blocks of an in-memory layer: record (L - NREG - 1, i, o) of this wave's 1 KB-record area
-    static __device__ __forceinline__ int acc_record(int L, int i, int o) { return ((L - NREG - 1) * IBW * OBW + i * OBW + o) * 1024; }
+    static __device__ __forceinline__ int acc_record(int L, int i, int o) { return ((L - NREG - 1) * NSUM + i * OBW + o) * 1024; }
+    static __device__ __forceinline__ int bias_record(int L) { return ((L - NREG - 1) * NSUM + IBW * OBW) * 1024; }
+    // Early sums (LDSOP): a layer's running sums go back to memory, and the next layer's are requested, right behind the layer's weight
+    // gradient -- not in the next hand-off window, where their issue (a compute unit's request capacity against the memory latency)
+    // kept every wave of the workgroup waiting.  The first barrier of a layer is then an LDS-only one for this role.
+#ifdef PINN_X_EARLY_ONESLOT
+    static constexpr bool EARLY_SUMS = ONE_SLOT;
+#else
+    static constexpr bool EARLY_SUMS = LDSOP;
+#endif
+    static __device__ __forceinline__ void store_sums(__amdgpu_buffer_rsrc_t accr, unsigned lane16, int L, const Sums& p) {
+#pragma unroll
+        for (int i = 0; i < IBW; ++i)
+#pragma unroll
+            for (int o = 0; o < OBW; ++o) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p.blk[i][o]), accr, lane16, acc_record(L, i, o), 0);
+        if constexpr (LDSOP) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p.bias), accr, lane16, bias_record(L), 0);
+    }
+    static __device__ __forceinline__ void load_sums(__amdgpu_buffer_rsrc_t accr, unsigned lane16, int L, Sums& p) {
+#pragma unroll
+        for (int i = 0; i < IBW; ++i)
+#pragma unroll
+            for (int o = 0; o < OBW; ++o) p.blk[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), 0));
+        if constexpr (LDSOP) p.bias = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(L), 0));
+    }
 
     // "wait until at most N of this wave's vector-memory operations are outstanding" (they complete in issue order)
     template <int N>
@@ -572,31 +625,24 @@ struct Fused {
     struct WgDown {     // same barrier sequence as the chain role's Down<>
         // vector-memory operations this wave issues in the hand-off window of layer L (between the two barriers), in this order:
         // the stores of layer L+1's in-memory sums, the loads of layer L's, the LDS-DMA of S_{L-1}
-        static constexpr int N_STORE = in_memory(L + 1) ? IBW * OBW : 0;
-        static constexpr int N_LOAD = in_memory(L) ? IBW * OBW : 0;
+        static constexpr int N_STORE = in_memory(L + 1) ? NSUM : 0;
+        static constexpr int N_LOAD = in_memory(L) ? NSUM : 0;
         // LDSOP mid layers: the DMA of S_{L-1} is issued inside the weight gradient of layer L (wg_blocks33), not in the window
         // ONE_SLOT: the DMA of S_L itself, in layer L's own window, and the window waits for all of it
         static constexpr bool DMA_IN_WINDOW = !SLDS && !ONE_SLOT && L >= 2 && (!DMA_IN_WGRAD || L == NL);
         static constexpr bool DMA_OWN = ONE_SLOT && L >= 1 && L <= NL - 1;
         static constexpr int N_DMA = DMA_IN_WINDOW ? N_DMA_ALL : 0;
         static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const WgCtx& w, const DmaSrc& scr, __amdgpu_buffer_rsrc_t accr,
-                                                   unsigned lane16, char* tile_lds, Acc& A, int quad, f32x4 (&pend)[IBW][OBW]) {
-            __syncthreads();                                   // (chain waves now overwrite the tensors; everything this wave had in flight is done)
+                                                   unsigned lane16, char* tile_lds, Acc& A, int quad, Sums& pend, Sums& ld) {
+            // (chain waves now overwrite the tensors; this wave's reads of them are done)
+            if constexpr (EARLY_SUMS) lds_barrier();
+            else __syncthreads();
             fused_stamp(a, tracer, 64 + 3 * (NL - L));
             // While the chain waves write their Z rows this wave has nothing to compute: it issues its memory traffic here, off
             // the critical phase.  The slot of S_{L-1} is free (its last readers finished before the barrier above).
-            if constexpr (in_memory(L + 1)) {                  // the layer before: its sums go back to memory, a whole layer ahead of the next full drain
-#pragma unroll
-                for (int i = 0; i < IBW; ++i)
-#pragma unroll
-                    for (int o = 0; o < OBW; ++o) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend[i][o]), accr, lane16, acc_record(L + 1, i, o), 0);
-            }
-            f32x4 ld[IBW][OBW];
-            if constexpr (in_memory(L)) {
-#pragma unroll
-                for (int i = 0; i < IBW; ++i)
-#pragma unroll
-                    for (int o = 0; o < OBW; ++o) ld[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), 0));
+            if constexpr (!EARLY_SUMS) {
+                if constexpr (in_memory(L + 1)) store_sums(accr, lane16, L + 1, pend);      // a whole layer ahead of the next full drain
+                if constexpr (in_memory(L)) load_sums(accr, lane16, L, ld);
             }
             if constexpr (DMA_IN_WINDOW) dma_state(scr, lane16, tile_lds, L - 1, quad);      // S_{L-1} streams in while layer L is worked on
             if constexpr (DMA_OWN) dma_state(scr, lane16, tile_lds, L, quad);
@@ -604,8 +650,9 @@ struct Fused {
             fused_stamp(a, tracer, 96 + 2 * (NL - L));
 #endif
             // Second barrier: the tensors of layer L are complete.  This wave's contribution is the LDS-DMA of S_L, issued one layer
-            // ago; everything issued since (the operations above) may stay in flight, so the drain is a COUNTED one.  (A surplus
-            // operation the compiler might add only makes the wait more conservative: completion is in issue order.)
+            // ago; everything issued since (the sums of layer L+1 stored, those of layer L requested, the window's DMA) may stay in flight,
+            // so the drain is a COUNTED one.  (A surplus operation the compiler might add only makes the wait more conservative:
+            // completion is in issue order.)
             __builtin_amdgcn_sched_barrier(0);
             wait_vmcnt<DMA_OWN ? 0 : N_STORE + N_LOAD + N_DMA>();
 #ifdef PINN_X_WSTAMP
@@ -615,8 +662,12 @@ struct Fused {
             __builtin_amdgcn_sched_barrier(0);
             fused_stamp(a, tracer, 65 + 3 * (NL - L));
             wgrad<L>(w, A, quad, ld, pend, DmaJob{&scr, lane16, tile_lds, quad});
+            if constexpr (EARLY_SUMS) {
+                if constexpr (in_memory(L)) store_sums(accr, lane16, L, pend);
+                if constexpr (in_memory(L - 1)) load_sums(accr, lane16, L - 1, ld);
+            }
             fused_stamp(a, tracer, 66 + 3 * (NL - L));
-            if constexpr (L >= 1) WgDown<L - 1>::run(a, tracer, w, scr, accr, lane16, tile_lds, A, quad, pend);
+            if constexpr (L >= 1) WgDown<L - 1>::run(a, tracer, w, scr, accr, lane16, tile_lds, A, quad, pend, ld);
         }
     };
 
@@ -633,8 +684,6 @@ struct Fused {
         A.bias0b = 0.0f;
 #pragma unroll
         for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
-#pragma unroll
-        for (int l = 0; l < (LDSOP ? NL : 1); ++l) A.biasw[l][0] = A.biasw[l][1] = A.biasw[l][2] = 0.0f;
         WgCtx w;
         {
             const char* wave0 = lds + (q >> 1) * WAVE_B;
@@ -658,9 +707,9 @@ struct Fused {
             (void*)(reinterpret_cast<char*>(a.wg_acc) + ((long)blockIdx.x * 4 + quad) * (long)WG_ACC_BYTES), 0, (int)WG_ACC_BYTES, 0x00020000);
         if constexpr (NG > 0) {
 #pragma unroll
-            for (int r = 0; r < NG * IBW * OBW; ++r) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, accr, lane16, r * 1024, 0);
+            for (int r = 0; r < NG * NSUM; ++r) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, accr, lane16, r * 1024, 0);
         }
-        f32x4 pend[IBW][OBW];
+        Sums pend, ld;
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
             if constexpr (LDSOP) {
                 __syncthreads();                          // step barrier (see the chain role): this wave's reads of the previous step are done
@@ -671,7 +720,7 @@ struct Fused {
                     if (l + 1 <= NL - 1) park_image(scr_st, lane16, tile_lds, l + 1, quad);
                 }
             }
-            WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend);
+            WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend, ld);
         }
         // ---- write this workgroup's partial gradient
         float* part = a.partial + (long)blockIdx.x * a.net.nparams;
@@ -715,11 +764,12 @@ struct Fused {
                         const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(l, i, o), 0));
                         put_block(v, l, wide_block(wi, i), wide_block(wo, o), H, H);
                     }
+                const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l), 0));
                 if (wi == 0 && q == 0) {
 #pragma unroll
-                    for (int o = 0; o < 3; ++o) {
+                    for (int o = 0; o < OBW; ++o) {
                         const int ob = wide_block(wo, o);
-                        if (16 * ob + c < H) part[a.net.b_off[l] + 16 * ob + c] = A.biasw[l][o];
+                        if (16 * ob + c < H) part[a.net.b_off[l] + 16 * ob + c] = bv[o];
                     }
                 }
             }
@@ -1239,7 +1289,8 @@ struct Fused {
     // record 1.  The wave's results are local fragments Fl[s][0][0][p] = the pair's record, Fl[s][0][1][p].xy = the single block's
     // 8 bytes; block numbers enter as run-time offsets only, so both halves run the same code.
     static constexpr int HB = WB / 2;
-    static __device__ __forceinline__ int half_block(int h, int j) { return h ? (j < 2 ? 4 + j : 3) : j; }
+    // (Padded width 128: four blocks per half, 4h .. 4h+3 = the two records 2h, 2h+1.)
+    static __device__ __forceinline__ int half_block(int h, int j) { return WB == 8 ? 4 * h + j : (h ? (j < 2 ? 4 + j : 3) : j); }
     // workgroup barrier that orders LDS traffic only: the chain waves' park stores and fragment loads stay in flight across it
     // hand-off barriers of the chain waves: LDS traffic only, the fragment / low-part loads requested in front of them stay in flight
     static __device__ __forceinline__ void hand_barrier() {
@@ -1265,7 +1316,8 @@ struct Fused {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 *reinterpret_cast<u32x4*>(img + ((s * KS + 2 * h) * NP + p) * 1024) = Fl[s][0][0][p];
-                *reinterpret_cast<u32x2*>(img + ((s * KS + 1) * NP + p) * 1024 + 8 * h) = u32x2{Fl[s][0][1][p][0], Fl[s][0][1][p][1]};
+                if constexpr (WB == 8) *reinterpret_cast<u32x4*>(img + ((s * KS + 2 * h + 1) * NP + p) * 1024) = Fl[s][0][1][p];
+                else *reinterpret_cast<u32x2*>(img + ((s * KS + 1) * NP + p) * 1024 + 8 * h) = u32x2{Fl[s][0][1][p][0], Fl[s][0][1][p][1]};
             }
     }
     // The GEMM of a half: its HB blocks accumulate over the KS k-steps of the operand image, NIT = KS * HB items of (k-step, block).
@@ -1281,7 +1333,7 @@ struct Fused {
     // The chain waves issue no stores in the forward: vector-memory operations complete in order on one counter, and a park store in
     // the queue puts its write acknowledgement -- ~2 k cycles -- in front of the next fragment wait.  The weight-gradient waves, idle in
     // the forward, copy every finished state image from LDS to the scratch image instead (park_image).
-    static constexpr int RING = 6;
+    static constexpr int RING = WB == 8 ? 4 : 6;
     static_assert(!LDSOP || (2 * NIT) % RING == 0, "ring phase repeats every two layers");
     template <int PAR /* l & 1 */>
     static __device__ __forceinline__ void fwd_request(const Ctx& x, int l, int h, int t /*item of layer l, may run past NIT*/, u32x4 (&Ar)[RING][1][FP]) {
@@ -1302,10 +1354,7 @@ struct Fused {
         }
     }
     // reverse: the same kind of ring over the items of layers NL-1 .. 1 (T0 = global index of this layer's item 0)
-#ifndef PINN_X_RINGB
-#define PINN_X_RINGB 6
-#endif
-    static constexpr int RINGB = PINN_X_RINGB;
+    static constexpr int RINGB = WB == 8 ? 4 : 6;      // (three fragment parts per item: 12 registers a slot)
     template <int L>
     static __device__ __forceinline__ void ring_request(const Ctx& x, int h, int t /*item of layer L, may run past NIT*/, u32x4 (&Ar)[RINGB][1][RP]) {
         constexpr int T0 = (NL - 1 - L) * NIT;
@@ -1756,7 +1805,7 @@ struct Fused {
             }
     }
 
-    static __device__ void run(const FusedArgs& a) {
+    static __device__ __forceinline__ void run(const FusedArgs& a) {
         __shared__ __attribute__((aligned(16))) char lds[LDS_B];
         const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
         const int wave8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // provably wave-uniform

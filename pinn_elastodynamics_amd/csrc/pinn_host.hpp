@@ -93,10 +93,10 @@ struct Host {
     static constexpr int FUSED_PARTS = SPLIT == 3 ? 3 : 1;   // ... of the fused kernel's format (repack_kernel)
     static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
     static constexpr int FUSED_GRID = 256;    // persistent workgroups of the fused kernel (one per MI355X CU)
-    static constexpr int FUSED_MAX_WIDTH = 96;      // widest padded net the fused kernel takes (4 streams; 32 / 64 also 1 and 5 streams)
-    static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? 32 * 1024 : 64 * 1024;     // per weight-gradient wave: in-memory accumulator blocks
+    static constexpr int FUSED_MAX_WIDTH = 128;     // widest padded net the fused kernel takes (4 streams; 96 also 5 streams, 32 / 64 also 1 stream)
+    static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? 32 * 1024 : (WIDTH <= 96 ? 72 * 1024 : 128 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
     template <int NS>
-    static constexpr bool fused_has() { return WIDTH <= 64 || (WIDTH <= FUSED_MAX_WIDTH && (NS == 4 || NS == 5) && SPLIT == 3); }
+    static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5)) || (WIDTH <= FUSED_MAX_WIDTH && NS == 4))); }
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
     static constexpr long MIN_TILES = 64;
     typedef FragIndex<WIDTH> FI;
@@ -413,7 +413,7 @@ struct Host {
     static int try_fused(const Call& c, int* out, int nterms) {
         if constexpr (fused_has<NS>()) {
             if (c.net.nl != 4 && c.net.nl != 8) return 0;
-            if (WIDTH > 64 && c.net.nl != 8) return 0;          // padded width 96: the 8-layer instantiation only (INF:645, 8 x 80)
+            if (WIDTH > 64 && c.net.nl != 8) return 0;          // padded widths 96 / 128: the 8-layer instantiations only (INF:645 8 x 80, SEMI:679 8 x 100)
             Plan p;
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);

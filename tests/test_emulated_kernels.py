@@ -92,13 +92,15 @@ def test_fp16_state_flag_emulated(emu):
     assert e_loss < 2e-6 and e_loss2 < 2e-6 and e_acc < e_fast < 1e-4
 
 
-def test_fused_wide_emulated(emu):
-    """Padded width 96 (the reference's 8 x 80 net, INF:645) through the LDS-operand layout of the fused kernel: the tile's state lives
-    in the chain wave's LDS image and is read one k-step at a time; six feature blocks per side in the weight gradient; two tiles per
-    workgroup.  Against the oracle (gradient within the 1/sqrt(points) rounding noise of the fp16-parked state) and the two-kernel path."""
-    layers = [3] + 8 * [80] + [7]
+@pytest.mark.parametrize("width", [80, 100])
+def test_fused_wide_emulated(emu, width):
+    """Padded widths 96 / 128 (the reference's 8 x 80 and 8 x 100 nets, INF:645, SEMI:679) through the LDS-operand layout of the fused
+    kernel: the tile's state lives in its LDS image and is read one k-step at a time, two waves share a tile's chain (three / four
+    feature blocks each), six / eight blocks per side in the weight gradient, two tiles per workgroup (width 128: one state slot).
+    Against the oracle (both state parts are kept: the two-kernel path's accuracy) and the two-kernel path."""
+    layers = [3] + 8 * [width] + [7]
     e_loss, e_grad = run_wave(emu, layers, 70, "f16x3", fused=True)
-    assert e_loss < 2e-6 and e_grad < 1e-4
+    assert e_loss < 2e-6 and e_grad < 3e-6
     e_loss, e_grad = run_wave(emu, layers, 70, "f16x3", fused=False)
     assert e_loss < 2e-6 and e_grad < 2e-6
     e_loss, e_grad = run_wave(emu, layers, 300, "f16x3", min_ws=True, fused=True, normalize=False, seed=4)      # several steps per workgroup

@@ -521,10 +521,11 @@ def test_fp32_mode_drives_the_model_class(dev):
     assert np.all(np.isfinite(runs["fp32"])) and rel(runs["f16x3"], runs["fp32"]) < 1e-4
 
 
-@pytest.mark.parametrize("width,n", [(80, 30000), (70, 9001), (96, 4096)])
+@pytest.mark.parametrize("width,n", [(80, 30000), (70, 9001), (96, 4096), (100, 30011), (128, 4096)])
 def test_fused_wide_kernel_against_oracle_and_two_kernel_path(dev, width, n):
-    """Padded width 96 (the reference's 8 x 80 INF net, INF:645; 8 x 70 is the plate's width) runs through the LDS-operand layout of the
-    fused kernel.  Same numbers as the two-kernel path for the same call and as the float64 oracle (on a subsample)."""
+    """Padded widths 96 and 128 (the reference's 8 x 80 INF net, INF:645, and 8 x 100 SEMI net, SEMI:679; 8 x 70 is the plate's width) run
+    through the LDS-operand layout of the fused kernel.  Same numbers as the two-kernel path for the same call and as the float64
+    oracle (on a subsample)."""
     layers = [3] + 8 * [width] + [7]
     rng = np.random.default_rng(12)
     Ws, bs = po.xavier_init(layers, rng)
