@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 wave, 60 plate, 12 nc3d)")
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--config", default="wave", choices=["wave", "plate", "nc3d"])
+    ap.add_argument("--width", type=int, default=64, help="hidden width of the 8-layer net (wave / plate): 64 = BASELINE configs; the reference's own "
+                    "scripts train 80 (INF:645), 100 (SEMI:679) and, for the plate, 70 (PLATE:885)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--points-per-gpu", type=int, default=None, help="weak scaling: points per GPU (default 2 M; nc3d 4 M)")
     ap.add_argument("--global-points", type=int, default=2_000_000, help="strong scaling: total points")
@@ -173,30 +175,30 @@ def main():
     # ------------------------------------------------------------------------------------------------------------------
     if cfg == "wave":
         from pinn_elastodynamics_amd.elastic_wave import DeepHPM
-        layers = [3] + 8 * [64] + [7]
-        streams, label = 4, "8x64"
+        layers = [3] + 8 * [args.width] + [7]
+        streams, label = 4, f"8x{args.width}"
         Collo = synth_points(n_global, 1111)
         SRC, IC = ricker_source(), ic_grid()
         eng = HipEngine(layers, precision=args.precision, device=dev, max_points=args.chunk_points)
         model = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, case="infinite", engine=eng, seed=1111, verbose=False)
         step = lambda k: model.train(k, 1e-3, 1)
-        workload = (f"2D elastic wave (infinite), 8x64 tanh MLP, {pts_per_rank} collocation pts per GPU + IC 10201 + SRC 70400, Adam (TF1 rule) step "
-                    f"incl. gradient all-reduce (BASELINE configs[1]; x8 GPUs weak = configs[3]); {PRECISION_NOTE}")
+        workload = (f"2D elastic wave (infinite), 8x{args.width} tanh MLP, {pts_per_rank} collocation pts per GPU + IC 10201 + SRC 70400, Adam (TF1 rule) step "
+                    f"incl. gradient all-reduce ({'BASELINE configs[1]; x8 GPUs weak = configs[3]' if args.width == 64 else 'a net width of the reference scripts, not a BASELINE config'}); {PRECISION_NOTE}")
     elif cfg == "plate":
         from pinn_elastodynamics_amd import pointsets as ps
         from pinn_elastodynamics_amd.plate_hole import PINN
-        c = ps.plate_case(seed=1111, n_collo=int(n_global * 0.65), n_refine=int(n_global * 0.38), uv_width=64)
+        c = ps.plate_case(seed=1111, n_collo=int(n_global * 0.65), n_refine=int(n_global * 0.38), uv_width=args.width)
         c["Collo"] = c["Collo"][:n_global] if c["Collo"].shape[0] >= n_global else c["Collo"]
         n_global = c["Collo"].shape[0]
         pts_per_rank = n_global // world
         layers = c["uv_layers"]
-        streams, label = 5, "8x64 plate"
+        streams, label = 5, f"8x{args.width} plate"
         model = PINN(c["Collo"], c["HOLE"], c["IC"], c["LF"], c["RT"], c["UP"], c["LW"], c["DIST"], c["uv_layers"], c["dist_layers"], c["part_layers"],
                      c["lb"], c["ub"], precision=args.precision, seed=1111, verbose=False)
         eng = model.eng["uv"]
         step = lambda k: model.train(k, 1e-3)
-        workload = (f"2D plate with hole (hard BC: composite P + D*N, nested u_tt, plane stress), 8x64 tanh MLP + frozen 4x20 distance / particular "
-                    f"nets, {pts_per_rank} collocation pts per GPU + 9960 hole-traction pts, Adam step (BASELINE configs[2]; its L-BFGS stage runs "
+        workload = (f"2D plate with hole (hard BC: composite P + D*N, nested u_tt, plane stress), 8x{args.width} tanh MLP + frozen 4x20 distance / particular "
+                    f"nets, {pts_per_rank} collocation pts per GPU + 9960 hole-traction pts, Adam step ({'BASELINE configs[2]' if args.width == 64 else 'the reference script net, not a BASELINE config'}; its L-BFGS stage runs "
                     f"on the host over the same kernels); collocation set through the five-stream fused kernel, hole traction through the two-kernel path; {PRECISION_NOTE}")
     else:
         from pinn_elastodynamics_amd.navier_cauchy_3d import NavierCauchy3D, halfspace_case
@@ -262,7 +264,7 @@ def main():
             tflops = kflop * pts_per_rank / (acc["chain"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": "fused_wave_kernel (forward + reverse chain + weight gradient)" if fused else "chain_kernel (forward + reverse chain)",
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
-                               "traffic": None, "traffic_from_profiles": traffic_from_profiles("fused") if fused and args.precision == "f16x3" else None,
+                               "traffic": None, "traffic_from_profiles": traffic_from_profiles("fused") if fused and args.precision == "f16x3" and args.width == 64 else None,
                                "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch, "algorithmic_flop_per_point": kflop,
                                "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (one product per contraction) / HIP-event launch time; the f16x3 mode issues 3 MFMAs per "
@@ -270,7 +272,7 @@ def main():
                                        "Measured limiter: the SIMD's instruction issue, not a pipe (DESIGN.md section 6). traffic is not measured in this "
                                        "run (PMC counters need rocprofv3); see traffic_from_profiles"}
             out["kernel_ms_per_step"] = acc
-        elif cfg == "plate" and eng.lib.supported_width(layers[1]) <= 64 and len(layers) - 2 in (4, 8):
+        elif cfg == "plate" and eng.lib.supported_width(layers[1]) <= 96 and len(layers) - 2 in (4, 8):
             # ---- the five-stream instantiation of the fused kernel: HIP events around the kernel on the launch stream (process-wide
             # profiling hook of the library, include/pinn_hip.h)
             x, y, t = model._collo
@@ -321,7 +323,7 @@ def main():
                                             "blocks by cancellation (fp32: 2e-4), DESIGN.md section 6: not parity-grade" if fast else "")}
                     del m2, e2
                 out["other_precision_modes"] = modes
-                if not args.no_small_config:
+                if not args.no_small_config and args.width == 64:
                     # BASELINE configs[0]: 4x32 net, 50 k collocation points (the reference's own CPU-runnable case), GPU and CPU side by side
                     l0 = [3] + 4 * [32] + [7]
                     e0 = HipEngine(l0, precision=args.precision, device=dev, max_points=1 << 16)
@@ -339,7 +341,7 @@ def main():
                 if cfg == "nc3d":
                     out["cpu_baseline"] = cpu_baseline_nc3d(layers, c["lb"], c["ub"])
                 else:
-                    out["cpu_baseline"] = cpu_baseline([3] + 8 * [64] + [layers[-1] if cfg == "wave" else 7], 32768, 3, "8x64")
+                    out["cpu_baseline"] = cpu_baseline([3] + 8 * [args.width] + [layers[-1] if cfg == "wave" else 7], 32768, 3, f"8x{args.width}")
                     if cfg == "plate":
                         out["cpu_baseline"]["sample"] += " (the 2-D wave head on the same net size: the plate's composite graph has no separate CPU restatement in bench.py)"
         print(json.dumps(out))

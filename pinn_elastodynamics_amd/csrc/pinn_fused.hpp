@@ -593,8 +593,8 @@ struct Fused {
     // Early sums (LDSOP): a layer's running sums go back to memory, and the next layer's are requested, right behind the layer's weight
     // gradient -- not in the next hand-off window, where their issue (a compute unit's request capacity against the memory latency)
     // kept every wave of the workgroup waiting.  The first barrier of a layer is then an LDS-only one for this role.
-#ifdef PINN_X_EARLY_ONESLOT
-    static constexpr bool EARLY_SUMS = ONE_SLOT;
+#ifdef PINN_X_EARLY_ALL
+    static constexpr bool EARLY_SUMS = !SLDS;
 #else
     static constexpr bool EARLY_SUMS = LDSOP;
 #endif

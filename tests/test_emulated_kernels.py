@@ -103,8 +103,8 @@ def test_fused_wide_emulated(emu, width):
     assert e_loss < 2e-6 and e_grad < 3e-6
     e_loss, e_grad = run_wave(emu, layers, 70, "f16x3", fused=False)
     assert e_loss < 2e-6 and e_grad < 2e-6
-    e_loss, e_grad = run_wave(emu, layers, 300, "f16x3", min_ws=True, fused=True, normalize=False, seed=4)      # several steps per workgroup
-    assert e_loss < 2e-6 and e_grad < 5e-5
+    e_loss, e_grad = run_wave(emu, layers, 300 if width == 80 else 130, "f16x3", min_ws=True, fused=True, normalize=False, seed=4)      # several steps per workgroup
+    assert e_loss < 2e-6 and e_grad < 5e-6
 
 
 def test_chunked_workspace_emulated(emu):
