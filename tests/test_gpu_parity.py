@@ -333,7 +333,8 @@ def test_lbfgs_stage_on_device(dev, backend):
 @pytest.mark.parametrize("args", [["elastic_wave.py", "--case", "infinite", "--iters", "5", "--n-f", "4000", "--bfgs-iters", "3", "--width", "32"],
                                   ["elastic_wave.py", "--case", "semi", "--iters", "5", "--n-f", "4000", "--width", "48"],
                                   ["elastic_wave.py", "--case", "confined", "--iters", "5", "--n-f", "4000", "--width", "64"],
-                                  ["plate_hole.py", "--pre-iters", "5", "--iters", "3", "--bfgs-iters", "3", "--n-collo", "3000", "--n-refine", "500"]])
+                                  ["plate_hole.py", "--pre-iters", "5", "--iters", "3", "--bfgs-iters", "3", "--n-collo", "3000", "--n-refine", "500"],
+                                  ["navier_cauchy_3d.py", "--iters", "5", "--n-f", "4000", "--bfgs-iters", "3", "--width", "48", "--depth", "3"]])
 def test_example_drivers_run(dev, tmp_path, args):
     """The drivers shaped like the reference's __main__ blocks run end to end (point sets -> model -> Adam / L-BFGS -> save -> predict)."""
     import os
