@@ -76,7 +76,7 @@ struct FusedArgs {
 // such constants alone (2 * term weight, the packed tangent seeds of the input state ...) out of the loop into registers it then has
 // to spill -- and a spill reload in the step is a full memory round trip (round-2 phase stamps: 3.5 k cycles in the residual head).
 __device__ __forceinline__ float in_loop(float v) {
-#if defined(__AMDGCN__) && !defined(PINN_X_NOINLOOP)
+#if defined(__AMDGCN__)
     asm volatile("" : "+v"(v));      // (a vector register: a scalar constraint is refused where the compiler holds the value in one)
 #endif
     return v;
@@ -550,11 +550,7 @@ struct Fused {
     };
     static constexpr int N_DMA_ALL = LDSOP ? IMG_B / 2048 : IMG_B / 1024;       // LDSOP: two waves share a tile's records
     // mid layers: the LDS-DMA of S_{L-1} is issued in slices inside the weight gradient of layer L, not as a burst in the hand-off window
-#ifdef PINN_X_DMAWIN
-    static constexpr bool DMA_IN_WGRAD = LDSOP && !ONE_SLOT;
-#else
     static constexpr bool DMA_IN_WGRAD = !SLDS && !ONE_SLOT;
-#endif
     static __device__ __forceinline__ void dma_state(const DmaSrc& src, unsigned lane16, char* tile_lds, int l /*1..NL-1*/, int quad, int ii0 = 0,
                                                      int ii1 = N_DMA_ALL) {
         if constexpr (SLDS) return;
@@ -593,11 +589,7 @@ struct Fused {
     // Early sums (LDSOP): a layer's running sums go back to memory, and the next layer's are requested, right behind the layer's weight
     // gradient -- not in the next hand-off window, where their issue (a compute unit's request capacity against the memory latency)
     // kept every wave of the workgroup waiting.  The first barrier of a layer is then an LDS-only one for this role.
-#ifdef PINN_X_EARLY_ALL
-    static constexpr bool EARLY_SUMS = !SLDS;
-#else
-    static constexpr bool EARLY_SUMS = LDSOP;
-#endif
+    static constexpr bool EARLY_SUMS = LDSOP;      // (the narrow layouts measure the same either way: 5.77 / 5.78 ms)
     static __device__ __forceinline__ void store_sums(__amdgpu_buffer_rsrc_t accr, unsigned lane16, int L, const Sums& p) {
 #pragma unroll
         for (int i = 0; i < IBW; ++i)
@@ -1294,11 +1286,7 @@ struct Fused {
     // workgroup barrier that orders LDS traffic only: the chain waves' park stores and fragment loads stay in flight across it
     // hand-off barriers of the chain waves: LDS traffic only, the fragment / low-part loads requested in front of them stay in flight
     static __device__ __forceinline__ void hand_barrier() {
-#ifdef PINN_X_FULLBAR
-        __syncthreads();
-#else
         lds_barrier();
-#endif
     }
     static __device__ __forceinline__ void lds_barrier() {
 #if defined(__AMDGCN__)
