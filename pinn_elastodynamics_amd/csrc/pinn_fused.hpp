@@ -82,6 +82,13 @@ __device__ __forceinline__ float in_loop(float v) {
     return v;
 }
 
+__device__ __forceinline__ unsigned in_loop(unsigned v) {
+#if defined(__AMDGCN__)
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+
 __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int slot) {
     if (a.dbg != nullptr && who) a.dbg[slot] = __builtin_readcyclecounter();
 }
@@ -1751,6 +1758,10 @@ struct Fused {
                 load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + wave, c, xin, valid, pidx);
             }
             x.tracer = blockIdx.x == 0 && wave4 == 0 && lane == 0 && step == 2 * (long)gridDim.x;      // a steady-state step
+            if constexpr (LDSOP) {                 // lane addresses derived from these are then formed where they are used, not hoisted and spilled
+                x.imgoff = in_loop(x.imgoff);
+                x.lane16 = in_loop(x.lane16);
+            }
             fused_stamp(a, x.tracer, 0);
             if constexpr (LDSOP) {
                 u32x4 ZL[NS][1][1][NP];
