@@ -12,4 +12,14 @@ cp $(find $OUT/prof_$TAG -name '*kernel_stats.csv' | head -1) $OUT/${TAG}_fused_
 cd $ROOT
 bash tools/pmc_collect.sh prod > $OUT/pmc_prod.log 2>&1
 cp $OUT/pmc_prod/summary.json $OUT/${TAG}_fused_pmc_summary.json
+# the reference's own net widths through the LDS-operand layouts: kernel-trace stats of short bench runs
+cd /tmp
+for cfg in "wave 80" "wave 100" "plate 70"; do
+    set -- $cfg
+    rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_${TAG}_$1$2 -o bench -- python $ROOT/bench.py --config $1 --width $2 --points-per-gpu 1000000 --steps 10 --warmup 3 --ramp-steps 10 --no-cpu-baseline --extra-modes none > $OUT/prof_${TAG}_$1$2.log 2>&1
+    head -4 $(find $OUT/prof_${TAG}_$1$2 -name '*kernel_stats.csv' | head -1) | sed "s/^/$1$2,/" >> $OUT/${TAG}_wide_kernel_stats.csv.tmp
+done
+cd $ROOT
+mv $OUT/${TAG}_wide_kernel_stats.csv.tmp $OUT/${TAG}_wide_kernel_stats.csv
 head -8 $OUT/${TAG}_fused_kernel_stats.csv
+cat $OUT/${TAG}_wide_kernel_stats.csv
