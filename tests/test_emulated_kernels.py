@@ -312,6 +312,14 @@ def test_empty_and_ragged_batches_emulated(emu):
     emu.set_fused(1)
 
 
+@pytest.mark.parametrize("n", [1, 15, 17, 33, 47])
+def test_ragged_batches_wide_layout_emulated(emu, n):
+    """Sizes around the 16-point tile and the 32-point workgroup step of the LDS-operand layout (padded width 96, two waves per tile):
+    masked points of a partial tile contribute nothing, a missing second tile neither."""
+    e_loss, e_grad = run_wave(emu, [3] + 8 * [80] + [7], n, "f16x3", fused=True, seed=n)
+    assert e_loss < 2e-6 and e_grad < 3e-6, n
+
+
 @pytest.mark.parametrize("layers,n,fused", [([3] + 4 * [32] + [7], 150, 1), ([3] + 8 * [64] + [7], 90, 1), ([3] + 8 * [64] + [7], 90, 0)])
 def test_data_terms_fused_and_two_kernel_emulated(emu, layers, n, fused):
     """value-only side sets (loss_IC / loss_SRC / ...) through the fused kernel's 1-stream instantiation and the two-kernel path"""
