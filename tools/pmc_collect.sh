@@ -1,8 +1,12 @@
 #!/bin/bash
 # Dev tool (GPU box): per-kernel PMC counters of an experiment library's fused launch, several passes of <= 4 counters.
-#   tools/pmc_collect.sh NAME      (library build/exp/NAME/libpinn_hip.so; output gpurun_out/pmc_NAME/)
+#   tools/pmc_collect.sh NAME [WIDTH]     (library build/exp/NAME/libpinn_hip.so; output gpurun_out/pmc_NAME[_WIDTH]/)
+# WIDTH (80, 100): the launches of tools/wide_time.py WIDTH NAME (1,000,000 points of the 8 x WIDTH net) instead of tools/exp_run.py (8x64, 2 M).
 NAME=$1
-OUT=$PWD/gpurun_out/pmc_$NAME
+WIDTH=$2
+OUT=$PWD/gpurun_out/pmc_$NAME${WIDTH:+_$WIDTH}
+if [ -n "$WIDTH" ]; then CMD="$GRAFT_REPO_ROOT/tools/wide_time.py $WIDTH $NAME"; WHAT="8x$WIDTH net, 1,000,000 points per launch (tools/wide_time.py)"
+else CMD="$GRAFT_REPO_ROOT/tools/exp_run.py $NAME"; WHAT="fused_wave_kernel<OpF16,3,64,8,4>, 2,000,000 points per launch (tools/exp_run.py)"; fi
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 i=0
@@ -11,7 +15,7 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY 
            "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_LDS_IDX_ACTIVE SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_VMEM SQ_IFETCH" \
            "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_EA0_RDREQ_DRAM_sum TCC_EA0_WRREQ_DRAM_sum TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p -- python $GRAFT_REPO_ROOT/tools/exp_run.py $NAME > $OUT/p$i.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/p$i -o p -- python $CMD > $OUT/p$i.log 2>&1
 done
 python - <<PY
 import csv, glob, collections
@@ -38,8 +42,8 @@ if g('TCC_EA0_RDREQ_sum') is not None and g('TCC_EA0_WRREQ_sum') is not None:
     # exact request sizes on the L2 <-> fabric interface: 32-byte and 64-byte requests counted separately
     js['ea_read_bytes_per_launch'] = 32.0 * g('TCC_EA0_RDREQ_32B_sum') + 64.0 * (g('TCC_EA0_RDREQ_sum') - g('TCC_EA0_RDREQ_32B_sum'))
     js['ea_write_bytes_per_launch'] = 64.0 * g('TCC_EA0_WRREQ_64B_sum') + 32.0 * (g('TCC_EA0_WRREQ_sum') - g('TCC_EA0_WRREQ_64B_sum'))
-js['note'] = ('fused_wave_kernel<OpF16,3,64,8,4>, 2,000,000 points per launch (tools/pmc_collect.sh on tools/exp_run.py; one rocprofv3 --pmc pass per '
-              'group of <= 4 counters, --kernel-trace only). FETCH_SIZE/WRITE_SIZE are in KB; hbm_bytes = 2*FETCH (gfx950 correction) + WRITE. These '
+js['note'] = ('$WHAT; tools/pmc_collect.sh: one rocprofv3 --pmc pass per '
+              'group of <= 4 counters, --kernel-trace only. FETCH_SIZE/WRITE_SIZE are in KB; hbm_bytes = 2*FETCH (gfx950 correction) + WRITE. These '
               'L2<->fabric counters include Infinity-Cache hits.')
 json.dump(js, open('$OUT/summary.json', 'w'), indent=1, sort_keys=True)
 PY
