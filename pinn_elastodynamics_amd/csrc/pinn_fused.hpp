@@ -229,7 +229,7 @@ struct Fused {
         int quad;
     };
     // DL >= 2: the LDS-DMA of S_{DL-1} rides along, a slice behind every group (see DmaJob)
-    template <int NA, int NBK, bool SLO = false, int DL = 0>
+    template <int NA, int NBK, bool SLO = false, int DL = 0, int SSTR = KS * SP * 1024>
     static __device__ __forceinline__ void wg_blocks(const char* s0, const char* s1, const char* z0, const char* z1, f32x4 (&acc)[NA][NBK],
                                                      float (&bias_out)[NBK], const DmaJob* job = nullptr) {
         auto dma_slice = [&](int g) {
@@ -254,8 +254,8 @@ struct Fused {
             const int j = g / NS, st = g % NS;
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
-                f.Ah[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * KS * SP * 1024 + 8 * a);
-                if constexpr (SLO) f.Al[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * KS * SP * 1024 + 1024 + 8 * a);
+                f.Ah[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * SSTR + 8 * a);
+                if constexpr (SLO) f.Al[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * SSTR + 1024 + 8 * a);
             }
 #pragma unroll
             for (int b = 0; b < NBK; ++b) {
@@ -494,7 +494,7 @@ struct Fused {
     }
     template <int L>
     static __device__ __forceinline__ void wgrad_narrow(const WgCtx& w, Acc& A, int quad, const f32x4 (&ld)[IBW][OBW], f32x4 (&pend)[IBW][OBW], const DmaJob& job) {
-        constexpr int DMA_L = DMA_IN_WGRAD && L >= 2 && L <= NL - 1 ? L : 0;
+        constexpr int DMA_L = DMA_IN_WGRAD && L >= 2 && L <= NL - 1 && !kept_in_lds(L - 1) ? L : 0;
         const char* s0 = w.s0 + slot_of(L) * IMG_B;
         const char* s1 = w.s1 + slot_of(L) * IMG_B;
         const int wi = quad >> 1, wo = quad & 1;
@@ -510,7 +510,8 @@ struct Fused {
             if (quad < WB) {
                 f32x4 t[1][1] = {{A.last}};
                 float b[1];
-                wg_blocks<1, 1>(s0 + img_block(quad), s1 + img_block(quad), w.z0, w.z1, t, b);
+                if constexpr (TOP_IN_Z) wg_blocks<1, 1, false, 0, TOPZ_STRIDE>(w.z0 + TOPZ_OFF + img_block(quad), w.z1 + TOPZ_OFF + img_block(quad), w.z0, w.z1, t, b);
+                else wg_blocks<1, 1>(s0 + img_block(quad), s1 + img_block(quad), w.z0, w.z1, t, b);
                 A.last = t[0][0];
                 if (quad == 0) A.bias[NL] += b[0];
             }
@@ -555,6 +556,20 @@ struct Fused {
 #endif
         }
     };
+    // Narrow layouts: the state slots are idle in the forward, so the high parts of the last parked states go straight into them instead of
+    // to scratch and back by LDS-DMA (the kernel moves 17 KB per point through L2 at ~6 TB/s, profiles/README.md): S_{NL-1} always, and
+    // S_{NL-2} where S_NL -- which takes the other slot at the top of the reverse -- can live in the Z area instead (TOP_IN_Z: the
+    // 16-output adjoint Z_NL fills only the k-step-0 records of the Z area; with two k-steps and both parts the k-step-1 records are
+    // exactly one high-part state image, stream stride 4 KB).  One LDS barrier in the forward, in front of the first such write, orders
+    // it behind the previous step's last weight gradient (which finished a forward ago; the barrier makes that formal).
+    static constexpr bool KEEP2 = !SLDS && !LDSOP;
+    // (LDS-operand layouts with two slots: slot 1 is idle in the forward too; S_{NL-1} is written there beside its ping-pong image and
+    // neither parked nor brought back.)
+    static constexpr bool KEEP_W = LDSOP && !ONE_SLOT;
+    static constexpr bool TOP_IN_Z = KEEP2 && KS == 2 && NP == 2;
+    static constexpr int FIRST_KEPT = TOP_IN_Z ? NL - 2 : NL - 1;
+    static __device__ __forceinline__ constexpr bool kept_in_lds(int l) { return (KEEP2 && l >= FIRST_KEPT && l <= NL - 1) || (KEEP_W && l == NL - 1); }
+    static constexpr int TOPZ_OFF = NP * 1024, TOPZ_STRIDE = KS * NP * 1024;      // S_NL inside the Z area: record (s * KS + 1) * NP + kk
     static constexpr int N_DMA_ALL = LDSOP ? IMG_B / 2048 : IMG_B / 1024;       // LDSOP: two waves share a tile's records
     // mid layers: the LDS-DMA of S_{L-1} is issued in slices inside the weight gradient of layer L, not as a burst in the hand-off window
     static constexpr bool DMA_IN_WGRAD = !SLDS && !ONE_SLOT;
@@ -628,7 +643,7 @@ struct Fused {
         static constexpr int N_LOAD = in_memory(L) ? NSUM : 0;
         // LDSOP mid layers: the DMA of S_{L-1} is issued inside the weight gradient of layer L (wg_blocks33), not in the window
         // ONE_SLOT: the DMA of S_L itself, in layer L's own window, and the window waits for all of it
-        static constexpr bool DMA_IN_WINDOW = !SLDS && !ONE_SLOT && L >= 2 && (!DMA_IN_WGRAD || L == NL);
+        static constexpr bool DMA_IN_WINDOW = !SLDS && !ONE_SLOT && L >= 2 && (!DMA_IN_WGRAD || L == NL) && !kept_in_lds(L - 1);
         static constexpr bool DMA_OWN = ONE_SLOT && L >= 1 && L <= NL - 1;
         static constexpr int N_DMA = DMA_IN_WINDOW ? N_DMA_ALL : 0;
         static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const WgCtx& w, const DmaSrc& scr, __amdgpu_buffer_rsrc_t accr,
@@ -710,13 +725,14 @@ struct Fused {
         }
         Sums pend, ld;
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
+            if constexpr (KEEP2) lds_barrier();           // the forward's barrier in front of its first state-slot write (see KEEP2)
             if constexpr (LDSOP) {
                 __syncthreads();                          // step barrier (see the chain role): this wave's reads of the previous step are done
                 // the forward's exchange barriers between the two halves of a tile; behind barrier l the image of S_{l+1} is complete and
                 // this wave parks its share of it (the records it will bring back by LDS-DMA: same wave, same addresses, program order)
                 for (int l = 0; l < NL; ++l) {
                     lds_barrier();
-                    if (l + 1 <= NL - 1) park_image(scr_st, lane16, tile_lds, l + 1, quad);
+                    if (l + 1 <= NL - 1 && !kept_in_lds(l + 1)) park_image(scr_st, lane16, tile_lds, l + 1, quad);
                 }
             }
             WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend, ld);
@@ -1014,6 +1030,9 @@ struct Fused {
     static __device__ __forceinline__ void park_state(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
         if constexpr (SLDS) {
             put_image<KS>(x.imgS(l), Sf);               // the tile's own records of slot l; nobody else touches them in the forward
+        } else if (kept_in_lds(l)) {
+            if (l == FIRST_KEPT) lds_barrier();         // (see KEEP2)
+            put_image<KS>(x.imgS(l), Sf);
         } else {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
@@ -1382,6 +1401,7 @@ struct Fused {
         u32x4 out[NS][1][2][NP];
         wide_fwd_epilogue<0>(acc, out);
         half_store(outimg, h, out);
+        if (kept_in_lds(l + 1)) half_store(x.imgS(l + 1), h, out);       // S_{NL-1} also into its reverse slot (KEEP_W)
     }
     template <int J>
     static __device__ __forceinline__ void wide_first(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, u32x4 (&Bn)[NS][1][2][NP]) {
@@ -1703,7 +1723,14 @@ struct Fused {
         __syncthreads();              // the one full drain of the reverse: every park store of this forward has landed before an LDS-DMA reads it
         fused_stamp(a, x.tracer, 3);
         put_zimage<1>(x.imgZ(), ZL);
-        put_image<KS>(x.imgS(NL), B);
+        if constexpr (TOP_IN_Z) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int kk = 0; kk < KS; ++kk) *reinterpret_cast<u32x4*>(x.imgZ() + TOPZ_OFF + s * TOPZ_STRIDE + kk * 1024) = B[s][0][kk][0];
+        } else {
+            put_image<KS>(x.imgS(NL), B);
+        }
         hand_barrier();
         fused_stamp(a, x.tracer, 4);
         u32x4 Zn[NS][1][KS][NP];
