@@ -563,12 +563,16 @@ struct Fused {
     // exactly one high-part state image, stream stride 4 KB).  One LDS barrier in the forward, in front of the first such write, orders
     // it behind the previous step's last weight gradient (which finished a forward ago; the barrier makes that formal).
     static constexpr bool KEEP2 = !SLDS && !LDSOP;
+    // ... and S_1 is not parked at all: the first layer is three multiply-adds and a tanh per feature, so the reverse recomputes it from
+    // the inputs (first_mb, the forward's own function: the same bits) instead of moving 2 KB per point through L2.
+    // (Four streams only: the five-stream instantiation has no registers for it -- 43 -> 63 spilled, 4.0 -> 4.25 ms.)
+    static constexpr bool RECOMP1 = KEEP2 && NL >= 4 && NS_ == 4;
     // (LDS-operand layouts with two slots: slot 1 is idle in the forward too; S_{NL-1} is written there beside its ping-pong image and
     // neither parked nor brought back.)
     static constexpr bool KEEP_W = LDSOP && !ONE_SLOT;
     static constexpr bool TOP_IN_Z = KEEP2 && KS == 2 && NP == 2;
     static constexpr int FIRST_KEPT = TOP_IN_Z ? NL - 2 : NL - 1;
-    static __device__ __forceinline__ constexpr bool kept_in_lds(int l) { return (KEEP2 && l >= FIRST_KEPT && l <= NL - 1) || (KEEP_W && l == NL - 1); }
+    static __device__ __forceinline__ constexpr bool kept_in_lds(int l) { return (KEEP2 && l >= FIRST_KEPT && l <= NL - 1) || (KEEP_W && l == NL - 1) || (RECOMP1 && l == 1); }
     static constexpr int TOPZ_OFF = NP * 1024, TOPZ_STRIDE = KS * NP * 1024;      // S_NL inside the Z area: record (s * KS + 1) * NP + kk
     static constexpr int N_DMA_ALL = LDSOP ? IMG_B / 2048 : IMG_B / 1024;       // LDSOP: two waves share a tile's records
     // mid layers: the LDS-DMA of S_{L-1} is issued in slices inside the weight gradient of layer L, not as a burst in the hand-off window
@@ -1030,6 +1034,8 @@ struct Fused {
     static __device__ __forceinline__ void park_state(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
         if constexpr (SLDS) {
             put_image<KS>(x.imgS(l), Sf);               // the tile's own records of slot l; nobody else touches them in the forward
+        } else if (RECOMP1 && l == 1) {
+            return;                                     // recomputed by the reverse (hi and lo)
         } else if (kept_in_lds(l)) {
             if (l == FIRST_KEPT) lds_barrier();         // (see KEEP2)
             put_image<KS>(x.imgS(l), Sf);
@@ -1242,15 +1248,21 @@ struct Fused {
         static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&Zc)[NS][1][KS][NP]) {
             u32x4 Aa[KS][RP], Ab[KS][RP];
             u32x2 sla[NS], slb[NS];
+            constexpr bool RECOMP = RECOMP1 && L == 1;
+            u32x4 S1[NS][1][KS][NP];                           // (RECOMP only)
             if constexpr (L >= 1) {                            // this layer's first fragments travel during the hand-off
                 load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 0, 0), Aa);
                 load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 1, 0), Ab);
-                lo_from_scratch<0>(x, L, sla);
+                if constexpr (!RECOMP) lo_from_scratch<0>(x, L, sla);
             }
             hand_barrier();                                    // previous layer's fragment reads are done
             fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
             put_zimage<KS>(x.imgZ(), Zc);
             if constexpr (L == 0) put_input_state(a, x, xin);
+            if constexpr (RECOMP) {                            // S_1 again from the inputs; its high parts into the layer's slot for the weight gradient
+                first_mb<0>(a, x, xin, S1);
+                put_image<KS>(x.imgS(1), S1);
+            }
             hand_barrier();                                    // tensors visible to the weight-gradient waves; S_L has landed
             fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
             if constexpr (L >= 1) {
@@ -1259,7 +1271,8 @@ struct Fused {
                 f32x4 acca[NS], accb[NS];
                 acc_zero(acca);
                 bwd_ksteps<0, KS, KS>(Aa, Zc, acca);
-                bwd_step<0, KS, false>(x, FI::bwd_mid(NL, L, 0, 0), L, x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb, sla, slb);
+                if constexpr (RECOMP) bwd_step<0, KS, true>(x, FI::bwd_mid(NL, L, 0, 0), L, nullptr, S1, Zc, Zn, Aa, Ab, acca, accb, sla, slb);
+                else bwd_step<0, KS, false>(x, FI::bwd_mid(NL, L, 0, 0), L, x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb, sla, slb);
                 pin<KS>(Zn);
                 fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
                 Down<L - 1>::run(a, x, xin, Zn);

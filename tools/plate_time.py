@@ -13,7 +13,8 @@ C = np.stack([rng.random(n) * 0.5, rng.random(n) * 0.5, rng.random(n) * 10], 1)
 xs = [torch.from_numpy(C[:, k].astype(np.float32)).to(dev) for k in range(3)]
 frozen = torch.from_numpy(rng.standard_normal((2, 5, 5, n)).astype(np.float32)).to(dev)
 th = torch.from_numpy(fN.astype(np.float32)).to(dev)
-eng = HipEngine(lN, precision='f16x3', device=dev, max_points=1 << 18)
+libp = os.path.join(ROOT, 'build/exp', sys.argv[2], 'libpinn_hip.so') if len(sys.argv) > 2 else None
+eng = HipEngine(lN, precision='f16x3', device=dev, max_points=1 << 18, **({'lib_path': libp} if libp else {}))
 tw = [10.0 / n] * 5
 m = 8192
 fz = frozen[:, :, :, :m].contiguous().cpu().numpy().astype(np.float64)
