@@ -316,7 +316,7 @@ struct Fused {
                                                        const char* zs0, const char* zs1, f32x4 (&acc)[3][3], const DmaJob& job) {
         constexpr int NGRP = NJ * NS;
         auto dma_slice = [&](int g) {
-            if constexpr (L >= 2 && !ONE_SLOT) dma_state(*job.scr, job.lane16, job.tile_lds, L - 1, job.quad, g * N_DMA_ALL / NGRP, (g + 1) * N_DMA_ALL / NGRP);
+            if constexpr (L >= 2 && !ONE_SLOT && !kept_in_lds(L - 1)) dma_state(*job.scr, job.lane16, job.tile_lds, L - 1, job.quad, g * N_DMA_ALL / NGRP, (g + 1) * N_DMA_ALL / NGRP);
         };
         static_assert(NP == 2 || !LDSOP, "split-precision layout");
         f32x4 cc[3][3];
@@ -567,12 +567,17 @@ struct Fused {
     // the inputs (first_mb, the forward's own function: the same bits) instead of moving 2 KB per point through L2.
     // (Four streams only: the five-stream instantiation has no registers for it -- 43 -> 63 spilled, 4.0 -> 4.25 ms.)
     static constexpr bool RECOMP1 = KEEP2 && NL >= 4 && NS_ == 4;
+    // LDS-operand layouts: the chain halves write the recomputed S_1 (both parts) straight into the layer's slot in its hand-off window
+    // (no registers involved: their states are read from the image anyway); neither parked nor brought back.
+    // One-slot layouts only, where it also empties the layer-1 window of its LDS-DMA (8x100: 13.0 -> 11.7 ms; the two-slot width-96
+    // layout measures the same with and without).
+    static constexpr bool RECOMP_W = ONE_SLOT;
     // (LDS-operand layouts with two slots: slot 1 is idle in the forward too; S_{NL-1} is written there beside its ping-pong image and
     // neither parked nor brought back.)
     static constexpr bool KEEP_W = LDSOP && !ONE_SLOT;
     static constexpr bool TOP_IN_Z = KEEP2 && KS == 2 && NP == 2;
     static constexpr int FIRST_KEPT = TOP_IN_Z ? NL - 2 : NL - 1;
-    static __device__ __forceinline__ constexpr bool kept_in_lds(int l) { return (KEEP2 && l >= FIRST_KEPT && l <= NL - 1) || (KEEP_W && l == NL - 1) || (RECOMP1 && l == 1); }
+    static __device__ __forceinline__ constexpr bool kept_in_lds(int l) { return (KEEP2 && l >= FIRST_KEPT && l <= NL - 1) || (KEEP_W && l == NL - 1) || ((RECOMP1 || RECOMP_W) && l == 1); }
     static constexpr int TOPZ_OFF = NP * 1024, TOPZ_STRIDE = KS * NP * 1024;      // S_NL inside the Z area: record (s * KS + 1) * NP + kk
     static constexpr int N_DMA_ALL = LDSOP ? IMG_B / 2048 : IMG_B / 1024;       // LDSOP: two waves share a tile's records
     // mid layers: the LDS-DMA of S_{L-1} is issued in slices inside the weight gradient of layer L, not as a burst in the hand-off window
@@ -648,7 +653,7 @@ struct Fused {
         // LDSOP mid layers: the DMA of S_{L-1} is issued inside the weight gradient of layer L (wg_blocks33), not in the window
         // ONE_SLOT: the DMA of S_L itself, in layer L's own window, and the window waits for all of it
         static constexpr bool DMA_IN_WINDOW = !SLDS && !ONE_SLOT && L >= 2 && (!DMA_IN_WGRAD || L == NL) && !kept_in_lds(L - 1);
-        static constexpr bool DMA_OWN = ONE_SLOT && L >= 1 && L <= NL - 1;
+        static constexpr bool DMA_OWN = ONE_SLOT && L >= 1 && L <= NL - 1 && !kept_in_lds(L);
         static constexpr int N_DMA = DMA_IN_WINDOW ? N_DMA_ALL : 0;
         static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const WgCtx& w, const DmaSrc& scr, __amdgpu_buffer_rsrc_t accr,
                                                    unsigned lane16, char* tile_lds, Acc& A, int quad, Sums& pend, Sums& ld) {
@@ -1545,6 +1550,11 @@ struct Fused {
         half_store(x.imgZ(), h, Zc);
         if constexpr (L == 0) {
             if (h == 0) put_input_state(a, x, xin);
+        }
+        if constexpr (RECOMP_W && L == 1) {                     // S_1 again from the inputs, this half's blocks (the forward's own function)
+            u32x4 S1[NS][1][2][NP];
+            wide_first<0>(a, x, xin, h, S1);
+            half_store(x.imgS(1), h, S1);
         }
 #ifdef PINN_X_WSTAMP
         fused_stamp(a, x.tracer, 44 + (NL - L));
