@@ -174,7 +174,9 @@ struct Fused {
     // (loaded in the layer's hand-off window, stored one layer later so that the write acknowledgement never sits in front of a
     // full drain): with all NL-1 layers in registers the compiler spilled several layers' worth anyway, reloaded and stored them
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
-    static constexpr int NG = LDSOP ? NL - 1 : (NL >= 8 ? 5 : (NL >= 4 ? 2 : 0));      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
+    // (two-slot wide layout: layer 1's nine blocks stay in registers -- one layer less of the sums' round trip through L2: 6.39 -> 6.28 ms;
+    // a second layer spills 82 registers)
+    static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? 5 : (NL >= 4 ? 2 : 0));      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
     static constexpr int NSUM = IBW * OBW + (LDSOP ? 1 : 0);                   // in-memory records per layer: the blocks (+ LDSOP: the bias blocks' lane record)
     static constexpr unsigned WG_ACC_BYTES = (unsigned)((NG > 0 ? NG : 1) * NSUM * 1024);
@@ -192,6 +194,7 @@ struct Fused {
         // blocks per mid layer held by the waves with wi == 0
         f32x4 first2, last2;
         float bias0b;                  // (LDSOP mid-layer bias blocks: one more in-memory record per layer, bias_record)
+        float biasr[NREG > 0 ? NREG : 1][3];      // ... of the in-register layers (LDSOP)
     };
 
     // ---------------------------------------------------------------------------------------------
@@ -438,7 +441,25 @@ struct Fused {
                 }
             }
         } else {
-            static_assert(in_memory(L), "LDSOP keeps every mid-layer accumulator in memory");
+            if constexpr (!in_memory(L)) {               // an in-register layer (two-slot layout): the nine blocks accumulate in place
+                static_assert(WB == 6, "in-register layers of the LDS-operand layouts: width 96 only");
+                const char* sp0 = s0 + img_block(2 * wi);
+                const char* sp1 = s1 + img_block(2 * wi);
+                const char* ss0 = s0 + img_block(4 + wi);
+                const char* ss1 = s1 + img_block(4 + wi);
+                const char* zp0 = w.z0 + zimg_block(2 * wo);
+                const char* zp1 = w.z1 + zimg_block(2 * wo);
+                const char* zs0 = w.z0 + zimg_block(4 + wo);
+                const char* zs1 = w.z1 + zimg_block(4 + wo);
+                wg_blocks33<L>(sp0, sp1, ss0, ss1, zp0, zp1, zs0, zs1, A.mid[L - 1], job);
+                if (wi == 0) {
+                    float b3[3];
+                    wg_bias3(zp0, zp1, zs0, zs1, b3);
+                    A.biasr[L - 1][0] += b3[0];
+                    A.biasr[L - 1][1] += b3[1];
+                    A.biasr[L - 1][2] += b3[2];
+                }
+            } else {
             pends_.bias = lds_.bias;
             // pend starts from the layer's running sums
 #pragma unroll
@@ -478,6 +499,7 @@ struct Fused {
                 pends_.bias[0] += b3[0];
                 pends_.bias[1] += b3[1];
                 pends_.bias[2] += b3[2];
+            }
             }
             }
         }
@@ -707,6 +729,8 @@ struct Fused {
         A.bias0b = 0.0f;
 #pragma unroll
         for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
+#pragma unroll
+        for (int l = 0; l < (NREG > 0 ? NREG : 1); ++l) A.biasr[l][0] = A.biasr[l][1] = A.biasr[l][2] = 0.0f;
         WgCtx w;
         {
             const char* wave0 = lds + (q >> 1) * WAVE_B;
@@ -785,10 +809,14 @@ struct Fused {
                 for (int i = 0; i < IBW; ++i)
 #pragma unroll
                     for (int o = 0; o < OBW; ++o) {
-                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(l, i, o), 0));
+                        f32x4 v;
+                        if (in_memory(l)) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(l, i, o), 0));
+                        else v = A.mid[l <= NREG ? l - 1 : 0][i][o];
                         put_block(v, l, wide_block(wi, i), wide_block(wo, o), H, H);
                     }
-                const f32x4 bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l), 0));
+                f32x4 bv;
+                if (in_memory(l)) bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l), 0));
+                else bv = f32x4{A.biasr[l <= NREG ? l - 1 : 0][0], A.biasr[l <= NREG ? l - 1 : 0][1], A.biasr[l <= NREG ? l - 1 : 0][2], 0.0f};
                 if (wi == 0 && q == 0) {
 #pragma unroll
                     for (int o = 0; o < OBW; ++o) {
