@@ -81,7 +81,7 @@ static void run_block(Block& b) {
             const int lo = w * 64, hi = std::min(nthreads, lo + 64);
             // run this wave until every lane sits at a block barrier or has finished
             for (;;) {
-                int n_wave = 0, n_block = 0, n_done = 0;
+                int n_wave = 0, n_block = 0, n_done = 0, n_spin = 0;
                 for (int i = lo; i < hi; ++i) {
                     Lane& l = b.lanes[(size_t)i];
                     if (l.state == 0 || l.state == 1) {
@@ -92,9 +92,14 @@ static void run_block(Block& b) {
                     n_wave += l.state == 1;
                     n_block += l.state == 2;
                     n_done += l.state == 3;
+                    n_spin += l.state == 4;
                 }
                 const int n = hi - lo;
                 if (n_wave == n) continue;                      // all at the same wave collective: release
+                if (n_spin == n) {                              // the whole wave polls a flag: give the other waves a turn
+                    for (int i = lo; i < hi; ++i) b.lanes[(size_t)i].state = 0;
+                    break;
+                }
                 if (n_done == n) { ++done_waves; break; }
                 if (n_block == n) { ++at_block; break; }
                 if (n_wave + n_done == n && n_wave > 0) {

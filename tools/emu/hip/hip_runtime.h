@@ -56,7 +56,7 @@ struct Lane {
     void* sp = nullptr;          // saved stack pointer of the fiber
     char* stack = nullptr;
     dim3 tid;
-    int state = 0;               // 0 runnable, 1 at wave sync, 2 at block sync, 3 done
+    int state = 0;               // 0 runnable, 1 at wave sync, 2 at block sync, 3 done, 4 polling (runnable again on the next round)
     const void* xchg[3] = {nullptr, nullptr, nullptr};
 };
 struct Block {
@@ -73,6 +73,7 @@ inline int lane_id() { return g_blk->cur & 63; }
 void yield_to_scheduler(int state);
 inline void wave_sync() { yield_to_scheduler(1); }
 inline void block_sync() { yield_to_scheduler(2); }
+inline void spin_yield() { yield_to_scheduler(4); }      // a lane polling a flag another wave will set: let the other waves run
 void run_grid(dim3 grid, dim3 block, const std::function<void()>& body);
 extern long g_mfma_count;
 }  // namespace emu
@@ -242,6 +243,7 @@ inline float __builtin_amdgcn_sqrtf(float x) { return sqrtf(x); }
 inline float __builtin_amdgcn_rsqf(float x) { return 1.0f / sqrtf(x); }
 inline void __builtin_amdgcn_s_setprio(int) {}
 inline void __builtin_amdgcn_sched_barrier(int) {}
+inline void __builtin_amdgcn_s_sleep(int) { emu::spin_yield(); }
 inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 
 template <class T>
