@@ -25,6 +25,7 @@ import pickle
 import numpy as np
 import scipy.io
 
+from . import golden_points as gp
 from . import pinn_oracle as po
 from . import plate_oracle as pl
 
@@ -150,9 +151,46 @@ def plate():
     print("  FEM rel-L2 per frame u:", np.round(rel[0], 3), "v:", np.round(rel[1], 3), "s11:", np.round(rel[2], 3))
 
 
+def large():
+    """golden_<case>_32k.npz: float64 oracle sums and gradient on oracle/golden_points.py's 32 768 seeded points at the reference's trained
+    weights (the 1024-point sets above stay what they are: they also carry fields, Jacobians and the residual vectors)."""
+    for name, c in CASES.items():
+        if name == "inf10s":
+            continue
+        W, b = load_pickle(os.path.join(REF, c["pkl"]))
+        layers = [W[0].shape[0]] + [w.shape[1] for w in W]
+        flat = po.pack_params(W, b)
+        X = gp.wave_points(c["lb"], c["ub"], c["src"])
+        N = X.shape[0]
+        ss, g, f = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], np.array(c["lb"], float), np.array(c["ub"], float),
+                                       c["normalize"], term_weights=np.ones(7) / N)
+        np.savez_compressed(os.path.join(OUT, f"golden_{name}_32k.npz"), n=np.array(N), sumsq=ss, grad=g, lb=np.array(c["lb"], float),
+                            ub=np.array(c["ub"], float), src=np.array(c["src"], float), normalize=np.array(c["normalize"]),
+                            f_colnorm=np.linalg.norm(f, axis=0))
+        print(name, "32k: loss_f_uv", ss[:4].sum() / N, "loss_f_s", ss[4:].sum() / N)
+    base = os.path.join(REF, "PlateHoleQuarter", "train")
+    nets = {}
+    for key, fn in (("uv", "uvNN_float64.pickle"), ("dist", "distNN_float64.pickle"), ("part", "partNN_float64.pickle")):
+        W, b = load_pickle(os.path.join(base, fn))
+        nets[key] = (po.pack_params(W, b), [W[0].shape[0]] + [w.shape[1] for w in W])
+    X = gp.plate_points()
+    N = X.shape[0]
+    st = {k: pl.net_streams(nets[k][0], nets[k][1], X[:, 0], X[:, 1], X[:, 2]) for k in ("dist", "part")}
+    ss, g, f = pl.plate_loss_grad(nets["uv"][0], nets["uv"][1], X[:, 0], X[:, 1], X[:, 2], st["dist"], st["part"], term_weights=np.ones(5) / N)
+    H = gp.hole_points()
+    DH = pl.net_streams(nets["dist"][0], nets["dist"][1], H[:, 0], H[:, 1], H[:, 2])[0]
+    PH = pl.net_streams(nets["part"][0], nets["part"][1], H[:, 0], H[:, 1], H[:, 2])[0]
+    ssh, gh = pl.traction_loss_grad(nets["uv"][0], nets["uv"][1], H[:, 0], H[:, 1], H[:, 2], DH, PH, 0.1, weight=1.0 / H.shape[0])
+    np.savez_compressed(os.path.join(OUT, "golden_plate_32k.npz"), n=np.array(N), sumsq=ss, grad=g, hole_n=np.array(H.shape[0]), hole_sumsq=ssh,
+                        hole_grad=gh, f_colnorm=np.linalg.norm(f, axis=0))
+    print("plate 32k: loss_f_uv", ss[:2].sum() / N, "loss_f_s", ss[2:].sum() / N, "loss_HOLE", ssh.sum() / H.shape[0])
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) < 2 or sys.argv[1] == "wave":
         main()
     if len(sys.argv) < 2 or sys.argv[1] == "plate":
         plate()
+    if len(sys.argv) < 2 or sys.argv[1] == "large":
+        large()

@@ -39,6 +39,11 @@ class PinnLibError(RuntimeError):
     pass
 
 
+# The profiling hook of the library is process-wide and keeps a raw host pointer: the buffer it writes to is owned HERE, at module
+# level, for as long as the hook is on -- never by a PinnLib instance that may be collected while another engine still launches.
+_PROFILE_BUFFER = None
+
+
 class PinnLib:
     """Thin, checked wrapper over the shared library's entry points."""
 
@@ -88,6 +93,10 @@ class PinnLib:
         L.pinn_nc3d_fields.restype = i32
         L.pinn_adam_step.argtypes = [vp, vp, vp, vp, i64, f64, f64, f64, f64, i64, vp]
         L.pinn_adam_step.restype = i32
+        L.pinn_debug_set_profile_buffer.argtypes = [vp]
+        L.pinn_debug_set_profile_buffer.restype = None
+        L.pinn_debug_set_fused.argtypes = [i32]
+        L.pinn_debug_set_fused.restype = i32
 
     # -- helpers -------------------------------------------------------------------------------
     @staticmethod
@@ -118,14 +127,28 @@ class PinnLib:
     def set_profile_buffer(self, enable: bool):
         """Process-wide profiling hook: while on, every loss+gradient call writes its kernel milliseconds {repack, chain or whole
         fused kernel, weight gradient, reductions} into the returned float32[4] (and synchronises the stream)."""
-        import numpy as _np
+        global _PROFILE_BUFFER
         if enable:
-            self._prof = _np.zeros(4, dtype=_np.float32)
-            self.lib.pinn_debug_set_profile_buffer(C.c_void_p(self._prof.ctypes.data))
-            return self._prof
-        self.lib.pinn_debug_set_profile_buffer(None)
-        self._prof = None
+            if _PROFILE_BUFFER is None:
+                _PROFILE_BUFFER = (C.c_float * 4)()
+            self.lib.pinn_debug_set_profile_buffer(C.cast(_PROFILE_BUFFER, C.c_void_p))
+            import numpy as _np
+            return _np.ctypeslib.as_array(_PROFILE_BUFFER)
+        self.lib.pinn_debug_set_profile_buffer(None)      # (the module-level buffer stays allocated: a launch in flight may still write to it)
         return None
+
+    def profiling(self):
+        """Context manager around set_profile_buffer: the hook is always reset, whatever the body raises."""
+        lib = self
+
+        class _Ctx:
+            def __enter__(self_inner):
+                return lib.set_profile_buffer(True)
+
+            def __exit__(self_inner, *exc):
+                lib.set_profile_buffer(False)
+                return False
+        return _Ctx()
 
     def set_fused(self, enable: bool) -> bool:
         return bool(self.lib.pinn_debug_set_fused(int(bool(enable))))

@@ -336,8 +336,10 @@ class DeepHPM:
             return tuple(a[s:e] for a in self._collo_full)
         key = (lo, hi)
         if key not in self._collo_cache:
-            if len(self._collo_cache) >= 64:          # a new batching: drop the previous one's shards
-                self._collo_cache.clear()
+            # a block that overlaps cached ones belongs to another batching (getloss() asks for (0, N) after train() walked the
+            # blocks): drop what it overlaps first, so a rank never keeps more than its shard of the set on the device
+            for k in [k for k in self._collo_cache if k[0] < hi and lo < k[1]]:
+                del self._collo_cache[k]
             self._collo_cache[key] = tuple(torch.from_numpy(h[s:e]).to(self.device) for h in self._collo_host)
         return self._collo_cache[key]
 

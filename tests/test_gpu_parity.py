@@ -443,6 +443,40 @@ def test_residual_vector_and_layer_gradients_within_fp32_bounds(dev, golden_dir,
 
 
 @pytest.mark.parametrize("case", ["inf20s", "semi16s", "conf14s"])
+def test_trained_weight_gradient_over_many_workgroup_steps(dev, golden_dir, case):
+    """The 1024-point golden sets are 16-32 workgroup steps spread over as many workgroups: one step each.  Here: 32 768 seeded points
+    (oracle/golden_points.py; sums and gradient of the float64 oracle in golden_<case>_32k.npz) at the reference's TRAINED weights,
+    once through a workspace sized for 1024 points -- 16 or 32 workgroups that each walk 32 steps, so the persistent accumulators and
+    the in-memory running sums of the fused layouts carry a cancellation-prone gradient across many steps -- and once through the
+    default workspace.  Bars as in the test above: what a host fp32 evaluation of the same formulas achieves, per weight layer."""
+    from oracle import golden_points as gp
+    w = np.load(f"{golden_dir}/weights_{case}.npz")
+    g = np.load(f"{golden_dir}/golden_{case}_32k.npz")
+    layers = [int(v) for v in w["layers"]]
+    L = len(layers) - 1
+    flat = po.pack_params([w[f"W{i}"] for i in range(L)], [w[f"b{i}"] for i in range(L)])
+    lb, ub, norm, n = g["lb"], g["ub"], bool(g["normalize"]), int(g["n"])
+    X = gp.wave_points(lb, ub, tuple(g["src"]), n)
+    tw = np.ones(7) / n
+    ss64, grad64 = g["sumsq"], g["grad"]
+    ss32, grad32, _ = po.wave2d_loss_grad(flat.astype(np.float32), layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, norm, term_weights=tw, dtype=np.float32)
+    W32, b32 = po.unpack_params(grad32.astype(np.float64), layers)
+    W64, b64 = po.unpack_params(grad64, layers)
+    theta = to_dev(flat, dev)
+    xs = [to_dev(X[:, k], dev) for k in range(3)]
+    for max_points in (1024, n):
+        eng = engine(layers, "f16x3", dev, max_points)
+        ss, grad = eng.wave_loss_grad(theta, *xs, lb, ub, norm, tw)
+        ssd = ss.cpu().numpy().astype(np.float64)
+        for i in range(7):
+            assert abs(ssd[i] - ss64[i]) <= 4.0 * abs(float(ss32[i]) - ss64[i]) + 2e-5 * ss64[i], (max_points, i, ssd[i], ss64[i])
+        Wd, bd = po.unpack_params(grad.cpu().numpy().astype(np.float64), layers)
+        for l in range(L):
+            for d_, s_, r_ in ((Wd[l], W32[l], W64[l]), (bd[l], b32[l], b64[l])):
+                assert np.linalg.norm(d_ - r_) <= 6.0 * np.linalg.norm(s_ - r_) + 1e-6 * np.linalg.norm(r_), (max_points, l, np.linalg.norm(d_ - r_), np.linalg.norm(s_ - r_))
+
+
+@pytest.mark.parametrize("case", ["inf20s", "semi16s", "conf14s"])
 def test_fem_bands_on_device(dev, golden_dir, case):
     """The reference's only validation is PINN-vs-FEM scatter plots (INF:427-610).  On the committed sub-sample of its FEM frames the
     device's predict reproduces, frame by frame and field by field, the relative L2 distances the float64 oracle measured when the

@@ -139,3 +139,22 @@ def test_total_loss_layouts():
     lp, _ = po.wave_total_loss_grad(flat + eps * d, layers, sets, [0, 0, 0], [1, 1, 1], True, "semi_infinite")
     lm, _ = po.wave_total_loss_grad(flat - eps * d, layers, sets, [0, 0, 0], [1, 1, 1], True, "semi_infinite")
     assert abs((lp["loss"] - lm["loss"]) / (2 * eps) - g @ d) < 1e-6 * max(1.0, abs(g @ d))
+
+
+def test_large_golden_points_and_sums_reproduce(golden_dir):
+    """golden_<case>_32k.npz holds no points: oracle/golden_points.py regenerates them from a seed.  The float64 oracle on the
+    regenerated points reproduces the stored sums bit-for-bit-class (1e-12) and the stored gradient -- pins generator and seed."""
+    from oracle import golden_points as gp
+    w = np.load(f"{golden_dir}/weights_inf20s.npz")
+    g = np.load(f"{golden_dir}/golden_inf20s_32k.npz")
+    layers = [int(v) for v in w["layers"]]
+    L = len(layers) - 1
+    flat = po.pack_params([w[f"W{i}"] for i in range(L)], [w[f"b{i}"] for i in range(L)])
+    n = int(g["n"])
+    X = gp.wave_points(g["lb"], g["ub"], tuple(g["src"]), n)
+    m = 4096                                   # a prefix: the column norms of f over all points are stored as well
+    ss, grad, f = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], g["lb"], g["ub"], bool(g["normalize"]), term_weights=np.ones(7) / n)
+    assert np.allclose(ss, g["sumsq"], rtol=1e-12, atol=0)
+    assert np.linalg.norm(grad - g["grad"]) <= 1e-12 * np.linalg.norm(g["grad"])
+    assert np.allclose(np.linalg.norm(f, axis=0), g["f_colnorm"], rtol=1e-12)
+    assert f[:m].shape == (m, 7)
