@@ -30,11 +30,19 @@ extern "C" {
 /* precision_mode: operand type of the matrix pipe (accumulation is always fp32) */
 enum {
     PINN_PREC_BF16 = 0,   /* bf16 operands, one MFMA per product (BASELINE config "bf16-MFMA/fp32-accum") */
-    PINN_PREC_F16X3 = 1,  /* fp16 hi + scaled-lo split, three MFMAs per product: fp32-class accuracy */
+    PINN_PREC_F16X3 = 1,  /* fp16 hi + scaled-lo split, three MFMAs per product: fp32-class accuracy.  Limits of the class (DESIGN
+                             section 7): (1) the hi + lo weights carry ~23 significant bits -- their split error is 1.75x the fp32
+                             rounding of the same weights and, like it, the same for every point: where a residual is a > 1000-fold
+                             cancellation of O(1) outputs (the plate's hole traction at trained weights) the gradient error does
+                             not fall with the number of points as host fp32's does; (2) the weight gradient of padded widths <= 64
+                             takes the layer states as fp16 high parts: a rounding noise of 2^-12 / sqrt(points) relative to the
+                             gradient (2e-5 at 70 points, 1e-6 at 200 k) -- the wider layouts use both parts; (3) |w| < 2047 in the
+                             fused kernels' weight format (32 w must stay finite in fp16): larger weights give non-finite sums. */
     PINN_PREC_F16 = 2,    /* fp16 operands, one MFMA per product */
     PINN_PREC_BF16X3 = 3, /* bf16 hi/lo split, three MFMAs per product (16-bit significand) */
     PINN_PREC_FP32 = 4,   /* plain fp32 FMA arithmetic, no matrix pipe (the reference's own precision, INF:71-92): ~100x slower,
-                             for parity checks; pinn_wave2d_loss_grad, pinn_data_loss_grad(_multi), pinn_wave2d_fields only */
+                             for parity checks; offered by every entry point (wave, data, fields, the plate family with its second
+                             time derivative, the 4-input heads) */
     /* OR this into precision_mode when the PREVIOUS call on the same workspace used the same params_flat contents, layers and
      * mode: the packed MFMA weight fragments are still in the workspace and the repack launch is skipped (the reference feeds
      * one set of variables to every loss term of a step, INF:297-305; a step makes 3-4 calls). */

@@ -186,10 +186,10 @@ size_t pinn_min_workspace_bytes(const int* layers, int n_layers, int precision_m
     return impl ? impl->ws_bytes(net, 1L << 40, 1) : 0;
 }
 
-// PINN_PREC_FP32: plain fp32 arithmetic (pinn_fp32.hpp), the points walked in as many passes as the workspace holds
-static int fp32_call(const Call& c, int head, int nterms) {
+// PINN_PREC_FP32: plain fp32 arithmetic (pinn_fp32.hpp), the points walked in as many passes as the workspace holds.
+// ns = streams of the head (1: data / traction heads, 4: wave / fields, 5: plate family and the 4-input heads), din = inputs.
+static int fp32_call(const Call& c, int head, int nterms, int ns, int din = 3) {
     hipStream_t st = c.stream;
-    const int ns = head == HEAD_DATA ? 1 : 4;
     const size_t per_point = fp32_bytes_per_point(c.net, ns);
     if (((uintptr_t)c.ws & 255) != 0 || c.ws_bytes < per_point * 256) return PINN_ERR_WORKSPACE;
     long mmax = (long)(c.ws_bytes / per_point);
@@ -199,19 +199,30 @@ static int fp32_call(const Call& c, int head, int nterms) {
     a.params = c.params;
     a.x = c.x;
     a.y = c.y;
+    a.z = c.z;
     a.t = c.t;
     a.n = c.n;
-    for (int k = 0; k < 3; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
+    for (int k = 0; k < 4; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
     a.c1 = c.c1;
     a.c2 = c.c2;
     a.G = c.G;
     a.rho = c.rho;
-    for (int i = 0; i < 8; ++i) a.tw[i] = c.tw[i];
+    for (int i = 0; i < 16; ++i) a.tw[i] = c.tw[i];
+    // stream-wise data head: the loss sums are reported weight-normalised like the 16-bit kernels do (sum_s w[s][o] / max|w| d^2)
+    float wmax = 0.0f;
+    for (int i = 0; i < 5; ++i)
+        for (int o = 0; o < 8; ++o) { const float v = c.w5[i][o] < 0 ? -c.w5[i][o] : c.w5[i][o]; if (v > wmax) wmax = v; }
+    for (int i = 0; i < 5; ++i)
+        for (int o = 0; o < 8; ++o) { a.w5[i][o] = c.w5[i][o]; a.w5n[i][o] = wmax > 0.0f ? c.w5[i][o] / wmax : 0.0f; }
     a.targets = c.targets;
+    a.aux = c.aux;
     a.fields_out = c.fields_out;
     a.ns = ns;
     a.hr = c.net.h > 16 ? c.net.h : 16;
     a.head = head;
+    a.din = din;
+    a.second = (din == 3 && ns == 5) ? 1 : 0;
+    const bool forward_only = head == HEAD_FIELDS || head == HEAD_FIELDS3D;
     int pass = 0;
     for (long p0 = 0; p0 < c.n; p0 += mmax, ++pass) {
         a.p0 = p0;
@@ -223,7 +234,7 @@ static int fp32_call(const Call& c, int head, int nterms) {
         int blocks = (int)((a.m + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(fp32_chain_kernel, dim3(blocks), dim3(256), 0, st, a);
-        if (head != HEAD_FIELDS) {
+        if (!forward_only) {
             hipLaunchKernelGGL(fp32_sum_kernel, dim3(nterms), dim3(256), 0, st, (const float*)a.fsq, a.m, c.loss_out, pass > 0 ? 1 : 0);
             hipLaunchKernelGGL(fp32_wgrad_kernel, dim3((c.net.nparams + 255) / 256), dim3(256), 0, st, a, c.grad_out, (c.accumulate || pass > 0) ? 1 : 0);
         }
@@ -263,7 +274,7 @@ static int wave2d_loss_grad_impl(const float* params_flat, const int* layers, in
     c.accumulate = accumulate;
     if (prof_ms) c.prof_ms = prof_ms;
     if (n == 0) return empty_batch(c, 7);
-    if (!impl) return fp32_call(c, HEAD_WAVE, 7);
+    if (!impl) return fp32_call(c, HEAD_WAVE, 7, 4);
     return impl->wave_loss_grad(c);
 }
 
@@ -299,7 +310,7 @@ int pinn_data_loss_grad(const float* params_flat, const int* layers, int n_layer
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, c.net.nout);
-    if (!impl) return fp32_call(c, HEAD_DATA, c.net.nout);
+    if (!impl) return fp32_call(c, HEAD_DATA, c.net.nout, 1);
     return impl->data_loss_grad(c);
 }
 
@@ -354,7 +365,7 @@ int pinn_data_loss_grad_multi(const float* params_flat, const int* layers, int n
             for (int i = 0; i < 8; ++i) s1.tw[i] = c.sets[k].tw[i];
             s1.loss_out = sets[k].loss_terms_out;
             s1.accumulate = accumulate || !first_set;
-            if ((rc = fp32_call(s1, HEAD_DATA, c.net.nout))) return rc;
+            if ((rc = fp32_call(s1, HEAD_DATA, c.net.nout, 1))) return rc;
             first_set = false;
         }
         return PINN_OK;
@@ -372,7 +383,7 @@ int pinn_wave2d_fields(const float* params_flat, const int* layers, int n_layers
     if (n > 0 && !fields_out) return PINN_ERR_NULL;
     c.fields_out = fields_out;
     if (n == 0) return 0;
-    if (!impl) return fp32_call(c, HEAD_FIELDS, 0);
+    if (!impl) return fp32_call(c, HEAD_FIELDS, 0, 4);
     return impl->fields(c);
 }
 
@@ -386,7 +397,7 @@ int pinn_net_streams(const float* params_flat, const int* layers, int n_layers, 
     if (n > 0 && !streams_out) return PINN_ERR_NULL;
     c.fields_out = streams_out;
     if (n == 0) return 0;
-    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
+    if (!impl) return fp32_call(c, HEAD_FIELDS, 0, 5);
     return impl->streams(c);
 }
 
@@ -410,7 +421,7 @@ int pinn_plate2d_loss_grad(const float* params_flat, const int* layers, int n_la
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, 5);
-    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
+    if (!impl) return fp32_call(c, HEAD_PLATE, 5, 5);
     return impl->plate_loss_grad(c);
 }
 
@@ -432,7 +443,7 @@ int pinn_plate2d_traction_loss_grad(const float* params_flat, const int* layers,
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, 2);
-    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
+    if (!impl) return fp32_call(c, HEAD_TRACTION, 2, 1);
     return impl->traction_loss_grad(c);
 }
 
@@ -452,7 +463,7 @@ int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_lay
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, c.net.nout);
-    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
+    if (!impl) return fp32_call(c, HEAD_STREAMS, c.net.nout, 5);
     return impl->stream_loss_grad(c);
 }
 
@@ -477,7 +488,7 @@ int pinn_nc3d_loss_grad(const float* params_flat, const int* layers, int n_layer
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, 12);
-    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
+    if (!impl) return fp32_call(c, HEAD_NC3D, 12, 5, 4);
     return impl->nc3d_loss_grad(c);
 }
 
@@ -496,7 +507,7 @@ int pinn_nc3d_data_loss_grad(const float* params_flat, const int* layers, int n_
     c.grad_out = grad_flat_out;
     c.accumulate = accumulate;
     if (n == 0) return empty_batch(c, c.net.nout);
-    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
+    if (!impl) return fp32_call(c, HEAD_DATA3D, c.net.nout, 1, 4);
     return impl->nc3d_data_loss_grad(c);
 }
 
@@ -510,7 +521,7 @@ int pinn_nc3d_fields(const float* params_flat, const int* layers, int n_layers, 
     if (n > 0 && !fields_out) return PINN_ERR_NULL;
     c.fields_out = fields_out;
     if (n == 0) return 0;
-    if (!impl) return PINN_ERR_PRECISION;      // PINN_PREC_FP32 is offered for the wave / data / fields entry points only
+    if (!impl) return fp32_call(c, HEAD_FIELDS3D, 0, 5, 4);
     return impl->nc3d_fields(c);
 }
 

@@ -97,7 +97,7 @@ __device__ __forceinline__ void split2<OpF16>(float a, float b, uint32_t& hi, ui
 }
 #endif
 // (a, b) -> packed hi pair and packed UNSCALED low pair  lo = T(x - float(T(x))).  Used for the forward activations of the fused
-// kernel, whose weights carry the 2^11 scale instead (see repack_fused_kernel): measured in tools/precision_study3.py, an
+// kernel, whose weights carry the scale instead (FUSED_WEIGHT_SCALE = 2^5, see repack_kernel's fused format): measured in tools/precision_study3.py, an
 // unscaled (possibly subnormal) low part of the ACTIVATIONS costs nothing in accuracy, an unscaled low part of the weights does.
 template <class Op>
 __device__ __forceinline__ void split2u(float a, float b, uint32_t& hi, uint32_t& lo) {

@@ -135,8 +135,9 @@ struct Fused {
     // lane records rotated (imgoff): record block (stream, k-step) of the state's high parts (S), (stream, k-step, part) of the
     // adjoints' high and scaled low parts (Z).  A chain lane writes / reads its own records with 16-byte LDS accesses; the
     // weight-gradient waves rebuild transposed MFMA fragments from the same bytes with ds_read_b64_tr_b16.
-    // The parked state S is kept in the operand type's precision only (no low part): measured in tools/precision_study2.py,
-    // rounding S for the reverse pass changes the gradient error by < 10 % of itself as long as adjoints and weights stay split.
+    // The state images in LDS hold the operand type's precision only (no low part): that is enough for the WEIGHT GRADIENT's operand
+    // (a 2^-12 / sqrt(points) rounding noise), not for the chain wave's own activation reverse, which reads the low parts back from the
+    // scratch image (STATE_LO below: at trained weights cancellation amplifies a 2^-12 state rounding ~20x).
     static constexpr int TENSOR_Z_B = NS * KS * NP * 1024;
     // LDSOP keeps the state images with BOTH parts (records ((s * KS + kk) * NP + p), the operand layout): the chain wave's reverse
     // reads its state in full precision.  (At the reference's trained weights the activation reverse amplifies a 2^-12 rounding of

@@ -150,7 +150,7 @@ class DeepHPM:
 
     def __init__(self, Collo, SRC, IC, UP, uv_layers, lb, ub, ExistModel=0, modelDir='', *, case="infinite",
                  FIX=None, precision="f16x3", engine=None, seed=1111, process_group=None, verbose=True,
-                 E=2.5, mu=0.25, rho=1.0):
+                 E=2.5, mu=0.25, rho=1.0, always_reduce=False):
         self.count = 0                      # callback counter (INF:26)
         self._shift_state = {}              # adjoint-shift bookkeeping of evaluate_with_finite_gradient
         self.loss_rec = []                  # SEMI:39
@@ -170,6 +170,9 @@ class DeepHPM:
             self.world = torch.distributed.get_world_size(self.pg)
         else:
             self.rank, self.world = 0, 1
+        # ``always_reduce``: run the step's all-reduce even in a process group of one rank -- the collective branch (RCCL under the
+        # "nccl" backend) then executes on a single GPU exactly as it does on eight, which is how the tests prove that path here
+        self._reduce = self.world > 1 or (bool(always_reduce) and torch.distributed.is_available() and torch.distributed.is_initialized())
 
         # ---- engine (GPU kernels); tests may inject a stand-in with the same methods
         if engine is None:
@@ -353,7 +356,7 @@ class DeepHPM:
         all-reduces.  Returns nothing; everything stays on the device.  Single process only: ``sums_out`` (a view of
         8*len(_SLOTS) floats, zero where no set exists) receives the sums directly instead of the tail of the buffer."""
         P, lay, eng, buf = self.n_params, self.layout, self.engine, self._buf
-        if sums_out is None or self.world > 1:
+        if sums_out is None or self._reduce:
             sums = buf[P:]
             sums.zero_()                    # slots of skipped sets must read zero (getloss toggles the NB weight)
         else:
@@ -384,7 +387,9 @@ class DeepHPM:
             wrote = True
         if not wrote:
             grad.zero_()
-        if self.world > 1:
+        if self._reduce:
+            # one fused buffer [gradient | loss sums] (latency-bound message); enqueued behind the kernels in stream order, and Adam is
+            # enqueued behind it: the host never waits
             torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def _terms_from_sums(self, sums, n_blk):
@@ -431,7 +436,7 @@ class DeepHPM:
                 self._shift_state["probed"] = True
             for it in range(iter):
                 self._loss_and_grad(idx_start, idx_end, sums_out=rec[it])     # one launch less per step than copying afterwards
-                if self.world > 1:
+                if self._reduce:
                     rec[it].copy_(self._buf[P:])
                 self.adam_t += 1
                 self.engine.adam_step(self.theta, self.adam_m, self.adam_v, self._buf[:P], learning_rate, self.adam_t)

@@ -32,7 +32,8 @@ class NavierCauchy3D:
     uv_layers = [4] + depth * [width] + [12]."""
 
     def __init__(self, Collo, SRC, IC, TOP, uv_layers, lb, ub, ExistModel=0, modelDir='', *, precision="f16x3", engine=None, seed=1111,
-                 process_group=None, verbose=True, E=2.5, mu=0.25, rho=1.0, normalize=True, layout: Optional[dict] = None):
+                 process_group=None, verbose=True, E=2.5, mu=0.25, rho=1.0, normalize=True, layout: Optional[dict] = None,
+                 always_reduce=False):
         self.count = 0
         self._shift_state = {}
         self.loss_rec = []
@@ -51,6 +52,8 @@ class NavierCauchy3D:
             self.world = torch.distributed.get_world_size(self.pg)
         else:
             self.rank, self.world = 0, 1
+        # (always_reduce: the collective branch also at one rank -- see elastic_wave.DeepHPM)
+        self._reduce = self.world > 1 or (bool(always_reduce) and torch.distributed.is_available() and torch.distributed.is_initialized())
         if engine is None:
             from .hip_engine import HipEngine
             n_max = max(int(np.asarray(Collo).shape[0]) // self.world + 1, 1 << 14)
@@ -221,7 +224,7 @@ class NavierCauchy3D:
             wrote = True
         if not wrote:
             grad.zero_()
-        if self.world > 1:
+        if self._reduce:
             torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def _terms_from_sums(self, sums, n_blk):

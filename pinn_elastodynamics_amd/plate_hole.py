@@ -29,7 +29,8 @@ BFGS_OPTIONS = {   # PLATE:220-247
 
 class PINN:
     def __init__(self, Collo, HOLE, IC, LF, RT, UP, LW, DIST, uv_layers, dist_layers, part_layers, lb, ub,
-                 partDir='', distDir='', uvDir='', *, precision="f16x3", engines=None, seed=1111, process_group=None, verbose=True):
+                 partDir='', distDir='', uvDir='', *, precision="f16x3", engines=None, seed=1111, process_group=None, verbose=True,
+                 always_reduce=False):
         self.count = 0
         self._shift_state = {}
         self.lb = np.asarray(lb, dtype=np.float64).reshape(-1)
@@ -44,6 +45,8 @@ class PINN:
             self.rank, self.world = torch.distributed.get_rank(self.pg), torch.distributed.get_world_size(self.pg)
         else:
             self.rank, self.world = 0, 1
+        # (always_reduce: the collective branch also at one rank -- see elastic_wave.DeepHPM)
+        self._reduce = self.world > 1 or (bool(always_reduce) and torch.distributed.is_available() and torch.distributed.is_initialized())
 
         if engines is None:
             from .hip_engine import HipEngine
@@ -239,7 +242,7 @@ class PINN:
             wrote = True
         if not wrote:
             grad.zero_()
-        if self.world > 1:
+        if self._reduce:
             torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
 
     def _terms(self, sums):

@@ -481,3 +481,92 @@ def test_nc3d_argument_checks_emulated(emu):
     with pytest.raises(PinnLibError):        # unsplit modes have no 5-stream kernels
         emu.nc3d_loss_grad(p.ctypes.data, layers, *[z.ctypes.data] * 4, 16, [0] * 4, [1] * 4, True, 2.5, 0.25, 1.0, np.ones(12), z.ctypes.data,
                            p.ctypes.data, False, "bf16", ws.ctypes.data, ws.size)
+
+
+def test_fp32_mode_plate_and_nc3d_emulated(emu):
+    """PINN_PREC_FP32 for the plate family (five streams with the second time derivative, composite head, hole traction, stream-wise
+    data head, pinn_net_streams) and for the 4-input heads: every entry point against the float64 oracles, workspace passes of 256
+    points included."""
+    from oracle import nc3d_oracle as n3
+    from oracle import plate_oracle as pl
+    LBp, UBp = [0, 0, 0], [0.5, 0.5, 10]
+    rng = np.random.default_rng(3)
+
+    def mk(l):
+        W, b = po.xavier_init(l, rng)
+        return po.pack_params(W, [0.2 * rng.standard_normal(x.shape) for x in b])
+
+    lN, lD, n = [3] + 3 * [24] + [5], [3, 20, 20, 5], 300
+    fN, fD, fP = mk(lN), mk(lD), mk(lD)
+    C = np.stack([rng.random(n) * 0.5, rng.random(n) * 0.5, rng.random(n) * 10], 1)
+    x, y, t = (C[:, k].astype(np.float32).copy() for k in range(3))
+    wsb = emu.min_workspace_bytes(lN, "fp32")            # 256 points per pass: two passes
+    ws = aligned(wsb)
+    Dref, Pref = pl.net_streams(fD, lD, C[:, 0], C[:, 1], C[:, 2]), pl.net_streams(fP, lD, C[:, 0], C[:, 1], C[:, 2])
+    Nref = pl.net_streams(fN, lN, C[:, 0], C[:, 1], C[:, 2])
+    pN = fN.astype(np.float32)
+    out = np.full((5, 5, n), np.nan, np.float32)
+    emu.net_streams(pN.ctypes.data, lN, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, out.ctypes.data, "fp32", ws.ctypes.data, wsb)
+    for s in range(5):
+        assert rel(out[s], Nref[s]) < 5e-6, s
+    tw = np.array([10, 7, 13, 9, 11.0]) / n
+    ss, g, _ = pl.plate_loss_grad(fN, lN, C[:, 0], C[:, 1], C[:, 2], Dref, Pref, term_weights=tw)
+    frozen = np.ascontiguousarray(np.stack([Dref, Pref]).astype(np.float32))
+    loss, grad = np.full(8, np.nan, np.float32), np.full(pN.size, np.nan, np.float32)
+    emu.plate2d_loss_grad(pN.ctypes.data, lN, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, frozen.ctypes.data, 20.0, 0.25, 1.0,
+                          tw, loss.ctypes.data, grad.ctypes.data, False, "fp32", ws.ctypes.data, wsb)
+    assert rel(loss[:5], ss) < 5e-6 and rel(grad, g) < 5e-6, (rel(loss[:5], ss), rel(grad, g))
+    th = rng.random(n) * np.pi / 2
+    H = np.stack([0.1 * np.cos(th), 0.1 * np.sin(th), rng.random(n) * 10], 1)
+    hx, hy, ht = (H[:, k].astype(np.float32).copy() for k in range(3))
+    DH, PH = pl.net_streams(fD, lD, H[:, 0], H[:, 1], H[:, 2])[0], pl.net_streams(fP, lD, H[:, 0], H[:, 1], H[:, 2])[0]
+    ssh, gh = pl.traction_loss_grad(fN, lN, H[:, 0], H[:, 1], H[:, 2], DH, PH, weight=10.0 / n)
+    aux = np.ascontiguousarray(np.concatenate([DH, PH, (-H[:, 0] / 0.1)[None], (-H[:, 1] / 0.1)[None]]).astype(np.float32))
+    emu.plate2d_traction_loss_grad(pN.ctypes.data, lN, hx.ctypes.data, hy.ctypes.data, ht.ctypes.data, n, LBp, UBp, False, aux.ctypes.data,
+                                   [10.0 / n] * 2, loss.ctypes.data, grad.ctypes.data, True, "fp32", ws.ctypes.data, wsb)      # accumulates
+    assert rel(loss[:2], ssh) < 5e-6 and rel(grad, g + gh) < 5e-6
+    tg = rng.standard_normal((5, 5, n))
+    w = np.zeros((5, 5))
+    w[0, :] = 1000.0 / n
+    w[3, 0] = w[3, 1] = 500.0 / n
+    pD = fD.astype(np.float32)
+    s3, g3 = pl.stream_loss_grad(fD, lD, C[:, 0], C[:, 1], C[:, 2], tg, w)
+    tg32 = np.ascontiguousarray(tg.astype(np.float32))
+    gradD = np.full(pD.size, np.nan, np.float32)
+    wsd = emu.workspace_bytes(lD, n, "fp32")
+    wsD = aligned(wsd)
+    emu.stream_loss_grad(pD.ctypes.data, lD, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, tg32.ctypes.data, w, loss.ctypes.data,
+                         gradD.ctypes.data, False, "fp32", wsD.ctypes.data, wsd)
+    assert rel(loss[:5], ((w / w.max()) * s3).sum(0)) < 5e-6 and rel(gradD, g3) < 5e-6
+    # ---- 4-input heads
+    layers, m = [4] + 3 * [24] + [12], 270
+    lb, ub = [0.0, 0.0, -20.0, 0.0], [30.0, 30.0, 0.0, 15.0]
+    Ws, bs = po.xavier_init(layers, rng)
+    flat = po.pack_params(Ws, [0.3 * rng.standard_normal(b.shape) for b in bs])
+    X = n3.halfspace_points(m, lb, ub, rng)
+    tw3 = (0.5 + rng.random(12)) / m
+    ss3, g3d, _ = n3.nc3d_loss_grad(flat, layers, *X.T, lb, ub, True, term_weights=tw3)
+    p32 = flat.astype(np.float32)
+    cols = [X[:, k].astype(np.float32).copy() for k in range(4)]
+    ptr = [v.ctypes.data for v in cols]
+    wsb3 = emu.min_workspace_bytes(layers, "fp32")
+    assert wsb3 > 0
+    ws3 = aligned(wsb3)
+    loss3 = np.full(16, np.nan, np.float32)
+    grad3 = np.full(p32.size, np.nan, np.float32)
+    emu.nc3d_loss_grad(p32.ctypes.data, layers, *ptr, m, lb, ub, True, 2.5, 0.25, 1.0, tw3, loss3.ctypes.data, grad3.ctypes.data, False, "fp32",
+                       ws3.ctypes.data, wsb3)
+    assert rel(loss3[:12], ss3) < 5e-6 and rel(grad3, g3d) < 5e-6, (rel(loss3[:12], ss3), rel(grad3, g3d))
+    ref = n3.nc3d_fields(flat, layers, *X.T, lb, ub, True)
+    fo = np.full((5, 12, m), np.nan, np.float32)
+    emu.nc3d_fields(p32.ctypes.data, layers, *ptr, m, lb, ub, True, fo.ctypes.data, "fp32", ws3.ctypes.data, wsb3)
+    assert rel(fo[0].T, ref["Y"]) < 5e-6
+    for k in range(4):
+        assert rel(fo[1 + k].T, ref["dY"][k]) < 5e-6
+    tgt = rng.standard_normal((m, 12))
+    ow = np.array([1, 1, 1, 0.5, 0.5, 0.5, 0, 0, 2, 0, 2, 2.0]) / m
+    ss_d, g_d, _ = n3.nc3d_data_loss_grad(flat, layers, *X.T, lb, ub, True, tgt, ow)
+    tgT = np.ascontiguousarray(tgt.T.astype(np.float32))
+    emu.nc3d_data_loss_grad(p32.ctypes.data, layers, *ptr, m, lb, ub, True, tgT.ctypes.data, ow, loss3.ctypes.data, grad3.ctypes.data, False, "fp32",
+                            ws3.ctypes.data, wsb3)
+    assert rel(loss3[:12], ss_d) < 5e-6 and rel(grad3, g_d) < 5e-6

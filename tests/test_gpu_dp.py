@@ -40,3 +40,38 @@ def test_two_ranks_on_one_gpu_match_a_single_process(tmp_path):
     assert np.linalg.norm(z["theta0"] - one) < 1e-5 * np.linalg.norm(one)
     np.testing.assert_allclose(z["loss"], np.array(losses[4]), rtol=1e-4)
     assert int(z["rows"][0]) == 15000                                                 # rank 0 holds its half of the rows only
+
+
+@pytest.mark.gpu
+def test_rccl_collective_branch_on_one_gpu(tmp_path):
+    """RCCL itself: ``init_process_group("nccl", world_size=1)`` and the model's step all-reduce forced on (``always_reduce=True``): the
+    library loads, the collective runs on the HIP-written buffer in stream order with Adam behind it, and the trajectory is bit-identical
+    to the run without the collective (a sum over one rank is the identity)."""
+    out = str(tmp_path / "rccl.npz")
+    env = dict(os.environ, PYTHONPATH=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_rccl_worker.py"), out], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = np.load(out)
+    assert np.array_equal(z["theta_plain"], z["theta_rccl"])
+    assert np.array_equal(z["loss_plain"], z["loss_rccl"]) and np.all(np.isfinite(z["loss_rccl"]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", ["plate", "nc3d"])
+def test_two_ranks_on_one_gpu_plate_and_nc3d(tmp_path, model):
+    """The 2-process run with the real HipEngine (both ranks on cuda:0, gloo) for the plate class (Adam steps, then an L-BFGS stage with its
+    per-evaluation all-reduce) and the 3-D class: ranks bit-identical, and the same numbers as one process to 1e-5."""
+    import torch
+    out = str(tmp_path / f"dp_{model}.npz")
+    port = "29534" if model == "plate" else "29535"
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", port, os.path.join(ROOT, "tests", "_dp_worker_gpu2.py"), model, out], env=env, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = np.load(out)
+    from tests._dp_worker_gpu2 import run_model
+    theta, loss = run_model(model, torch.device("cuda:0"))
+    assert np.array_equal(z["theta0"], z["theta1"])
+    assert np.linalg.norm(z["theta0"] - theta) < 1e-5 * np.linalg.norm(theta)
+    np.testing.assert_allclose(z["loss"], loss, rtol=1e-4)

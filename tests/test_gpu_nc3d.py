@@ -129,3 +129,35 @@ def test_nc3d_model_trains_on_device(dev):
     assert np.isfinite(hist[4]).all() and l1 < 0.7 * l0, (l0, l1)
     out = m.predict(*[c["Collo"][:100, k:k + 1] for k in range(4)])
     assert len(out) == 15 and all(np.isfinite(o).all() for o in out)
+
+
+def test_nc3d_fp32_device_leg(dev):
+    """BASELINE configs[4] says "fp32": PINN_PREC_FP32 runs the 4-input heads in plain fp32 arithmetic on the device (round 3).  On a
+    10 x 128 net: the fp32 run and the f16x3 product mode against the float64 oracle (build-side definition, parity unpinned), sums and
+    gradient, and the f16x3 gradient within a small factor of the fp32 run's own error per weight layer."""
+    from oracle import nc3d_oracle as n3
+    from pinn_elastodynamics_amd.hip_engine import HipEngine
+    layers = [4] + 10 * [128] + [12]
+    lb, ub = [0.0, 0.0, -20.0, 0.0], [30.0, 30.0, 0.0, 15.0]
+    rng = np.random.default_rng(9)
+    Ws, bs = po.xavier_init(layers, rng)
+    flat = po.pack_params(Ws, [0.2 * rng.standard_normal(b.shape) for b in bs])
+    n = 1500
+    X = n3.halfspace_points(n, lb, ub, rng)
+    tw = np.ones(12) / n
+    ss, g, _ = n3.nc3d_loss_grad(flat, layers, *X.T, lb, ub, True, term_weights=tw)
+    theta = torch.from_numpy(flat.astype(np.float32)).to(dev)
+    cols = [torch.from_numpy(np.ascontiguousarray(X[:, k], dtype=np.float32)).to(dev) for k in range(4)]
+    out = {}
+    for prec in ("fp32", "f16x3"):
+        eng = HipEngine(layers, precision=prec, device=dev, max_points=n)
+        l_, g_ = eng.nc3d_loss_grad(theta, *cols, lb, ub, True, tw)
+        out[prec] = (l_.cpu().numpy().astype(np.float64), g_.cpu().numpy().astype(np.float64))
+        assert np.linalg.norm(out[prec][0][:12] - ss) < 2e-5 * np.linalg.norm(ss), prec
+        assert np.linalg.norm(out[prec][1] - g) < 2e-5 * np.linalg.norm(g), prec
+    W32, b32 = po.unpack_params(out["fp32"][1], layers)
+    W16, b16 = po.unpack_params(out["f16x3"][1], layers)
+    W64, b64 = po.unpack_params(g, layers)
+    for l in range(len(layers) - 1):
+        for a16, a32, r in ((W16[l], W32[l], W64[l]), (b16[l], b32[l], b64[l])):
+            assert np.linalg.norm(a16 - r) <= 12.0 * np.linalg.norm(a32 - r) + 2e-6 * np.linalg.norm(r), l

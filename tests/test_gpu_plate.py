@@ -252,6 +252,49 @@ def test_plate_trained_weight_gradient_over_many_workgroup_steps(dev, golden_dir
     _layer_blocks_within(gh.cpu().numpy(), gh32, g["hole_grad"], lay["uv"], 25.0, 2e-6, "traction")
 
 
+def test_plate_three_legs_oracle_fp32_device_f16x3(dev, golden_dir):
+    """Third leg for the plate (round 3: PINN_PREC_FP32 now carries the second time derivative and the plate heads): at the reference's
+    TRAINED plate nets the fp32 device run agrees with the float64 oracle as well as fp32 can (five streams 2e-5, gradient to the
+    cancellation-limited accuracy), and the f16x3 product mode stays within a small factor of the fp32 device run's own error, per
+    weight layer, for the main head (PLATE:404-439) and the hole traction (PLATE:452-461)."""
+    from pinn_elastodynamics_amd.hip_engine import HipEngine
+    g = np.load(f"{golden_dir}/golden_plate.npz")
+    flat, lay, eng = _plate_nets(golden_dir, dev, 1024)
+    e32 = HipEngine(lay["uv"], precision="fp32", device=dev, max_points=1024)
+    X, H = g["X"], g["H"]
+    n = X.shape[0]
+    x, y, t = (to_dev(X[:, k], dev) for k in range(3))
+    theta = to_dev(flat["uv"], dev)
+    ref = g["N_streams"].astype(np.float64)
+    S32 = e32.net_streams(theta, x, y, t, LB, UB, False).cpu().numpy()
+    S16 = eng["uv"].net_streams(theta, x, y, t, LB, UB, False).cpu().numpy()
+    for s in range(5):
+        assert rel(S32[s], ref[s]) < 2e-5 and rel(S16[s], ref[s]) < 2e-5, s
+    tw = np.ones(5) / n
+    frozen = torch.stack([to_dev(g["D_streams"], dev), to_dev(g["P_streams"], dev)]).contiguous()
+    grad64 = g["grad"].astype(np.float64)
+    l32, g32 = (v.cpu().numpy().astype(np.float64) for v in e32.plate_loss_grad(theta, x, y, t, LB, UB, False, frozen, tw))
+    l16, g16 = (v.cpu().numpy().astype(np.float64) for v in eng["uv"].plate_loss_grad(theta, x, y, t, LB, UB, False, frozen, tw))
+    assert rel(l32, g["sumsq"]) < 2e-3 and rel(l16, g["sumsq"]) < 2e-3
+    hx, hy, ht = (to_dev(H[:, k], dev) for k in range(3))
+    D0 = pl.net_streams(flat["dist"], lay["dist"], H[:, 0], H[:, 1], H[:, 2])[0]
+    P0 = pl.net_streams(flat["part"], lay["part"], H[:, 0], H[:, 1], H[:, 2])[0]
+    aux = torch.cat([to_dev(D0, dev), to_dev(P0, dev), (-hx / 0.1)[None], (-hy / 0.1)[None]]).contiguous()
+    wgt = [1.0 / H.shape[0]] * 2
+    _, h32 = (v.cpu().numpy().astype(np.float64) for v in e32.traction_loss_grad(theta, hx, hy, ht, LB, UB, False, aux, wgt))
+    _, h16 = (v.cpu().numpy().astype(np.float64) for v in eng["uv"].traction_loss_grad(theta, hx, hy, ht, LB, UB, False, aux, wgt))
+    L = len(lay["uv"]) - 1
+    for tag, d16_, d32_, r_ in (("main", g16, g32, grad64), ("traction", h16, h32, g["hole_grad"].astype(np.float64))):
+        W16, b16 = po.unpack_params(d16_, lay["uv"])
+        W32, b32 = po.unpack_params(d32_, lay["uv"])
+        W64, b64 = po.unpack_params(r_, lay["uv"])
+        for l in range(L):
+            for a16, a32, r in ((W16[l], W32[l], W64[l]), (b16[l], b32[l], b64[l])):
+                e_32, e_16 = np.linalg.norm(a32 - r), np.linalg.norm(a16 - r)
+                assert e_32 <= 5e-2 * np.linalg.norm(r), (tag, l, e_32)
+                assert e_16 <= 12.0 * e_32 + 2e-6 * np.linalg.norm(r), (tag, l, e_16, e_32)
+
+
 def test_plate_model_on_device(dev, golden_dir, tmp_path):
     """PINN mirror end to end on the GPU: pre-training stages lower their losses, main-stage loss matches the oracle's
     evaluation of the same parameters, predict() follows the FEM fixture with the reference's trained nets."""
