@@ -34,6 +34,12 @@ def test_bench_line(cfg, extra):
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     if cfg in ("wave", "plate"):        # the fused kernel's own launch time, measured with HIP events in this run
         assert r["avg_launch_ms"] > 0 and r["avg_launch_ms"] <= d["ms_per_step"] * 1.05
+    # at least one second of timed work whatever --steps is: the K-step block is repeated, the median block is reported
+    tb = d["timed_blocks"]
+    assert tb["steps_per_block"] == 4 and tb["count"] >= 1 and tb["count"] * tb["block_ms_median"] >= 900.0 or tb["count"] == 64
+    assert tb["block_ms_min"] <= tb["block_ms_median"] <= tb["block_ms_max"] and abs(tb["block_ms_median"] / 4 - d["ms_per_step"]) < 1e-6
+    if cfg == "plate":
+        assert d["config"]["collocation_points_global"] == 120000          # exactly the requested number of collocation points
 
 
 def test_bench_two_ranks_strong_scaling_gloo():
