@@ -151,6 +151,31 @@ def plate():
     print("  FEM rel-L2 per frame u:", np.round(rel[0], 3), "v:", np.round(rel[1], 3), "s11:", np.round(rel[2], 3))
 
 
+def trained64():
+    """golden_wave64.npz / golden_wave64_32k.npz: the float64 oracle at the TRAINED 8x64 net of tools/make_trained64.py (this framework's
+    own training run on the MI355X, log in profiles/r03_trained64_train_log.txt, moved off the optimiser's own optimum by a seeded 1e-4 relative
+    perturbation -- NOT reference data: none of the reference's nets is 64 wide).
+    Same contents as the reference-weight fixtures; purpose: a cancellation-regime test point for the width-64 fused kernels."""
+    w = np.load(os.path.join(OUT, "weights_wave64.npz"))
+    layers = [int(v) for v in w["layers"]]
+    L = len(layers) - 1
+    flat = po.pack_params([w[f"W{i}"] for i in range(L)], [w[f"b{i}"] for i in range(L)])
+    lb, ub, src = np.array([0.0, 0.0, 0.0]), np.array([30.0, 30.0, 10.0]), (15.0, 15.0, 2.0)
+    X = gp.wave_points(lb, ub, src, 1024, seed=55551)
+    N = X.shape[0]
+    out = po.wave2d_fields(flat, layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, True)
+    ss, g, f = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, True, term_weights=np.ones(7) / N)
+    np.savez_compressed(os.path.join(OUT, "golden_wave64.npz"), X=X, lb=lb, ub=ub, normalize=np.array(True), Y=out["Y"], dY=np.stack(out["dY"]),
+                        f=f, sumsq=ss, grad=g.astype(np.float32), case=np.array("infinite"))
+    print("wave64", layers, "loss_f_uv", ss[:4].sum() / N, "loss_f_s", ss[4:].sum() / N)
+    X = gp.wave_points(lb, ub, src)
+    N = X.shape[0]
+    ss, g, f = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, True, term_weights=np.ones(7) / N)
+    np.savez_compressed(os.path.join(OUT, "golden_wave64_32k.npz"), n=np.array(N), sumsq=ss, grad=g, lb=lb, ub=ub, src=np.array(src),
+                        normalize=np.array(True), f_colnorm=np.linalg.norm(f, axis=0))
+    print("wave64 32k: loss_f_uv", ss[:4].sum() / N, "loss_f_s", ss[4:].sum() / N)
+
+
 def large():
     """golden_<case>_32k.npz: float64 oracle sums and gradient on oracle/golden_points.py's 32 768 seeded points at the reference's trained
     weights (the 1024-point sets above stay what they are: they also carry fields, Jacobians and the residual vectors)."""
@@ -194,3 +219,5 @@ if __name__ == "__main__":
         plate()
     if len(sys.argv) < 2 or sys.argv[1] == "large":
         large()
+    if len(sys.argv) < 2 or sys.argv[1] == "trained64":
+        trained64()

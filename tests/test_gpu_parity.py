@@ -66,9 +66,11 @@ def test_wave_loss_grad_xavier(dev, prec, depth, width, n):
 
 
 @pytest.mark.parametrize("case,tol_fields,tol_grad", [("inf20s", 1e-4, 2e-2), ("semi16s", 1e-4, 5e-2), ("conf14s", 1e-4, 5e-2),
-                                                      ("inf10s", 1e-4, 2e-2)])
+                                                      ("inf10s", 1e-4, 2e-2), ("wave64", 1e-4, 2e-2)])
 def test_reference_weights_golden(dev, golden_dir, case, tol_fields, tol_grad):
-    """The reference's trained nets (widths 80/100/140) on the committed golden vectors."""
+    """The reference's trained nets (widths 80/100/140) on the committed golden vectors -- and "wave64", the TRAINED 8x64 net of
+    tools/make_trained64.py (this framework's own training run, residual losses 1e-5 like the reference's nets): the only trained
+    weights that run through the width-64 fused kernels of BASELINE configs[1] (golden vectors = the float64 oracle at those weights)."""
     w = np.load(f"{golden_dir}/weights_{case}.npz")
     g = np.load(f"{golden_dir}/golden_{case}.npz")
     layers = [int(v) for v in w["layers"]]
@@ -405,7 +407,7 @@ def test_adjoint_shift_keeps_the_gradient_and_rescues_overflow(dev):
 
 
 # ---- parity that cancellation cannot excuse: everything measured against what an fp32 evaluation of the same formulas achieves ----
-@pytest.mark.parametrize("case", ["inf20s", "inf10s", "semi16s", "conf14s"])
+@pytest.mark.parametrize("case", ["inf20s", "inf10s", "semi16s", "conf14s", "wave64"])
 def test_residual_vector_and_layer_gradients_within_fp32_bounds(dev, golden_dir, case):
     """At the reference's TRAINED weights the residuals are ~1e-3 differences of O(1) numbers, so relative errors of sums / gradients look
     large for ANY finite precision.  The fair bar is what the reference's own arithmetic (fp32, INF:71-92) achieves: the float64 oracle
@@ -442,7 +444,7 @@ def test_residual_vector_and_layer_gradients_within_fp32_bounds(dev, golden_dir,
             assert np.linalg.norm(d_ - r_) <= 6.0 * np.linalg.norm(s_ - r_) + 1e-6 * np.linalg.norm(r_), (l, np.linalg.norm(d_ - r_), np.linalg.norm(s_ - r_))
 
 
-@pytest.mark.parametrize("case", ["inf20s", "semi16s", "conf14s"])
+@pytest.mark.parametrize("case", ["inf20s", "semi16s", "conf14s", "wave64"])
 def test_trained_weight_gradient_over_many_workgroup_steps(dev, golden_dir, case):
     """The 1024-point golden sets are 16-32 workgroup steps spread over as many workgroups: one step each.  Here: 32 768 seeded points
     (oracle/golden_points.py; sums and gradient of the float64 oracle in golden_<case>_32k.npz) at the reference's TRAINED weights,
@@ -504,7 +506,7 @@ def test_fem_bands_on_device(dev, golden_dir, case):
             assert abs(r - ref[j, i]) <= 2e-3 * max(1.0, ref[j, i]), (q, i, r, ref[j, i])
 
 
-@pytest.mark.parametrize("case", ["inf20s", "conf14s"])
+@pytest.mark.parametrize("case", ["inf20s", "conf14s", "wave64"])
 def test_three_legs_oracle_fp32_device_f16x3(dev, golden_dir, case):
     """Third leg on the device: PINN_PREC_FP32 runs the same entry points in plain fp32 arithmetic (what the reference's TF1 graph
     computes in, INF:71-92).  At the reference's TRAINED weights: (1) the fp32 device run agrees with the float64 oracle as well as

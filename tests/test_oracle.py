@@ -9,6 +9,7 @@ from oracle import pinn_oracle as po
 from oracle.tf1_shaped import MinimalWave, TF1ShapedWave
 
 CASES = ["inf20s", "inf10s", "semi16s", "conf14s"]
+GOLDEN_CASES = CASES + ["wave64"]      # + the trained 8x64 net of tools/make_trained64.py (not reference data)
 
 
 def load_case(golden_dir, case):
@@ -51,7 +52,7 @@ def test_raw_input_variant_matches_too():
     assert np.linalg.norm(gt.numpy() - g) <= 1e-12 * np.linalg.norm(g)
 
 
-@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("case", GOLDEN_CASES)
 def test_golden_vectors_reproduce(golden_dir, case):
     layers, Ws, bs, g = load_case(golden_dir, case)
     X = g["X"]
