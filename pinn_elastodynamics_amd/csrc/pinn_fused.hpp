@@ -48,11 +48,12 @@ struct FusedArgs {
     const float* x;
     const float* y;
     const float* t;
+    const float* z;            // 4-input instantiations only (input order x, y, z, t)
     long n;
     long nsteps;               // workgroup steps = ceil(n / (16 * TILES))
-    float sx[3], ox[3];
+    float sx[4], ox[4];        // input map; 4 inputs: index 2 = z, 3 = t
     float c1, c2, G, rho;
-    float tw[8];
+    float tw[16];
     const float* targets;      // NS = 1 only: [nout][n] or nullptr (= 0)   (single-set form; the set table below supersedes it)
     const float* aux;          // NS = 5 (plate head): the frozen nets' streams [2 nets (D,P)][5 streams][5 fields][n]
     // NS = 1: up to FUSED_MAX_SETS value-only point sets in ONE launch (loss_IC, loss_SRC, loss_NB, loss_FIX of a step): set k owns
@@ -97,15 +98,20 @@ __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int sl
 // sum_o w_o (Y_o - target_o)^2 -- the side sets loss_IC / loss_SRC / loss_NB / loss_FIX (INF:111-118, CONF:145-146).
 // FASTSTATE (PINN_FLAG_STATE_FP16): the parked states keep their fp16 high parts only -- 17 % faster for the 8x64 net, at the price of
 // a 2^-12 state rounding that cancellation amplifies at trained weights (see STATE_LO below).  Not the default.
-template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4, bool FASTSTATE = false>
+// DIN_ = 4 (round 3): the 3-D Navier-Cauchy extension of BASELINE configs[4] -- inputs (x, y, z, t), five FIRST-order streams (value, x, y, z,
+// t), 12 outputs and the 3-D residual head (oracle/nc3d_oracle.py); built for the LDS-operand layout of padded width 128.
+template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4, bool FASTSTATE = false, int DIN_ = 3>
 struct Fused {
-    static constexpr int NS = NS_, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1;
-    static_assert(NS == 4 || NS == 1 || NS == 5, "wave residual head (4 streams), value-only data head (1 stream) or plate head (5 streams)");
-    // NS = 5: streams (value, x, y, t, tt) -- the fifth carries the second time derivative (PLATE:417-419) -- and the plate head:
+    static constexpr int NS = NS_, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1, DIN = DIN_;
+    static_assert(NS == 4 || NS == 1 || NS == 5, "wave residual head (4 streams), value-only data head (1 stream) or plate / 3-D head (5 streams)");
+    static_assert(DIN == 3 || (DIN == 4 && NS == 5), "4 inputs: the five-stream 3-D head only");
+    // NS = 5, 3 inputs: streams (value, x, y, t, tt) -- the fifth carries the second time derivative (PLATE:417-419) -- and the plate head:
     // composite F = P + D*N with the frozen nets' streams, plane-stress residuals (PLATE:358-439)
-    static constexpr bool SECOND = NS == 5;
-    static constexpr int NT = NS >= 4 ? 3 : 0;                 // first-order tangent streams 1..NT
-    static constexpr int HEAD = NS == 4 ? HEAD_WAVE : (NS == 1 ? HEAD_DATA : HEAD_PLATE);
+    static constexpr bool SECOND = NS == 5 && DIN == 3;
+    static constexpr int NT = NS >= 4 ? (SECOND ? 3 : NS - 1) : 0;                 // first-order tangent streams 1..NT (stream s differentiates by input s - 1)
+    static constexpr int HEAD = DIN == 4 ? HEAD_NC3D : (NS == 4 ? HEAD_WAVE : (NS == 1 ? HEAD_DATA : HEAD_PLATE));
+    static constexpr int NOG = DIN == 4 ? 16 : 8;              // outputs a lane gathers for the head
+    static constexpr int LT = DIN == 4 ? LOSS_SLOTS_3D : 8;    // loss partial slots per tile and set
     // weight fragments in the fused format of repack_kernel: [T(V), T(V - T(V)), T(T(V)/LO_SCALE)] with V = FUSED_WEIGHT_SCALE * w
     // when split, [T(w)] otherwise.  Every accumulator of this kernel holds WS * (W . x).
     static constexpr int P3 = NP == 2 ? 3 : 1;
@@ -124,7 +130,9 @@ struct Fused {
     // -- in the hand-off window of layer L itself -- and that window waits for it.
     // Padded width 128 (the reference's semi-infinite net, 8 x 100: SEMI:679) with four streams: images of 32 KB, the same budget.
     static constexpr bool ONE_SLOT = LDSOP && (NS_ == 5 || WB == 8);
-    static_assert(!(NS_ == 5 && WB == 8), "five streams at padded width 128: 40 KB images, no room for two tiles");
+    // (Five streams at padded width 128 -- the 3-D net of BASELINE configs[4]: 40 KB images, two tiles fill the 160 KB exactly and the
+    // net constants come from memory.)
+    static_assert(!(NS_ == 5 && WB == 8) || DIN_ == 4, "five streams at padded width 128: the 3-D instantiation only");
     static constexpr int TILES = LDSOP ? 2 : 4;               // 16-point tiles per workgroup step (one per chain wave)
     static constexpr int NJ = TILES / 2;                      // 32-point k-steps of the weight gradient per workgroup step
     static constexpr int IBW = WB / 2, OBW = WB / 2;          // weight-gradient wave (i,o) owns IBW x OBW blocks of every mid Wbar
@@ -795,11 +803,11 @@ struct Fused {
         }
         if constexpr (LDSOP) {
             // wave quad: first / last blocks quad and quad + 4; mid layers: in-blocks wide_block(wi, i) x out-blocks wide_block(wo, o)
-            put_block(A.first, 0, 0, quad, 3, H);
+            put_block(A.first, 0, 0, quad, DIN, H);
             put_block(A.last, NL, quad, 0, H, NO);
             if (q == 0 && 16 * quad + c < H) part[a.net.b_off[0] + 16 * quad + c] = A.bias[0];
             if (quad + 4 < WB) {
-                put_block(A.first2, 0, 0, quad + 4, 3, H);
+                put_block(A.first2, 0, 0, quad + 4, DIN, H);
                 put_block(A.last2, NL, quad + 4, 0, H, NO);
                 if (q == 0 && 16 * (quad + 4) + c < H) part[a.net.b_off[0] + 16 * (quad + 4) + c] = A.bias0b;
             }
@@ -829,7 +837,7 @@ struct Fused {
             return;
         }
         if (quad < WB) {
-            put_block(A.first, 0, 0, quad, 3, H);
+            put_block(A.first, 0, 0, quad, DIN, H);
             put_block(A.last, NL, quad, 0, H, NO);
             if (q == 0 && 16 * quad + c < H) part[a.net.b_off[0] + 16 * quad + c] = A.bias[0];
         }
@@ -871,7 +879,7 @@ struct Fused {
             frags = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.frags, 0, (int)a.frags_bytes, 0x00020000);
             if constexpr (!CONST_LDS) {
                 bias = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.bias_mid, 0, (NL - 1) * WIDTH * 4, 0x00020000);
-                w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * 16, 0x00020000);
+                w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * (DIN == 4 ? 32 : 16), 0x00020000);
                 blast = a.pw.bias_last;
             }
             lane16 = (unsigned)lane * 16u;
@@ -1046,7 +1054,7 @@ struct Fused {
 
     // forward first layer (K = 3, VALU): INF:191-195 with the tangent seeds e_k * sx_k
     template <int MB>
-    static __device__ __forceinline__ void first_mb(const FusedArgs& a, const Ctx& x, const float (&xin)[3], u32x4 (&Bn)[NS][1][KS][NP]) {
+    static __device__ __forceinline__ void first_mb(const FusedArgs& a, const Ctx& x, const float (&xin)[4], u32x4 (&Bn)[NS][1][KS][NP]) {
         float vals[NS][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1251,7 +1259,7 @@ struct Fused {
     }
 
     // S_0: the inputs as a 16-feature state (rows 0..2 = x', tangent stream k carries sx_k in row k) -> image slot 0
-    static __device__ __forceinline__ void put_input_state(const FusedArgs& a, const Ctx& x, const float (&xin)[3]) {
+    static __device__ __forceinline__ void put_input_state(const FusedArgs& a, const Ctx& x, const float (&xin)[4]) {
         float v0[NS][1][4];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
@@ -1260,8 +1268,8 @@ struct Fused {
                 // rows 0..2: hi parts; rows 4..6 (lanes q == 1): the 2^11-scaled low parts of the same numbers, so that the
                 // first layer's weight gradient keeps full input precision (combined at write-out)
                 float v = 0.0f;
-                if (x.q < 2 && r < 3) {
-                    const float full = (s == 0) ? xin[r] : (r == s - 1 ? in_loop(a.sx[r]) : 0.0f);
+                if (x.q < 2 && r < DIN) {
+                    const float full = (s == 0) ? xin[r] : ((s <= NT && r == s - 1) ? in_loop(a.sx[r]) : 0.0f);
                     v = x.q == 0 ? full : (full - round16<Op>(full)) * Op::LO_SCALE;
                 }
                 v0[s][0][r] = v;
@@ -1279,7 +1287,7 @@ struct Fused {
     template <int L>
     struct Down {
         // entry: Zc = Z_L (adjoint of weight layer L's pre-activation) in chain fragment order; S_L is (being) DMA'd into its slot
-        static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&Zc)[NS][1][KS][NP]) {
+        static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const float (&xin)[4], const u32x4 (&Zc)[NS][1][KS][NP]) {
             u32x4 Aa[KS][RP], Ab[KS][RP];
             u32x2 sla[NS], slb[NS];
             constexpr bool RECOMP = RECOMP1 && L == 1;
@@ -1317,7 +1325,7 @@ struct Fused {
     // ---- the forward in pieces ----
     // first layer + pipeline prologue: all fragments of layer 1 are requested BEFORE the first layer's vector work (they take a full
     // L2 round trip), then block 0's MFMAs
-    static __device__ __forceinline__ void fwd_first(const FusedArgs& a, const Ctx& x, const float (&xin)[3], u32x4 (&B)[NS][1][KS][NP], u32x4 (&A)[WB][KS][FP],
+    static __device__ __forceinline__ void fwd_first(const FusedArgs& a, const Ctx& x, const float (&xin)[4], u32x4 (&B)[NS][1][KS][NP], u32x4 (&A)[WB][KS][FP],
                                                      f32x4 (&acca)[NS], f32x4 (&bb)[WB]) {
 #pragma unroll
         for (int mb = 0; mb < WB; ++mb) load_afrags<KS, FP>(x, FI::fwd_mid(1, mb, 0), A[mb]);
@@ -1451,14 +1459,29 @@ struct Fused {
         if (kept_in_lds(l + 1)) half_store(x.imgS(l + 1), h, out);       // S_{NL-1} also into its reverse slot (KEEP_W)
     }
     template <int J>
-    static __device__ __forceinline__ void wide_first(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, u32x4 (&Bn)[NS][1][2][NP]) {
+    static __device__ __forceinline__ void wide_first(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, u32x4 (&Bn)[NS][1][2][NP]) {
         const int mb = half_block(h, J);
         float vals[NS][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(x.cw0 + (16 * mb + r) * 16);
+            // first-layer row of feature 16 mb + 4 q + r: (W0[0..DIN-1][f], b0[f]); from the LDS constants or, where the tensors fill the
+            // LDS (five streams at padded width 128), from memory
+            float w[5];
+            if constexpr (DIN == 4) {
+                const f32x4 wa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x.w0p, (unsigned)x.q * 128u, (16 * mb + r) * 32, 0));
+                const f32x4 wb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x.w0p, (unsigned)x.q * 128u, (16 * mb + r) * 32 + 16, 0));
+                w[0] = wa[0]; w[1] = wa[1]; w[2] = wa[2]; w[3] = wa[3]; w[4] = wb[0];
+            } else {
+                f32x4 wa;
+                if constexpr (CONST_LDS) wa = *reinterpret_cast<const f32x4*>(x.cw0 + (16 * mb + r) * 16);
+                else wa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x.w0p, (unsigned)x.q * 64u, (16 * mb + r) * 16, 0));
+                w[0] = wa[0]; w[1] = wa[1]; w[2] = wa[2]; w[3] = 0.0f; w[4] = wa[3];
+            }
+            float z0 = w[4];
+#pragma unroll
+            for (int k = 0; k < DIN; ++k) z0 += w[k] * xin[k];
             float hh, sd;
-            tanh_act(w[3] + w[0] * xin[0] + w[1] * xin[1] + w[2] * xin[2], hh, sd);
+            tanh_act(z0, hh, sd);
             vals[0][r] = hh;
 #pragma unroll
             for (int s = 1; s <= NT; ++s) vals[s][r] = sd * (a.sx[s - 1] * w[s - 1]);
@@ -1469,8 +1492,7 @@ struct Fused {
     }
     // forward of one tile (this wave's half): returns the output layer's products (acca, both halves compute them) for fwd_head; S_NL
     // ends in the second buffer.  One LDS barrier behind every layer: the halves exchange their blocks through the image.
-    static __device__ __forceinline__ void wide_forward(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, f32x4 (&acca)[NS]) {
-        static_assert(!LDSOP || CONST_LDS, "the LDS-operand layout reads the first layer's rows from the LDS constants");
+    static __device__ __forceinline__ void wide_forward(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, f32x4 (&acca)[NS]) {
         char* opa = x.tenZ + x.imgoff;                       // Z area
         char* opb = x.tenZ + TENSOR_Z_B + x.imgoff;          // S slot 0 = slot_of(NL): S_NL ends where the reverse expects it
         u32x4 Af[RING][1][FP];
@@ -1542,7 +1564,7 @@ struct Fused {
         if constexpr (J + 1 < HB) wide_bwd_epilogue<J + 1>(acc, simg, h, Zn, c, q);
     }
     // reverse of one tile; on entry the first barrier of the top layer has NOT been passed, S_NL (hi + lo) sits in S slot 0
-    static __device__ __forceinline__ void wide_reverse(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, const u32x4 (&ZL)[NS][1][1][NP]) {
+    static __device__ __forceinline__ void wide_reverse(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, const u32x4 (&ZL)[NS][1][1][NP]) {
         u32x4 Zn[NS][1][2][NP];
         u32x4 Ar[RINGB][1][RP];
         u32x4 At[HB][1][RP];
@@ -1572,7 +1594,7 @@ struct Fused {
     }
     // entry: Zc = this half's blocks of Z_L in registers, first barrier of layer L not yet passed
     template <int L>
-    static __device__ __forceinline__ void wide_down(const FusedArgs& a, const Ctx& x, const float (&xin)[3], int h, const u32x4 (&Zc)[NS][1][2][NP],
+    static __device__ __forceinline__ void wide_down(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, const u32x4 (&Zc)[NS][1][2][NP],
                                                      u32x4 (&Ar)[RINGB][1][RP]) {
         lds_barrier();                                          // A(L): the weight-gradient waves are done with Z_{L+1}, S_{L+1}
         fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
@@ -1604,7 +1626,7 @@ struct Fused {
 
     // forward + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
     // parks S_1..S_{NL-1} (scratch image or LDS slots), returns S_NL (fragments) and the head's adjoint Z_NL, adds the loss sums
-    static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], bool valid, long pidx, int set, float (&lsum)[8],
+    static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[4], bool valid, long pidx, int set, float (&lsum)[LT],
                                                         u32x4 (&B)[NS][1][KS][NP], u32x4 (&ZL)[NS][1][1][NP]) {
         u32x4 A[WB][KS][FP];
         f32x4 acca[NS], accb[NS], bb[WB];
@@ -1630,28 +1652,99 @@ struct Fused {
     }
 
     // output layer's products (acca) -> outputs, residual head, loss sums, adjoint seeds Z_NL
-    static __device__ __forceinline__ void fwd_head(const FusedArgs& a, const Ctx& x, bool valid, long pidx, int set, float (&lsum)[8], const f32x4 (&acca)[NS],
+    static __device__ __forceinline__ void fwd_head(const FusedArgs& a, const Ctx& x, bool valid, long pidx, int set, float (&lsum)[LT], const f32x4 (&acca)[NS],
                                                     u32x4 (&ZL)[NS][1][1][NP]) {
         const int c = x.c, q = x.q;
         fused_stamp(a, x.tracer, 1);
         // acca = WS * (Y of the 16 padded outputs, bias included): lane holds outputs 4q+r of its point
-        float Y[NS][8];
+        float Y[NS][NOG];
+        if constexpr (NOG == 16) {
+            // all 16 outputs of the point, from the four lanes (c, 0..3)
 #pragma unroll
-        for (int s = 0; s < NS; ++s)
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float own = acca[s][r] * INV_WS;
-                const float oth = __shfl_xor(own, 16);
-                Y[s][r] = (q & 1) ? oth : own;
-                Y[s][4 + r] = (q & 1) ? own : oth;
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const float own = acca[s][r] * INV_WS;
+                    const float o1 = __shfl_xor(own, 16), o2 = __shfl_xor(own, 32), o3 = __shfl_xor(own, 48);
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) Y[s][4 * qq + r] = q == qq ? own : ((q ^ 1) == qq ? o1 : ((q ^ 2) == qq ? o2 : o3));
+                }
+        } else {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float own = acca[s][r] * INV_WS;
+                    const float oth = __shfl_xor(own, 16);
+                    Y[s][r] = (q & 1) ? oth : own;
+                    Y[s][4 + r] = (q & 1) ? own : oth;
+                }
+        }
         const float vm = valid ? 1.0f : 0.0f;
-        float adj[NS][8];
+        float adj[NS][NOG];
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int o = 0; o < 8; ++o) adj[s][o] = 0.0f;
-        if constexpr (HEAD == HEAD_PLATE) {
+            for (int o = 0; o < NOG; ++o) adj[s][o] = 0.0f;
+        if constexpr (HEAD == HEAD_NC3D) {
+            // 3-D Navier-Cauchy residuals (oracle/nc3d_oracle.py: the 3-D statement of INF:221-265); outputs (u,v,w, ut,vt,wt, s11,s22,s33,
+            // s12,s13,s23); streams (value, d/dx, d/dy, d/dz, d/dt); c1 = lambda + 2G, c2 = lambda
+            const float(&V)[NOG] = Y[0];
+            const float(&X)[NOG] = Y[1];
+            const float(&Yy)[NOG] = Y[2];
+            const float(&Zz)[NOG] = Y[3];
+            const float(&T)[NOG] = Y[4];
+            const float e11 = X[0], e22 = Yy[1], e33 = Zz[2];
+            const float e12 = Yy[0] + X[1], e13 = Zz[0] + X[2], e23 = Zz[1] + Yy[2];
+            float f[12];
+            f[0] = X[6] + Yy[9] + Zz[10] - a.rho * T[3];
+            f[1] = X[9] + Yy[7] + Zz[11] - a.rho * T[4];
+            f[2] = X[10] + Yy[11] + Zz[8] - a.rho * T[5];
+            f[3] = T[0] - V[3];
+            f[4] = T[1] - V[4];
+            f[5] = T[2] - V[5];
+            f[6] = V[6] - (a.c1 * e11 + a.c2 * (e22 + e33));
+            f[7] = V[7] - (a.c1 * e22 + a.c2 * (e11 + e33));
+            f[8] = V[8] - (a.c1 * e33 + a.c2 * (e11 + e22));
+            f[9] = V[9] - a.G * e12;
+            f[10] = V[10] - a.G * e13;
+            f[11] = V[11] - a.G * e23;
+            float g[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) {
+                if (q == 0) lsum[i] += vm * f[i] * f[i];
+                g[i] = 2.0f * in_loop(a.tw[i]) * f[i] * vm;
+            }
+            adj[0][3] = -g[3];
+            adj[0][4] = -g[4];
+            adj[0][5] = -g[5];
+#pragma unroll
+            for (int i = 6; i < 12; ++i) adj[0][i] = g[i];
+            adj[1][0] = -(a.c1 * g[6] + a.c2 * (g[7] + g[8]));
+            adj[1][1] = -a.G * g[9];
+            adj[1][2] = -a.G * g[10];
+            adj[1][6] = g[0];
+            adj[1][9] = g[1];
+            adj[1][10] = g[2];
+            adj[2][0] = -a.G * g[9];
+            adj[2][1] = -(a.c1 * g[7] + a.c2 * (g[6] + g[8]));
+            adj[2][2] = -a.G * g[11];
+            adj[2][9] = g[0];
+            adj[2][7] = g[1];
+            adj[2][11] = g[2];
+            adj[3][0] = -a.G * g[10];
+            adj[3][1] = -a.G * g[11];
+            adj[3][2] = -(a.c1 * g[8] + a.c2 * (g[6] + g[7]));
+            adj[3][10] = g[0];
+            adj[3][11] = g[1];
+            adj[3][8] = g[2];
+            adj[4][0] = g[3];
+            adj[4][1] = g[4];
+            adj[4][2] = g[5];
+            adj[4][3] = -a.rho * g[0];
+            adj[4][4] = -a.rho * g[1];
+            adj[4][5] = -a.rho * g[2];
+        } else if constexpr (HEAD == HEAD_PLATE) {
             // composite F = P + D*N (PLATE:383-387) with product-rule derivatives, then net_f_sig PLATE:404-439
             // outputs (u,v,s11,s22,s12); streams (value, x, y, t, tt); aux = [D|P][stream][field][n]
             float D[5][5], F[5][5];
@@ -1756,7 +1849,10 @@ struct Fused {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) vals[s][0][r] = q < 2 ? ((q & 1) ? adj[s][4 + r] : adj[s][r]) : 0.0f;
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (NOG == 16) vals[s][0][r] = q == 0 ? adj[s][r] : (q == 1 ? adj[s][4 + r] : (q == 2 ? adj[s][8 + r] : adj[s][12 + r]));
+                else vals[s][0][r] = q < 2 ? ((q & 1) ? adj[s][4 + r] : adj[s][r]) : 0.0f;
+            }
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -1765,7 +1861,7 @@ struct Fused {
     }
 
     // reverse of one tile through all weight layers, in step with the weight-gradient waves; B holds S_NL
-    static __device__ __forceinline__ void reverse_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[3], const u32x4 (&B)[NS][1][KS][NP],
+    static __device__ __forceinline__ void reverse_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[4], const u32x4 (&B)[NS][1][KS][NP],
                                                         const u32x4 (&ZL)[NS][1][1][NP]) {
         // ---- top weight layer NL: hand Z_NL (16 outputs) and S_NL over, then reverse into the hidden chain
         fused_stamp(a, x.tracer, 2);
@@ -1799,13 +1895,19 @@ struct Fused {
     }
 
     static __device__ __forceinline__ void load_inputs(const FusedArgs& a, const float* px, const float* py, const float* pt, long n, long tile, int c,
-                                                       float (&xin)[3], bool& valid, long& pidx) {
+                                                       float (&xin)[4], bool& valid, long& pidx) {
         const long p = tile * 16 + c;
         valid = p < n;
         pidx = valid ? p : n - 1;
         xin[0] = px[pidx] * a.sx[0] + a.ox[0];
         xin[1] = py[pidx] * a.sx[1] + a.ox[1];
-        xin[2] = pt[pidx] * a.sx[2] + a.ox[2];
+        if constexpr (DIN == 4) {
+            xin[2] = a.z[pidx] * a.sx[2] + a.ox[2];
+            xin[3] = pt[pidx] * a.sx[3] + a.ox[3];
+        } else {
+            xin[2] = pt[pidx] * a.sx[2] + a.ox[2];
+            xin[3] = 0.0f;
+        }
     }
 
     static __device__ __forceinline__ void chain_role(const FusedArgs& a, char* lds, int wave4, int lane, int c, int q) {
@@ -1817,14 +1919,14 @@ struct Fused {
         x.set_tile(a, gwave);
         x.tracer = blockIdx.x == 0 && wave4 == 0 && lane == 0;
         constexpr int NSETS = NS == 1 ? FUSED_MAX_SETS : 1;
-        float lsum[NSETS][8];
+        float lsum[NSETS][LT];
 #pragma unroll
         for (int k = 0; k < NSETS; ++k)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) lsum[k][i] = 0.0f;
+            for (int i = 0; i < LT; ++i) lsum[k][i] = 0.0f;
 
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
-            float xin[3];
+            float xin[4];
             bool valid;
             long pidx;
             int set = 0;
@@ -1850,36 +1952,36 @@ struct Fused {
                 // show and that happened not to bite with two tiles.
                 __syncthreads();
                 wide_forward(a, x, xin, half, acca);
-                float ls[8];
+                float ls[LT];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ls[i] = 0.0f;
+                for (int i = 0; i < LT; ++i) ls[i] = 0.0f;
                 fwd_head(a, x, valid, pidx, set, ls, acca, ZL);          // both halves: the same Z_NL; the loss sums count once
 #pragma unroll
-                for (int i = 0; i < 8; ++i) lsum[0][i] += half == 0 ? ls[i] : 0.0f;
+                for (int i = 0; i < LT; ++i) lsum[0][i] += half == 0 ? ls[i] : 0.0f;
                 wide_reverse(a, x, xin, half, ZL);
             } else {
                 u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
-                float ls[8];
+                float ls[LT];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) ls[i] = 0.0f;
+                for (int i = 0; i < LT; ++i) ls[i] = 0.0f;
                 forward_tile(a, x, xin, valid, pidx, set, ls, B, ZL);
 #pragma unroll
                 for (int k = 0; k < NSETS; ++k)
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) lsum[k][i] += (k == set) ? ls[i] : 0.0f;
+                    for (int i = 0; i < LT; ++i) lsum[k][i] += (k == set) ? ls[i] : 0.0f;
                 reverse_tile(a, x, xin, B, ZL);
             }
         }
 #pragma unroll
         for (int k = 0; k < NSETS; ++k)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < LT; ++i) {
                 float v = lsum[k][i];
                 v += __shfl_xor(v, 1);
                 v += __shfl_xor(v, 2);
                 v += __shfl_xor(v, 4);
                 v += __shfl_xor(v, 8);
-                if (lane == 0 && half == 0) a.loss_part[(gwave * NSETS + k) * 8 + i] = v;
+                if (lane == 0 && half == 0) a.loss_part[(gwave * NSETS + k) * LT + i] = v;
             }
     }
 
@@ -1907,9 +2009,9 @@ struct Fused {
     }
 };
 
-template <class Op, int SPLIT, int WIDTH, int NL, int NS, bool FASTSTATE>
+template <class Op, int SPLIT, int WIDTH, int NL, int NS, bool FASTSTATE, int DIN = 3>
 __global__ __launch_bounds__(512) void fused_wave_kernel(const FusedArgs a) {
-    Fused<Op, SPLIT, WIDTH, NL, NS, FASTSTATE>::run(a);
+    Fused<Op, SPLIT, WIDTH, NL, NS, FASTSTATE, DIN>::run(a);
 }
 
 }  // namespace pinn

@@ -94,7 +94,7 @@ struct Host {
     static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
     static constexpr int FUSED_GRID = 256;    // persistent workgroups of the fused kernel (one per MI355X CU)
     static constexpr int FUSED_MAX_WIDTH = 128;     // widest padded net the fused kernel takes (4 streams; 96 also 5 streams, 32 / 64 also 1 stream)
-    static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? 32 * 1024 : (WIDTH <= 96 ? 72 * 1024 : 128 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
+    static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? 32 * 1024 : (WIDTH <= 96 ? 72 * 1024 : 160 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
     template <int NS>
     static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5)) || (WIDTH <= FUSED_MAX_WIDTH && NS == 4))); }
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
@@ -325,10 +325,12 @@ struct Host {
         return 1;
     }
 
-    template <int NL, int NS, bool FS = false>
+    // the 3-D instantiation (4 inputs, five first-order streams, 10 x 128: BASELINE configs[4]) exists for the split-precision width-128 family
+    static constexpr bool fused_has_3d() { return SPLIT == 3 && WIDTH == 128; }
+    template <int NL, int NS, bool FS = false, int DIN = 3>
     static int fused_launch(const Call& c, const Plan& p, int grid, int nterms, long nsteps) {
-        if constexpr (fused_has<NS>()) {
-            typedef Fused<Op, SPLIT, WIDTH, NL, NS, FS> F;
+        if constexpr (DIN == 4 ? fused_has_3d() : fused_has<NS>()) {
+            typedef Fused<Op, SPLIT, WIDTH, NL, NS, FS, DIN> F;
             int rc = repack(c, p);
             if (rc) return rc;
             char* b = static_cast<char*>(c.ws);
@@ -340,9 +342,10 @@ struct Host {
             a.x = c.x;
             a.y = c.y;
             a.t = c.t;
+            a.z = c.z;
             a.n = c.n;
             a.nsteps = nsteps;
-            for (int k = 0; k < 3; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
+            for (int k = 0; k < 4; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
             a.c1 = c.c1;
             a.c2 = c.c2;
             a.G = c.G;
@@ -372,11 +375,11 @@ struct Host {
                 }
                 a.set_step0[4] = s0;
                 a.nsets = nsets;
-                for (int i = 0; i < 8; ++i) a.tw[i] = 0.0f;
+                for (int i = 0; i < 16; ++i) a.tw[i] = 0.0f;
             } else {
-                for (int i = 0; i < 8; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
+                for (int i = 0; i < 16; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
                 twmax *= (float)(1u << c.adj_shift);
-                for (int i = 0; i < 8; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
+                for (int i = 0; i < 16; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
                 a.nsets = 1;
                 lo.p[0] = c.loss_out;
             }
@@ -389,7 +392,7 @@ struct Host {
             EventPair evp(c.prof_ms != nullptr);
             hipEvent_t (&ev)[2] = evp.ev;
             if (c.prof_ms) hipEventRecord(ev[0], c.stream);
-            hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL, NS, FS>), dim3(grid), dim3(512), 0, c.stream, a);
+            hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL, NS, FS, DIN>), dim3(grid), dim3(512), 0, c.stream, a);
             if ((rc = (int)hipGetLastError())) return rc;
             if (c.prof_ms) {
                 hipEventRecord(ev[1], c.stream);
@@ -399,6 +402,14 @@ struct Host {
             }
             // loss partials are [wave][set][8] with set = FUSED_MAX_SETS slots for NS = 1 and one slot for NS = 4
             constexpr int SLOTS = NS == 1 ? FUSED_MAX_SETS : 1;
+            if constexpr (DIN == 4) {
+                // 12 terms in LOSS_SLOTS_3D slots per tile: the gradient blocks of the fused reduction, then the loss reduction of the two-kernel path
+                hipLaunchKernelGGL((reduce_grad_loss_kernel<0>), dim3((c.net.nparams + 63) / 64), dim3(256), 0, c.stream, (const float*)a.partial,
+                                   grid, c.net.nparams, twmax, c.grad_out, c.accumulate, (const float*)a.loss_part, (long)grid * F::TILES, 0, 0, SLOTS, lo);
+                hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * F::TILES, nterms,
+                                   c.loss_out, 0, LOSS_SLOTS_3D);
+                return (int)hipGetLastError();
+            }
             hipLaunchKernelGGL((reduce_grad_loss_kernel<0>), dim3((c.net.nparams + 63) / 64 + nsets), dim3(256), 0, c.stream, (const float*)a.partial,
                                grid, c.net.nparams, twmax, c.grad_out, c.accumulate, (const float*)a.loss_part, (long)grid * F::TILES, nterms, nsets,
                                SLOTS, lo);
@@ -436,6 +447,28 @@ struct Host {
             if constexpr (WIDTH > 64) *out = fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
             else if (c.fast_state && SPLIT == 3 && NS == 4 && c.net.nl == 8) *out = fused_launch<8, NS, true>(c, p, (int)grid, nterms, nsteps);   // the collocation kernel of the 8-layer nets
             else *out = c.net.nl == 4 ? fused_launch<4, NS>(c, p, (int)grid, nterms, nsteps) : fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
+            return 1;
+        } else {
+            return 0;
+        }
+    }
+
+    // the 3-D head through the fused LDS-operand kernel: 10 hidden layers of padded width 128 (BASELINE configs[4])
+    static int try_fused_3d(const Call& c, int* out) {
+        if constexpr (fused_has_3d()) {
+            if (c.net.nl != 10 || c.net.din != 4 || c.net.nout != 12) return 0;
+            Plan p;
+            if (((uintptr_t)c.ws & 255) != 0) return 0;
+            plan_fixed<4>(c.net, c.n, p);
+            typedef Fused<Op, SPLIT, WIDTH, 10, 5, false, 4> F;
+            const size_t per_wg = (size_t)F::TILES * F::SCRATCH_BYTES;
+            if (c.ws_bytes < p.fixed_end + per_wg) return 0;
+            long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
+            if (grid > FUSED_GRID) grid = FUSED_GRID;
+            const long nsteps = (c.n + 16 * F::TILES - 1) / (16 * F::TILES);
+            if (nsteps == 0) return 0;
+            if (grid > nsteps) grid = nsteps;
+            *out = fused_launch<10, 5, false, 4>(c, p, (int)grid, 12, nsteps);
             return 1;
         } else {
             return 0;
@@ -512,7 +545,11 @@ struct Host {
     }
     // 4-input family (two-kernel path; the fused kernel covers the reference's 3-input nets only)
     static int nc3d_loss_grad(const Call& c) {
-        if constexpr (SPLIT == 3) return loss_grad<5, HEAD_NC3D>(c, 12);
+        if constexpr (SPLIT == 3) {
+            int rc = 0;
+            if (c.use_fused && try_fused_3d(c, &rc)) return rc;
+            return loss_grad<5, HEAD_NC3D>(c, 12);
+        }
         return PINN_ERR_PRECISION;
     }
     static int nc3d_data_loss_grad(const Call& c) {

@@ -570,3 +570,35 @@ def test_fp32_mode_plate_and_nc3d_emulated(emu):
     emu.nc3d_data_loss_grad(p32.ctypes.data, layers, *ptr, m, lb, ub, True, tgT.ctypes.data, ow, loss3.ctypes.data, grad3.ctypes.data, False, "fp32",
                             ws3.ctypes.data, wsb3)
     assert rel(loss3[:12], ss_d) < 5e-6 and rel(grad3, g_d) < 5e-6
+
+
+def test_fused_nc3d_emulated(emu):
+    """BASELINE configs[4] net shape (10 hidden layers, padded width 128, inputs (x, y, z, t), 12 outputs) through the five-stream
+    LDS-operand instantiation of the fused kernel (round 3: 40 KB images, two tiles fill the LDS, net constants from memory, 16-output
+    head) against the float64 oracle and against the two-kernel path; several workgroup steps and a ragged point count."""
+    from oracle import nc3d_oracle as n3
+    layers = [4] + 10 * [100] + [12]
+    lb, ub = [0.0, 0.0, -20.0, 0.0], [30.0, 30.0, 0.0, 15.0]
+    rng = np.random.default_rng(31)
+    Ws, bs = po.xavier_init(layers, rng)
+    flat = po.pack_params(Ws, [0.2 * rng.standard_normal(b.shape) for b in bs])
+    p32 = flat.astype(np.float32)
+    for n, min_ws in ((45, False), (150, True)):
+        X = n3.halfspace_points(n, lb, ub, rng)
+        tw = (0.5 + rng.random(12)) / n
+        ss, g, _ = n3.nc3d_loss_grad(flat, layers, *X.T, lb, ub, True, term_weights=tw)
+        cols = [X[:, k].astype(np.float32).copy() for k in range(4)]
+        ptr = [v.ctypes.data for v in cols]
+        wsb = emu.min_workspace_bytes(layers, "f16x3") if min_ws else emu.workspace_bytes(layers, n, "f16x3")
+        ws = aligned(wsb)
+        res = {}
+        for fused in (True, False):
+            emu.set_fused(fused)
+            loss = np.full(16, np.nan, np.float32)
+            grad = np.full(p32.size, np.nan, np.float32)
+            emu.nc3d_loss_grad(p32.ctypes.data, layers, *ptr, n, lb, ub, True, 2.5, 0.25, 1.0, tw, loss.ctypes.data, grad.ctypes.data, False,
+                               "f16x3", ws.ctypes.data, wsb)
+            res[fused] = (loss[:12].copy(), grad.copy())
+            assert rel(loss[:12], ss) < 2e-6 and rel(grad, g) < 5e-6, (fused, n, rel(loss[:12], ss), rel(grad, g))
+        emu.set_fused(True)
+        assert rel(res[True][1], res[False][1].astype(np.float64)) < 5e-6

@@ -161,3 +161,34 @@ def test_nc3d_fp32_device_leg(dev):
     for l in range(len(layers) - 1):
         for a16, a32, r in ((W16[l], W32[l], W64[l]), (b16[l], b32[l], b64[l])):
             assert np.linalg.norm(a16 - r) <= 12.0 * np.linalg.norm(a32 - r) + 2e-6 * np.linalg.norm(r), l
+
+
+def test_fused_nc3d_kernel_against_oracle_and_two_kernel_path(dev):
+    """Round 3: the 10 x 128 3-D net runs through the five-stream LDS-operand instantiation of the fused kernel (pinn_fused.hpp, DIN = 4).
+    The library's profiling hook tells which path ran (the fused kernel reports no separate weight-gradient time); both paths against the
+    float64 oracle (2e-5) and against each other (1e-5), on a point count that is not a multiple of the 32-point workgroup step, through
+    the default workspace and through one that leaves the fused kernel a few workgroups with many steps each."""
+    from pinn_elastodynamics_amd.hip_engine import HipEngine
+    flat, rng = net(LAYERS, 17)
+    n = 5000 + 13
+    X = n3.halfspace_points(n, LB, UB, rng)
+    tw = (0.5 + rng.random(12)) / n
+    ss, g, _ = n3.nc3d_loss_grad(flat, LAYERS, *X.T, LB, UB, True, term_weights=tw)
+    theta = to_dev(flat, dev)
+    cols = [to_dev(X[:, k], dev) for k in range(4)]
+    grads = {}
+    for max_points in (n, 512):
+        eng = HipEngine(LAYERS, precision="f16x3", device=dev, max_points=max_points)
+        for fused in (True, False):
+            eng.lib.set_fused(fused)
+            try:
+                with eng.lib.profiling() as prof:
+                    l_, g_ = eng.nc3d_loss_grad(theta, *cols, LB, UB, True, tw)
+                    torch.cuda.synchronize()
+                    ran_fused = float(prof[2]) == 0.0 and float(prof[1]) > 0.0
+            finally:
+                eng.lib.set_fused(True)
+            assert ran_fused == fused, (max_points, fused, list(prof))
+            assert rel(l_.cpu().numpy()[:12], ss) < 2e-5 and rel(g_.cpu().numpy(), g) < 2e-5, (max_points, fused)
+            grads[(max_points, fused)] = g_.cpu().numpy().astype(np.float64)
+    assert rel(grads[(n, True)], grads[(n, False)]) < 1e-5 and rel(grads[(512, True)], grads[(n, True)]) < 1e-5
