@@ -124,12 +124,15 @@ struct Fused {
     // at a time (one ds_read_b128 per stream and part); every layer is "all output blocks accumulate, then the vector part block by
     // block".  The images are 24 KB (hi + lo) per tensor and tile: two tiles per workgroup.
     static constexpr bool LDSOP = WB > 4;
-    static_assert(!LDSOP || ((NS_ == 4 || NS_ == 5) && NP == 2), "the LDS-operand layout is built for the 4- / 5-stream split-precision cases");
+    static_assert(!LDSOP || NP == 2, "the LDS-operand layout is built for the split-precision cases");
+    // One stream at these widths (the value-only side sets loss_IC / loss_SRC / loss_NB / loss_FIX of the reference's 8 x 80 / 8 x 100 nets,
+    // round 3): images of 6 / 8 KB, so ALL layer states S_0..S_NL of both tiles stay in LDS (NL + 1 slots) -- nothing is parked, no LDS-DMA.
+    static constexpr bool WSLDS = LDSOP && NS_ == 1;
     // Five streams at padded width 96 (the reference's plate net, 8 x 70: PLATE:885-887): images of 30 KB, and two tiles have room for
     // ONE state slot each beside the Z area (2 x 60 KB).  The LDS-DMA of S_L can then only start when the readers of S_{L+1} are done
     // -- in the hand-off window of layer L itself -- and that window waits for it.
     // Padded width 128 (the reference's semi-infinite net, 8 x 100: SEMI:679) with four streams: images of 32 KB, the same budget.
-    static constexpr bool ONE_SLOT = LDSOP && (NS_ == 5 || WB == 8);
+    static constexpr bool ONE_SLOT = LDSOP && !WSLDS && (NS_ == 5 || WB == 8);
     // (Five streams at padded width 128 -- the 3-D net of BASELINE configs[4]: 40 KB images, two tiles fill the 160 KB exactly and the
     // net constants come from memory.)
     static_assert(!(NS_ == 5 && WB == 8) || DIN_ == 4, "five streams at padded width 128: the 3-D instantiation only");
@@ -162,10 +165,11 @@ struct Fused {
     // trace, 1.6 k cycles for the first block step of a forward layer against 0.8 k for the others.
     static constexpr int CONST_BIAS_F = (NL - 1) * WIDTH + 16, CONST_F = CONST_BIAS_F + WIDTH * 4, CONST_B = CONST_F * 4;
     // (Five streams at width 64 fill the 160 KB with tensors alone: that instantiation reads the constants from memory.)
-    static constexpr bool CONST_LDS = TILES * (TENSOR_Z_B + (ONE_SLOT ? 1 : 2) * IMG_B) + CONST_B <= 160 * 1024;
+    static constexpr int BASE_SLOTS = WSLDS ? NL + 1 : (ONE_SLOT ? 1 : 2);
+    static constexpr bool CONST_LDS = TILES * (TENSOR_Z_B + BASE_SLOTS * IMG_B) + CONST_B <= 160 * 1024;
     static constexpr int CONST_USED = CONST_LDS ? CONST_B : 0;
     static constexpr bool SLDS = !LDSOP && 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) + CONST_USED <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
-    static constexpr int S_SLOTS = SLDS ? NL + 1 : (ONE_SLOT ? 1 : 2);
+    static constexpr int S_SLOTS = SLDS ? NL + 1 : BASE_SLOTS;
     static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * IMG_B;
     static constexpr int CONST_OFF = TILES * WAVE_B;
     static constexpr int LDS_B = CONST_OFF + CONST_USED;
@@ -177,7 +181,7 @@ struct Fused {
     static constexpr bool STATE_LO = !LDSOP && NP == 2 && !FASTSTATE;
     static constexpr unsigned SCRATCH_LO = (unsigned)((NL - 1) * IMG_B);          // byte offset of the low-part images
     static constexpr unsigned SCRATCH_BYTES = (unsigned)((STATE_LO ? 2 : 1) * (NL - 1) * IMG_B);
-    static __device__ __forceinline__ constexpr int slot_of(int L) { return SLDS ? L : (ONE_SLOT ? 0 : (L & 1)); }
+    static __device__ __forceinline__ constexpr int slot_of(int L) { return (SLDS || WSLDS) ? L : (ONE_SLOT ? 0 : (L & 1)); }
 
     // The NG mid weight layers that the reverse sweep reaches first (L = NL-1 .. NL-NG) keep their accumulator blocks in memory
     // (loaded in the layer's hand-off window, stored one layer later so that the write acknowledgement never sits in front of a
@@ -605,17 +609,17 @@ struct Fused {
     static constexpr bool RECOMP_W = ONE_SLOT;
     // (LDS-operand layouts with two slots: slot 1 is idle in the forward too; S_{NL-1} is written there beside its ping-pong image and
     // neither parked nor brought back.)
-    static constexpr bool KEEP_W = LDSOP && !ONE_SLOT;
+    static constexpr bool KEEP_W = LDSOP && !ONE_SLOT && !WSLDS;
     static constexpr bool TOP_IN_Z = KEEP2 && KS == 2 && NP == 2;
     static constexpr int FIRST_KEPT = TOP_IN_Z ? NL - 2 : NL - 1;
-    static __device__ __forceinline__ constexpr bool kept_in_lds(int l) { return (KEEP2 && l >= FIRST_KEPT && l <= NL - 1) || (KEEP_W && l == NL - 1) || ((RECOMP1 || RECOMP_W) && l == 1); }
+    static __device__ __forceinline__ constexpr bool kept_in_lds(int l) { return WSLDS || (KEEP2 && l >= FIRST_KEPT && l <= NL - 1) || (KEEP_W && l == NL - 1) || ((RECOMP1 || RECOMP_W) && l == 1); }
     static constexpr int TOPZ_OFF = NP * 1024, TOPZ_STRIDE = KS * NP * 1024;      // S_NL inside the Z area: record (s * KS + 1) * NP + kk
     static constexpr int N_DMA_ALL = LDSOP ? IMG_B / 2048 : IMG_B / 1024;       // LDSOP: two waves share a tile's records
     // mid layers: the LDS-DMA of S_{L-1} is issued in slices inside the weight gradient of layer L, not as a burst in the hand-off window
-    static constexpr bool DMA_IN_WGRAD = !SLDS && !ONE_SLOT;
+    static constexpr bool DMA_IN_WGRAD = !SLDS && !ONE_SLOT && !WSLDS;
     static __device__ __forceinline__ void dma_state(const DmaSrc& src, unsigned lane16, char* tile_lds, int l /*1..NL-1*/, int quad, int ii0 = 0,
                                                      int ii1 = N_DMA_ALL) {
-        if constexpr (SLDS) return;
+        if constexpr (SLDS || WSLDS) return;
         char* dst = tile_lds + TENSOR_Z_B + slot_of(l) * IMG_B;
         // LDSOP: two tiles, four waves: wave quad brings every second record of tile quad & 1 (records quad >> 1, +2, ...)
         const int i0 = LDSOP ? (quad >> 1) : 0;
@@ -683,7 +687,7 @@ struct Fused {
         static constexpr int N_LOAD = in_memory(L) ? NSUM : 0;
         // LDSOP mid layers: the DMA of S_{L-1} is issued inside the weight gradient of layer L (wg_blocks33), not in the window
         // ONE_SLOT: the DMA of S_L itself, in layer L's own window, and the window waits for all of it
-        static constexpr bool DMA_IN_WINDOW = !SLDS && !ONE_SLOT && L >= 2 && (!DMA_IN_WGRAD || L == NL) && !kept_in_lds(L - 1);
+        static constexpr bool DMA_IN_WINDOW = !SLDS && !WSLDS && !ONE_SLOT && L >= 2 && (!DMA_IN_WGRAD || L == NL) && !kept_in_lds(L - 1);
         static constexpr bool DMA_OWN = ONE_SLOT && L >= 1 && L <= NL - 1 && !kept_in_lds(L);
         static constexpr int N_DMA = DMA_IN_WINDOW ? N_DMA_ALL : 0;
         static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const WgCtx& w, const DmaSrc& scr, __amdgpu_buffer_rsrc_t accr,
@@ -1502,6 +1506,7 @@ struct Fused {
             u32x4 S1[NS][1][2][NP];
             wide_first<0>(a, x, xin, h, S1);
             half_store(opa, h, S1);
+            if constexpr (WSLDS) half_store(x.imgS(1), h, S1);       // every state keeps its own slot for the reverse
         }
         lds_barrier();
         fused_stamp(a, x.tracer, 32);
@@ -1957,7 +1962,9 @@ struct Fused {
                 for (int i = 0; i < LT; ++i) ls[i] = 0.0f;
                 fwd_head(a, x, valid, pidx, set, ls, acca, ZL);          // both halves: the same Z_NL; the loss sums count once
 #pragma unroll
-                for (int i = 0; i < LT; ++i) lsum[0][i] += half == 0 ? ls[i] : 0.0f;
+                for (int k = 0; k < NSETS; ++k)
+#pragma unroll
+                    for (int i = 0; i < LT; ++i) lsum[k][i] += (k == set && half == 0) ? ls[i] : 0.0f;
                 wide_reverse(a, x, xin, half, ZL);
             } else {
                 u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];

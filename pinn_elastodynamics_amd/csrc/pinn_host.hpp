@@ -96,7 +96,7 @@ struct Host {
     static constexpr int FUSED_MAX_WIDTH = 128;     // widest padded net the fused kernel takes (4 streams; 96 also 5 streams, 32 / 64 also 1 stream)
     static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? 32 * 1024 : (WIDTH <= 96 ? 72 * 1024 : 160 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
     template <int NS>
-    static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5)) || (WIDTH <= FUSED_MAX_WIDTH && NS == 4))); }
+    static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5 || NS == 1)) || (WIDTH <= FUSED_MAX_WIDTH && (NS == 4 || NS == 1)))); }
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
     static constexpr long MIN_TILES = 64;
     typedef FragIndex<WIDTH> FI;

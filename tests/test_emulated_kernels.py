@@ -320,9 +320,11 @@ def test_ragged_batches_wide_layout_emulated(emu, n):
     assert e_loss < 2e-6 and e_grad < 3e-6, n
 
 
-@pytest.mark.parametrize("layers,n,fused", [([3] + 4 * [32] + [7], 150, 1), ([3] + 8 * [64] + [7], 90, 1), ([3] + 8 * [64] + [7], 90, 0)])
+@pytest.mark.parametrize("layers,n,fused", [([3] + 4 * [32] + [7], 150, 1), ([3] + 8 * [64] + [7], 90, 1), ([3] + 8 * [64] + [7], 90, 0),
+                                            ([3] + 8 * [80] + [7], 100, 1), ([3] + 8 * [100] + [7], 75, 1)])
 def test_data_terms_fused_and_two_kernel_emulated(emu, layers, n, fused):
-    """value-only side sets (loss_IC / loss_SRC / ...) through the fused kernel's 1-stream instantiation and the two-kernel path"""
+    """value-only side sets (loss_IC / loss_SRC / ...) through the fused kernel's 1-stream instantiation and the two-kernel path; the
+    reference's 8 x 80 / 8 x 100 nets through the one-stream LDS-operand layout with all layer states in LDS (round 3)"""
     emu.set_fused(fused)
     rng = np.random.default_rng(8)
     Ws, bs = po.xavier_init(layers, rng)
@@ -340,7 +342,7 @@ def test_data_terms_fused_and_two_kernel_emulated(emu, layers, n, fused):
         grad = np.full(p32.size, np.nan, np.float32)
         emu.data_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, False, 0 if tg is None else tg.ctypes.data, ow,
                            loss.ctypes.data, grad.ctypes.data, False, "f16x3", ws.ctypes.data, wsb)
-        assert rel(loss[:7], ss) < 2e-6 and rel(grad, g) < (2e-4 if fused else 2e-6)
+        assert rel(loss[:7], ss) < 2e-6 and rel(grad, g) < ((2e-4 if layers[1] <= 64 else 3e-6) if fused else 2e-6)
     emu.set_fused(1)
 
 
@@ -376,7 +378,7 @@ def test_packed_weights_flag_emulated(emu):
     assert not np.allclose(l0, l3)
 
 
-@pytest.mark.parametrize("layers,fused", [([3] + 4 * [32] + [7], 1), ([3] + 2 * [48] + [7], 1)])
+@pytest.mark.parametrize("layers,fused", [([3] + 4 * [32] + [7], 1), ([3] + 2 * [48] + [7], 1), ([3] + 8 * [80] + [7], 1)])
 def test_data_loss_grad_multi_emulated(emu, layers, fused):
     """pinn_data_loss_grad_multi: three value-only sets (one of them empty, one with targets) in one call equal three single calls;
     4x32 takes the fused kernel's set table (one launch), 2x48 the two-kernel loop."""

@@ -588,6 +588,53 @@ def test_fused_wide_kernel_against_oracle_and_two_kernel_path(dev, width, n):
     assert rel(l.cpu().numpy(), ss) < 5e-6 and rel(g.cpu().numpy(), go) < 2e-5
 
 
+@pytest.mark.parametrize("width", [80, 100])
+def test_wide_side_sets_through_the_fused_kernel(dev, width):
+    """Round 3: the value-only side sets (loss_IC, loss_SRC, ...) of the reference's 8 x 80 / 8 x 100 nets run through the one-stream
+    LDS-operand instantiation of the fused kernel (all layer states of both tiles in LDS, one launch for up to four sets) instead of the
+    two-kernel path.  The library's profiling hook tells which path ran; both against the float64 oracle and each other."""
+    layers = [3] + 8 * [width] + [7]
+    rng = np.random.default_rng(21)
+    Ws, bs = po.xavier_init(layers, rng)
+    flat = po.pack_params(Ws, [0.2 * rng.standard_normal(b.shape) for b in bs])
+    lb, ub = [0.0, 0.0, 0.0], [30.0, 30.0, 20.0]
+    theta = to_dev(flat, dev)
+    eng = engine(layers, "f16x3", dev, 1 << 14)
+    sizes, g_ref, sets, refs = (7001, 0, 12345), np.zeros_like(flat), [], []
+    for k, n in enumerate(sizes):
+        X = rng.random((n, 3)) * np.array([30.0, 30.0, 20.0])
+        tgt = rng.standard_normal((n, 7)) if k == 2 else None
+        ow = (np.array([1, 1, 0, 0, 0, 2, 0.5]) if k == 2 else np.array([1, 1, 1, 1, 0, 0, 0.0])) / max(n, 1)
+        xs = [to_dev(X[:, j], dev) for j in range(3)]
+        tg = None if tgt is None else to_dev(tgt.T, dev)
+        sets.append((xs[0], xs[1], xs[2], tg, list(ow)))
+        if n:
+            ss, g, _ = po.data_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, True, tgt, ow)
+            g_ref += g
+            refs.append(ss)
+        else:
+            refs.append(np.zeros(7))
+    res = {}
+    for fused in (True, False):
+        eng.lib.set_fused(fused)
+        try:
+            los = [torch.full((8,), float("nan"), device=dev) for _ in sizes]
+            grad = torch.empty(flat.size, dtype=torch.float32, device=dev)
+            with eng.lib.profiling() as prof:
+                eng.data_loss_grad_multi(theta, [s_ + (lo,) for s_, lo in zip(sets, los)], lb, ub, True, grad_out=grad, accumulate=False)
+                torch.cuda.synchronize()
+                ran_fused = float(prof[2]) == 0.0 and float(prof[1]) > 0.0
+        finally:
+            eng.lib.set_fused(True)
+        assert ran_fused == fused, (fused, list(prof))
+        for k in range(3):
+            got = los[k].cpu().numpy()[:7]
+            assert (np.all(got == 0) if sizes[k] == 0 else rel(got, refs[k]) < 5e-6), (fused, k)
+        res[fused] = grad.cpu().numpy().astype(np.float64)
+        assert rel(res[fused], g_ref) < 2e-5, fused
+    assert rel(res[True], res[False]) < 1e-5
+
+
 def test_fp16_state_flag_is_opt_in_and_close_at_fresh_weights(dev):
     """PINN_FLAG_STATE_FP16 (HipEngine(fast_state=True)): the fused 8-layer collocation kernel parks fp16 states only.  Off by default; at
     fresh weights (no cancellation) it agrees with the default to the rounding noise of the parked state, and with the oracle to 2e-5."""
