@@ -117,7 +117,7 @@ struct Fused {
     static constexpr int P3 = NP == 2 ? 3 : 1;
     static constexpr float WS = NP == 2 ? FUSED_WEIGHT_SCALE : 1.0f;
     static constexpr float INV_WS = 1.0f / WS;
-    static_assert(WB == 2 || WB == 4 || WB == 6 || WB == 8, "fused kernel supports padded widths 32, 64, 96 and 128");
+    static_assert(WB == 2 || WB == 4 || WB == 6 || WB == 8 || WB == 10, "fused kernel supports padded widths 32, 64, 96, 128 and 160");
     static_assert(NL >= 2, "fused kernel needs at least two hidden layers");
     // LDSOP (padded width 96, the reference's 70 / 80): a tile's state does not fit the register file next to its successor (2 x 96
     // registers), so the chain wave keeps it in its LDS image -- the register image IS the MFMA operand layout -- and reads one k-step
@@ -132,7 +132,7 @@ struct Fused {
     // ONE state slot each beside the Z area (2 x 60 KB).  The LDS-DMA of S_L can then only start when the readers of S_{L+1} are done
     // -- in the hand-off window of layer L itself -- and that window waits for it.
     // Padded width 128 (the reference's semi-infinite net, 8 x 100: SEMI:679) with four streams: images of 32 KB, the same budget.
-    static constexpr bool ONE_SLOT = LDSOP && !WSLDS && (NS_ == 5 || WB == 8);
+    static constexpr bool ONE_SLOT = LDSOP && !WSLDS && (NS_ == 5 || WB >= 8);
     // (Five streams at padded width 128 -- the 3-D net of BASELINE configs[4]: 40 KB images, two tiles fill the 160 KB exactly and the
     // net constants come from memory.)
     static_assert(!(NS_ == 5 && WB == 8) || DIN_ == 4, "five streams at padded width 128: the 3-D instantiation only");
@@ -191,22 +191,28 @@ struct Fused {
     // a second layer spills 82 registers)
     static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? 5 : (NL >= 4 ? 2 : 0));      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
-    static constexpr int NSUM = IBW * OBW + (LDSOP ? 1 : 0);                   // in-memory records per layer: the blocks (+ LDSOP: the bias blocks' lane record)
+    // Padded width 160: 5 x 5 blocks per wave do not fit the register file next to their running sums (100 + 100 registers), so the
+    // weight gradient walks its out-blocks in three passes (2 + 2 + 1) and STREAMS the sums: a pass starts from its ten (five) records,
+    // requested one pass ahead, and stores them behind its last MFMA.
+    static constexpr bool STREAM_SUMS = LDSOP && WB == 10;
+    static constexpr int NBIASREC = (OBW + 3) / 4;                            // lane records holding the bias blocks (one float per block, four per record)
+    static constexpr int NSUM = IBW * OBW + (LDSOP ? NBIASREC : 0);            // in-memory records per layer: the blocks (+ LDSOP: the bias blocks' lane records)
     static constexpr unsigned WG_ACC_BYTES = (unsigned)((NG > 0 ? NG : 1) * NSUM * 1024);
     static __device__ __forceinline__ constexpr bool in_memory(int L) { return L >= 1 && L <= NL - 1 && L > NREG; }
     struct Sums {                      // running sums of one in-memory layer: this wave's blocks (+ LDSOP: its bias blocks, one float per lane and block)
-        f32x4 blk[IBW][OBW];
+        f32x4 blk[IBW][STREAM_SUMS ? 2 : OBW];      // (STREAM_SUMS: the first pass's two out-blocks only, requested ahead)
         f32x4 bias;
     };
     struct Acc {                       // persistent across the whole launch, all statically indexed
-        f32x4 mid[NREG > 0 ? NREG : 1][IBW][OBW];
+        f32x4 mid[NREG > 0 ? NREG : 1][NREG > 0 ? IBW : 1][NREG > 0 ? OBW : 1];
         f32x4 first;                   // Wbar_0 block (in-block 0, out-block = quad) if quad < WB
         f32x4 last;                    // Wbar_NL block (in-block = quad, out-block 0) if quad < WB
         float bias[NL + 1];
         // LDSOP (six blocks per side over four waves): a second first / last block (out- / in-block quad + 4 for quad < 2), and three bias
         // blocks per mid layer held by the waves with wi == 0
         f32x4 first2, last2;
-        float bias0b;                  // (LDSOP mid-layer bias blocks: one more in-memory record per layer, bias_record)
+        f32x4 first3, last3;           // (ten blocks per side: out- / in-block quad + 8 for quad < 2)
+        float bias0b, bias0c;          // (LDSOP mid-layer bias blocks: one more in-memory record per layer, bias_record)
         float biasr[NREG > 0 ? NREG : 1][3];      // ... of the in-register layers (LDSOP)
     };
 
@@ -243,6 +249,7 @@ struct Fused {
         unsigned lane16;
         char* tile_lds;
         int quad;
+        __amdgpu_buffer_rsrc_t accr;      // this wave's in-memory running sums (STREAM_SUMS: the weight gradient loads / stores them pass by pass)
     };
     // DL >= 2: the LDS-DMA of S_{DL-1} rides along, a slice behind every group (see DmaJob)
     template <int NA, int NBK, bool SLO = false, int DL = 0, int SSTR = KS * SP * 1024>
@@ -427,32 +434,147 @@ struct Fused {
     // LDSOP: six 16-feature blocks per side.  Wave (wi, wo) owns in-blocks {2wi, 2wi+1, 4+wi} x out-blocks {2wo, 2wo+1, 4+wo}: a pair that
     // shares a fragment record and a single block, the same shape for every wave (offsets at run time, block counts at compile time).
     // (Eight blocks per side, padded width 128: wave (wi, wo) owns in-blocks 4wi..4wi+3 x out-blocks 4wo..4wo+3, two record pairs each.)
-    static __device__ __forceinline__ int wide_block(int half, int i) { return WB == 8 ? 4 * half + i : (i < 2 ? 2 * half + i : 4 + half); }
+    // (Ten blocks per side, padded width 160: in-blocks 4wi..4wi+3 | 8+wi x out-blocks 4wo..4wo+3 | 8+wo, two record pairs and a single each.)
+    static __device__ __forceinline__ int wide_block(int half, int i) { return WB == 8 ? 4 * half + i : (WB == 10 ? (i < 4 ? 4 * half + i : 8 + half) : (i < 2 ? 2 * half + i : 4 + half)); }
+    // STREAM_SUMS (ten blocks per side): one pass = all IBW in-blocks x NBK out-blocks (O0, O0 + 1) of a mid layer over the step's 32 points.
+    // `start`: the pass's running sums (requested a pass ahead); the next pass's records are requested into `next` before the first MFMA
+    // and this pass's sums are stored behind the last one (loads ahead of stores: vector-memory operations complete in issue order).
+    template <int L, int O0, int NBK, int NNEXT>
+    static __device__ __forceinline__ void stream_pass(const char* s0, const char* s1, const char* z0, const char* z1, const int (&ia)[IBW], const int (&oz)[OBW],
+                                                       const f32x4 (&start)[IBW][2], f32x4 (&next)[IBW][2], float (&bias_out)[2], const DmaJob& job) {
+        f32x4 acc[IBW][NBK], cc[IBW][NBK], bm[NBK], bc[NBK];
+#pragma unroll
+        for (int i = 0; i < IBW; ++i)
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) {
+                acc[i][b] = start[i][b];
+                cc[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) bm[b] = bc[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (NNEXT > 0) {
+#pragma unroll
+            for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                for (int b = 0; b < NNEXT; ++b)
+                    next[i][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(job.accr, job.lane16, acc_record(L, i, O0 + NBK + b), 0));
+        }
+        const uint32_t one2 = pack2<Op>(1.0f, 1.0f);
+        const u32x4 ones = {one2, one2, one2, one2};
+        static_assert(NJ == 1, "one 32-point k-step per workgroup step");
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            u32x4 Ah[IBW], Al[IBW], Bh[NBK], Bl[NBK];
+#pragma unroll
+            for (int i = 0; i < IBW; ++i) {
+                Ah[i] = sfrag(s0 + ia[i], s1 + ia[i], st * KS * SP * 1024);
+                Al[i] = sfrag(s0 + ia[i], s1 + ia[i], st * KS * SP * 1024 + 1024);
+            }
+#pragma unroll
+            for (int b = 0; b < NBK; ++b) {
+                Bh[b] = sfrag(z0 + oz[O0 + b], z1 + oz[O0 + b], st * KS * NP * 1024);
+                Bl[b] = sfrag(z0 + oz[O0 + b], z1 + oz[O0 + b], st * KS * NP * 1024 + 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                for (int b = 0; b < NBK; ++b) {
+                    acc[i][b] = Op::mfma(Ah[i], Bh[b], acc[i][b]);
+                    cc[i][b] = Op::mfma(Ah[i], Bl[b], cc[i][b]);
+                    acc[i][b] = Op::mfma(Al[i], Bh[b], acc[i][b]);
+                }
+            if (st == 0) {                    // bias gradient = ones^T . Z (value stream)
+#pragma unroll
+                for (int b = 0; b < NBK; ++b) {
+                    bm[b] = Op::mfma(ones, Bh[b], bm[b]);
+                    bc[b] = Op::mfma(ones, Bl[b], bc[b]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int i = 0; i < IBW; ++i)
+#pragma unroll
+            for (int b = 0; b < NBK; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][b][r] += cc[i][b][r] * INV_LS;
+#pragma unroll
+        for (int b = 0; b < NBK; ++b) bias_out[b] = bm[b][0] + bc[b][0] * INV_LS;
+        // A THIRD hazard hipcc does not see (found on the GPU, round 3; the x86 emulator cannot show it): a 16-byte buffer store whose data
+        // registers a vector instruction overwrites in the NEXT issue slot stores the new value in its last dword.  The compiler pads that
+        // hazard only for stores without a scalar offset register; ours have one.  Written as "store; fma into the same registers; store",
+        // the per-block loop above produced exactly that sequence.  So: all sums are final first, then all stores, then wait states, and the
+        // scheduler may not move vector work in between.
+        store_fence(acc);
+#pragma unroll
+        for (int i = 0; i < IBW; ++i)
+#pragma unroll
+            for (int b = 0; b < NBK; ++b)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][b]), job.accr, job.lane16, acc_record(L, i, O0 + b), 0);
+        stores_issued();
+    }
+    // mid layer L of the ten-block layout: three passes over the out-blocks (pair, pair, single); lds_ = the first pass's sums (+ the bias
+    // records), requested behind the previous layer's weight gradient (load_sums)
+    template <int L>
+    static __device__ __forceinline__ void wgrad_stream(const WgCtx& w, int quad, const Sums& lds_, const DmaJob& job) {
+        static_assert(IBW == 5 && OBW == 5, "ten blocks per side");
+        const int wi = quad >> 1, wo = quad & 1;
+        const char* s0 = w.s0 + slot_of(L) * IMG_B;
+        const char* s1 = w.s1 + slot_of(L) * IMG_B;
+        int ia[IBW], oz[OBW];
+#pragma unroll
+        for (int i = 0; i < IBW; ++i) {
+            ia[i] = img_block(wide_block(wi, i));
+            oz[i] = zimg_block(wide_block(wo, i));
+        }
+        f32x4 n1[IBW][2], n2[IBW][2];
+        float b01[2], b23[2], b4[2];
+        stream_pass<L, 0, 2, 2>(s0, s1, w.z0, w.z1, ia, oz, lds_.blk, n1, b01, job);
+        stream_pass<L, 2, 2, 1>(s0, s1, w.z0, w.z1, ia, oz, n1, n2, b23, job);
+        stream_pass<L, 4, 1, 0>(s0, s1, w.z0, w.z1, ia, oz, n2, n1, b4, job);
+        if (wi == 0) {                         // the bias blocks of out-half wo: two lane records (four + one floats)
+            f32x4 ba = lds_.bias;
+            ba[0] += b01[0];
+            ba[1] += b01[1];
+            ba[2] += b23[0];
+            ba[3] += b23[1];
+            f32x4 bb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(job.accr, job.lane16, bias_record(L) + 1024, 0));
+            bb[0] += b4[0];
+            f32x4 both[1][2] = {{ba, bb}};
+            store_fence(both);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, both[0][0]), job.accr, job.lane16, bias_record(L), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, both[0][1]), job.accr, job.lane16, bias_record(L) + 1024, 0);
+            stores_issued();
+        }
+    }
+
     template <int L>
     static __device__ __forceinline__ void wgrad_wide(const WgCtx& w, Acc& A, int quad, const Sums& lds_, Sums& pends_, const DmaJob& job) {
-        const f32x4 (&ld)[IBW][OBW] = lds_.blk;
-        f32x4 (&pend)[IBW][OBW] = pends_.blk;
+        const auto& ld = lds_.blk;
+        auto& pend = pends_.blk;
         const char* s0 = w.s0 + slot_of(L) * IMG_B;
         const char* s1 = w.s1 + slot_of(L) * IMG_B;
         const int wi = quad >> 1, wo = quad & 1;
         if constexpr (L == 0 || L == NL) {
-            // first layer: in-block 0 x out-blocks {quad, quad + 4}; last layer: in-blocks {quad, quad + 4} x out-block 0
+            // first layer: in-block 0 x out-blocks {quad, quad + 4, quad + 8}; last layer: in-blocks {quad, quad + 4, quad + 8} x out-block 0
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < 3; ++k) {
                 const int blk = quad + 4 * k;
                 if (blk < WB) {
-                    f32x4 t[1][1] = {{L == 0 ? (k ? A.first2 : A.first) : (k ? A.last2 : A.last)}};
+                    f32x4 t[1][1] = {{L == 0 ? (k == 0 ? A.first : (k == 1 ? A.first2 : A.first3)) : (k == 0 ? A.last : (k == 1 ? A.last2 : A.last3))}};
                     float b[1];
                     if constexpr (L == 0) wg_blocks<1, 1>(s0, s1, w.z0 + zimg_block(blk), w.z1 + zimg_block(blk), t, b);
                     else wg_blocks<1, 1, true>(s0 + img_block(blk), s1 + img_block(blk), w.z0, w.z1, t, b);
                     if constexpr (L == 0) {
-                        if (k) { A.first2 = t[0][0]; A.bias0b += b[0]; } else { A.first = t[0][0]; A.bias[0] += b[0]; }
+                        if (k == 0) { A.first = t[0][0]; A.bias[0] += b[0]; } else if (k == 1) { A.first2 = t[0][0]; A.bias0b += b[0]; } else { A.first3 = t[0][0]; A.bias0c += b[0]; }
                     } else {
-                        if (k) A.last2 = t[0][0]; else A.last = t[0][0];
+                        if (k == 0) A.last = t[0][0]; else if (k == 1) A.last2 = t[0][0]; else A.last3 = t[0][0];
                         if (quad == 0 && k == 0) A.bias[NL] += b[0];
                     }
                 }
             }
+        } else if constexpr (STREAM_SUMS) {
+            wgrad_stream<L>(w, quad, lds_, job);
         } else {
             if constexpr (!in_memory(L)) {               // an in-register layer (two-slot layout): the nine blocks accumulate in place
                 static_assert(WB == 6, "in-register layers of the LDS-operand layouts: width 96 only");
@@ -657,20 +779,41 @@ struct Fused {
     // kept every wave of the workgroup waiting.  The first barrier of a layer is then an LDS-only one for this role.
     static constexpr bool EARLY_SUMS = LDSOP;      // (the narrow layouts measure the same either way: 5.77 / 5.78 ms)
     static __device__ __forceinline__ void store_sums(__amdgpu_buffer_rsrc_t accr, unsigned lane16, int L, const Sums& p) {
+        if constexpr (STREAM_SUMS) return;          // (stored pass by pass inside the weight gradient)
 #pragma unroll
         for (int i = 0; i < IBW; ++i)
 #pragma unroll
             for (int o = 0; o < OBW; ++o) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p.blk[i][o]), accr, lane16, acc_record(L, i, o), 0);
         if constexpr (LDSOP) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p.bias), accr, lane16, bias_record(L), 0);
+        stores_issued();
     }
     static __device__ __forceinline__ void load_sums(__amdgpu_buffer_rsrc_t accr, unsigned lane16, int L, Sums& p) {
 #pragma unroll
         for (int i = 0; i < IBW; ++i)
 #pragma unroll
-            for (int o = 0; o < OBW; ++o) p.blk[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), 0));
+            for (int o = 0; o < (STREAM_SUMS ? 2 : OBW); ++o) p.blk[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), 0));
         if constexpr (LDSOP) p.bias = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(L), 0));
     }
 
+    // fences around a group of 16-byte buffer stores (see stream_pass): the values are complete before the first store, and no vector
+    // instruction follows the last one within eight wait states
+    template <int NA, int NB>
+    static __device__ __forceinline__ void store_fence(f32x4 (&v)[NA][NB]) {
+#if defined(__AMDGCN__)
+#pragma unroll
+        for (int a = 0; a < NA; ++a)
+#pragma unroll
+            for (int b = 0; b < NB; ++b) asm volatile("" : "+v"(v[a][b]));
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    static __device__ __forceinline__ void stores_issued() {
+#if defined(__AMDGCN__)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 7" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
     // "wait until at most N of this wave's vector-memory operations are outstanding" (they complete in issue order)
     template <int N>
     static __device__ __forceinline__ void wait_vmcnt() {
@@ -719,7 +862,7 @@ struct Fused {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             fused_stamp(a, tracer, 65 + 3 * (NL - L));
-            wgrad<L>(w, A, quad, ld, pend, DmaJob{&scr, lane16, tile_lds, quad});
+            wgrad<L>(w, A, quad, ld, pend, DmaJob{&scr, lane16, tile_lds, quad, accr});
             if constexpr (EARLY_SUMS) {
                 if constexpr (in_memory(L)) store_sums(accr, lane16, L, pend);
                 if constexpr (in_memory(L - 1)) load_sums(accr, lane16, L - 1, ld);
@@ -737,9 +880,9 @@ struct Fused {
             for (int i = 0; i < IBW; ++i)
 #pragma unroll
                 for (int o = 0; o < OBW; ++o) A.mid[l][i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-        A.first = A.first2 = f32x4{0.f, 0.f, 0.f, 0.f};
-        A.last = A.last2 = f32x4{0.f, 0.f, 0.f, 0.f};
-        A.bias0b = 0.0f;
+        A.first = A.first2 = A.first3 = f32x4{0.f, 0.f, 0.f, 0.f};
+        A.last = A.last2 = A.last3 = f32x4{0.f, 0.f, 0.f, 0.f};
+        A.bias0b = A.bias0c = 0.0f;
 #pragma unroll
         for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
 #pragma unroll
@@ -804,6 +947,10 @@ struct Fused {
             for (int r = 0; r < 4; ++r) lo[r] = __shfl_xor(A.first2[r], 16);
 #pragma unroll
             for (int r = 0; r < 4; ++r) A.first2[r] += lo[r] * INV_LS;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lo[r] = __shfl_xor(A.first3[r], 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A.first3[r] += lo[r] * INV_LS;
         }
         if constexpr (LDSOP) {
             // wave quad: first / last blocks quad and quad + 4; mid layers: in-blocks wide_block(wi, i) x out-blocks wide_block(wo, o)
@@ -815,6 +962,11 @@ struct Fused {
                 put_block(A.last2, NL, quad + 4, 0, H, NO);
                 if (q == 0 && 16 * (quad + 4) + c < H) part[a.net.b_off[0] + 16 * (quad + 4) + c] = A.bias0b;
             }
+            if (quad + 8 < WB) {
+                put_block(A.first3, 0, 0, quad + 8, DIN, H);
+                put_block(A.last3, NL, quad + 8, 0, H, NO);
+                if (q == 0 && 16 * (quad + 8) + c < H) part[a.net.b_off[0] + 16 * (quad + 8) + c] = A.bias0c;
+            }
             if (quad == 0 && q == 0 && c < NO) part[a.net.b_off[NL] + c] = A.bias[NL];
 #pragma unroll
             for (int l = 1; l < NL; ++l) {
@@ -824,17 +976,21 @@ struct Fused {
                     for (int o = 0; o < OBW; ++o) {
                         f32x4 v;
                         if (in_memory(l)) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(l, i, o), 0));
-                        else v = A.mid[l <= NREG ? l - 1 : 0][i][o];
+                        else v = A.mid[l <= NREG ? l - 1 : 0][NREG > 0 ? i : 0][NREG > 0 ? o : 0];
                         put_block(v, l, wide_block(wi, i), wide_block(wo, o), H, H);
                     }
-                f32x4 bv;
-                if (in_memory(l)) bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l), 0));
-                else bv = f32x4{A.biasr[l <= NREG ? l - 1 : 0][0], A.biasr[l <= NREG ? l - 1 : 0][1], A.biasr[l <= NREG ? l - 1 : 0][2], 0.0f};
+                f32x4 bv, bv2 = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (in_memory(l)) {
+                    bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l), 0));
+                    if constexpr (NBIASREC > 1) bv2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l) + 1024, 0));
+                } else {
+                    bv = f32x4{A.biasr[l <= NREG ? l - 1 : 0][0], A.biasr[l <= NREG ? l - 1 : 0][1], A.biasr[l <= NREG ? l - 1 : 0][2], 0.0f};
+                }
                 if (wi == 0 && q == 0) {
 #pragma unroll
                     for (int o = 0; o < OBW; ++o) {
                         const int ob = wide_block(wo, o);
-                        if (16 * ob + c < H) part[a.net.b_off[l] + 16 * ob + c] = bv[o];
+                        if (16 * ob + c < H) part[a.net.b_off[l] + 16 * ob + c] = o < 4 ? bv[o] : bv2[o - 4];
                     }
                 }
             }
@@ -1366,8 +1522,12 @@ struct Fused {
     // record 1.  The wave's results are local fragments Fl[s][0][0][p] = the pair's record, Fl[s][0][1][p].xy = the single block's
     // 8 bytes; block numbers enter as run-time offsets only, so both halves run the same code.
     static constexpr int HB = WB / 2;
-    // (Padded width 128: four blocks per half, 4h .. 4h+3 = the two records 2h, 2h+1.)
-    static __device__ __forceinline__ int half_block(int h, int j) { return WB == 8 ? 4 * h + j : (h ? (j < 2 ? 4 + j : 3) : j); }
+    static constexpr int HR = (HB + 1) / 2;            // local fragment records of a half: its pairs, then (odd HB) the single block's half record
+    // (Padded width 128: four blocks per half, 4h .. 4h+3 = the two records 2h, 2h+1.  Padded width 160 -- the reference's confined-domain
+    // net, 6 x 140, CONF:891 --: five blocks per half, 4h .. 4h+3 = the records 2h, 2h+1, and block 8 + h = one half of record 4.)
+    static __device__ __forceinline__ int half_block(int h, int j) {
+        return WB == 8 ? 4 * h + j : (WB == 10 ? (j < 4 ? 4 * h + j : 8 + h) : (h ? (j < 2 ? 4 + j : 3) : j));
+    }
     // workgroup barrier that orders LDS traffic only: the chain waves' park stores and fragment loads stay in flight across it
     // hand-off barriers of the chain waves: LDS traffic only, the fragment / low-part loads requested in front of them stay in flight
     static __device__ __forceinline__ void hand_barrier() {
@@ -1383,14 +1543,15 @@ struct Fused {
         __syncthreads();
 #endif
     }
-    static __device__ __forceinline__ void half_store(char* img, int h, const u32x4 (&Fl)[NS][1][2][NP]) {
+    static __device__ __forceinline__ void half_store(char* img, int h, const u32x4 (&Fl)[NS][1][HR][NP]) {
 #pragma unroll
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 *reinterpret_cast<u32x4*>(img + ((s * KS + 2 * h) * NP + p) * 1024) = Fl[s][0][0][p];
-                if constexpr (WB == 8) *reinterpret_cast<u32x4*>(img + ((s * KS + 2 * h + 1) * NP + p) * 1024) = Fl[s][0][1][p];
-                else *reinterpret_cast<u32x2*>(img + ((s * KS + 1) * NP + p) * 1024 + 8 * h) = u32x2{Fl[s][0][1][p][0], Fl[s][0][1][p][1]};
+                if constexpr (WB >= 8) *reinterpret_cast<u32x4*>(img + ((s * KS + 2 * h + 1) * NP + p) * 1024) = Fl[s][0][1][p];
+                if constexpr (WB == 10) *reinterpret_cast<u32x2*>(img + ((s * KS + 4) * NP + p) * 1024 + 8 * h) = u32x2{Fl[s][0][2][p][0], Fl[s][0][2][p][1]};
+                if constexpr (WB == 6) *reinterpret_cast<u32x2*>(img + ((s * KS + 1) * NP + p) * 1024 + 8 * h) = u32x2{Fl[s][0][1][p][0], Fl[s][0][1][p][1]};
             }
     }
     // The GEMM of a half: its HB blocks accumulate over the KS k-steps of the operand image, NIT = KS * HB items of (k-step, block).
@@ -1406,7 +1567,7 @@ struct Fused {
     // The chain waves issue no stores in the forward: vector-memory operations complete in order on one counter, and a park store in
     // the queue puts its write acknowledgement -- ~2 k cycles -- in front of the next fragment wait.  The weight-gradient waves, idle in
     // the forward, copy every finished state image from LDS to the scratch image instead (park_image).
-    static constexpr int RING = WB == 8 ? 4 : 6;
+    static constexpr int RING = WB == 8 ? 4 : (WB == 10 ? 5 : 6);
     static_assert(!LDSOP || (2 * NIT) % RING == 0, "ring phase repeats every two layers");
     template <int PAR /* l & 1 */>
     static __device__ __forceinline__ void fwd_request(const Ctx& x, int l, int h, int t /*item of layer l, may run past NIT*/, u32x4 (&Ar)[RING][1][FP]) {
@@ -1427,7 +1588,7 @@ struct Fused {
         }
     }
     // reverse: the same kind of ring over the items of layers NL-1 .. 1 (T0 = global index of this layer's item 0)
-    static constexpr int RINGB = WB == 8 ? 4 : 6;      // (three fragment parts per item: 12 registers a slot)
+    static constexpr int RINGB = WB == 8 ? 4 : (WB == 10 ? 5 : 6);      // (three fragment parts per item: 12 registers a slot)
     template <int L>
     static __device__ __forceinline__ void ring_request(const Ctx& x, int h, int t /*item of layer L, may run past NIT*/, u32x4 (&Ar)[RINGB][1][RP]) {
         constexpr int T0 = (NL - 1 - L) * NIT;
@@ -1446,8 +1607,8 @@ struct Fused {
         }
     }
     template <int J>
-    static __device__ __forceinline__ void wide_fwd_epilogue(const f32x4 (&acc)[HB][NS], u32x4 (&out)[NS][1][2][NP]) {
-        fwd_valu<J, 2>(acc[J], out);
+    static __device__ __forceinline__ void wide_fwd_epilogue(const f32x4 (&acc)[HB][NS], u32x4 (&out)[NS][1][HR][NP]) {
+        fwd_valu<J, HR>(acc[J], out);
         if constexpr (J + 1 < HB) wide_fwd_epilogue<J + 1>(acc, out);
     }
     // one hidden weight layer l (1..NL-1): S_l (image `in`) -> this half's blocks of S_{l+1} (image `out`, parked if a reverse layer will DMA it back)
@@ -1457,13 +1618,13 @@ struct Fused {
 #pragma unroll
         for (int j = 0; j < HB; ++j) acc_init(load_bias(x, l, half_block(h, j)), acc[j]);
         half_gemm_fwd<PAR>(x, l, h, in, Af, acc);
-        u32x4 out[NS][1][2][NP];
+        u32x4 out[NS][1][HR][NP];
         wide_fwd_epilogue<0>(acc, out);
         half_store(outimg, h, out);
         if (kept_in_lds(l + 1)) half_store(x.imgS(l + 1), h, out);       // S_{NL-1} also into its reverse slot (KEEP_W)
     }
     template <int J>
-    static __device__ __forceinline__ void wide_first(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, u32x4 (&Bn)[NS][1][2][NP]) {
+    static __device__ __forceinline__ void wide_first(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, u32x4 (&Bn)[NS][1][HR][NP]) {
         const int mb = half_block(h, J);
         float vals[NS][4];
 #pragma unroll
@@ -1491,7 +1652,7 @@ struct Fused {
             for (int s = 1; s <= NT; ++s) vals[s][r] = sd * (a.sx[s - 1] * w[s - 1]);
             if constexpr (SECOND) vals[4][r] = -2.0f * hh * vals[3][r] * (a.sx[2] * w[2]);      // z_tt = 0 at the first layer
         }
-        emit_state<J, 2>(Bn, vals);
+        emit_state<J, HR>(Bn, vals);
         if constexpr (J + 1 < HB) wide_first<J + 1>(a, x, xin, h, Bn);
     }
     // forward of one tile (this wave's half): returns the output layer's products (acca, both halves compute them) for fwd_head; S_NL
@@ -1503,7 +1664,7 @@ struct Fused {
 #pragma unroll
         for (int t = 0; t < RING; ++t) fwd_request<1>(x, 1, h, t, Af);
         {
-            u32x4 S1[NS][1][2][NP];
+            u32x4 S1[NS][1][HR][NP];
             wide_first<0>(a, x, xin, h, S1);
             half_store(opa, h, S1);
             if constexpr (WSLDS) half_store(x.imgS(1), h, S1);       // every state keeps its own slot for the reverse
@@ -1527,7 +1688,7 @@ struct Fused {
     }
     // reverse vector part with the state in full precision (hi + unscaled lo from the operand-layout image)
     template <int J>
-    static __device__ __forceinline__ void wide_bwd_epilogue(f32x4 (&acc)[HB][NS], const char* simg, int h, u32x4 (&Zn)[NS][1][2][NP], int c, int q) {
+    static __device__ __forceinline__ void wide_bwd_epilogue(f32x4 (&acc)[HB][NS], const char* simg, int h, u32x4 (&Zn)[NS][1][HR][NP], int c, int q) {
         const int mb = half_block(h, J);
         float st[NS][4];
 #pragma unroll
@@ -1565,12 +1726,12 @@ struct Fused {
             }
             vals[0][0][r] = zb;
         }
-        CH::template emit<2, J>(Zn, vals, nullptr, WIDTH, c, q);
+        CH::template emit<HR, J>(Zn, vals, nullptr, WIDTH, c, q);
         if constexpr (J + 1 < HB) wide_bwd_epilogue<J + 1>(acc, simg, h, Zn, c, q);
     }
     // reverse of one tile; on entry the first barrier of the top layer has NOT been passed, S_NL (hi + lo) sits in S slot 0
     static __device__ __forceinline__ void wide_reverse(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, const u32x4 (&ZL)[NS][1][1][NP]) {
-        u32x4 Zn[NS][1][2][NP];
+        u32x4 Zn[NS][1][HR][NP];
         u32x4 Ar[RINGB][1][RP];
         u32x4 At[HB][1][RP];
         // (the fence keeps these requests behind the head's vector work: a spill reload in there would otherwise wait for all of them)
@@ -1599,7 +1760,7 @@ struct Fused {
     }
     // entry: Zc = this half's blocks of Z_L in registers, first barrier of layer L not yet passed
     template <int L>
-    static __device__ __forceinline__ void wide_down(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, const u32x4 (&Zc)[NS][1][2][NP],
+    static __device__ __forceinline__ void wide_down(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, const u32x4 (&Zc)[NS][1][HR][NP],
                                                      u32x4 (&Ar)[RINGB][1][RP]) {
         lds_barrier();                                          // A(L): the weight-gradient waves are done with Z_{L+1}, S_{L+1}
         fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
@@ -1608,7 +1769,7 @@ struct Fused {
             if (h == 0) put_input_state(a, x, xin);
         }
         if constexpr (RECOMP_W && L == 1) {                     // S_1 again from the inputs, this half's blocks (the forward's own function)
-            u32x4 S1[NS][1][2][NP];
+            u32x4 S1[NS][1][HR][NP];
             wide_first<0>(a, x, xin, h, S1);
             half_store(x.imgS(1), h, S1);
         }
@@ -1622,7 +1783,7 @@ struct Fused {
 #pragma unroll
             for (int j = 0; j < HB; ++j) acc_zero(acc[j]);
             half_gemm_bwd<L>(x, h, x.imgZ(), Ar, acc);           // operand: the Z_L image both halves have just written
-            u32x4 Zn[NS][1][2][NP];
+            u32x4 Zn[NS][1][HR][NP];
             wide_bwd_epilogue<0>(acc, x.imgS(L), h, Zn, x.c, x.q);
             fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
             wide_down<L - 1>(a, x, xin, h, Zn, Ar);

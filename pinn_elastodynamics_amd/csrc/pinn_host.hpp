@@ -93,10 +93,10 @@ struct Host {
     static constexpr int FUSED_PARTS = SPLIT == 3 ? 3 : 1;   // ... of the fused kernel's format (repack_kernel)
     static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
     static constexpr int FUSED_GRID = 256;    // persistent workgroups of the fused kernel (one per MI355X CU)
-    static constexpr int FUSED_MAX_WIDTH = 128;     // widest padded net the fused kernel takes (4 streams; 96 also 5 streams, 32 / 64 also 1 stream)
+    static constexpr int FUSED_MAX_WIDTH = 160;     // widest padded net the fused kernel takes (160: 4 streams, 6 layers = CONF:891; 128: 4 and 1 streams (+ the 3-D head); 96 also 5 streams)
     static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? 32 * 1024 : (WIDTH <= 96 ? 72 * 1024 : 160 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
     template <int NS>
-    static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5 || NS == 1)) || (WIDTH <= FUSED_MAX_WIDTH && (NS == 4 || NS == 1)))); }
+    static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5 || NS == 1)) || (WIDTH <= 128 && (NS == 4 || NS == 1)) || (WIDTH == 160 && NS == 4))); }
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
     static constexpr long MIN_TILES = 64;
     typedef FragIndex<WIDTH> FI;
@@ -423,14 +423,19 @@ struct Host {
     template <int NS>
     static int try_fused(const Call& c, int* out, int nterms) {
         if constexpr (fused_has<NS>()) {
-            if (c.net.nl != 4 && c.net.nl != 8) return 0;
-            if (WIDTH > 64 && c.net.nl != 8) return 0;          // padded widths 96 / 128: the 8-layer instantiations only (INF:645 8 x 80, SEMI:679 8 x 100)
+            if constexpr (WIDTH == 160) {
+                if (c.net.nl != 6) return 0;                    // padded width 160: the reference's confined-domain net, 6 x 140 (CONF:891)
+            } else {
+                if (c.net.nl != 4 && c.net.nl != 8) return 0;
+                if (WIDTH > 64 && c.net.nl != 8) return 0;      // padded widths 96 / 128: the 8-layer instantiations only (INF:645 8 x 80, SEMI:679 8 x 100)
+            }
             Plan p;
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
             constexpr int TILES = Fused<Op, SPLIT, WIDTH, 4, NS>::TILES;
             // (sized for the default layout, which parks more than the fp16-state one)
-            const size_t per_wg = (size_t)TILES * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NS>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NS>::SCRATCH_BYTES);
+            const size_t per_wg = (size_t)TILES * (WIDTH == 160 ? Fused<Op, SPLIT, WIDTH, 6, NS>::SCRATCH_BYTES
+                                                                : (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NS>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NS>::SCRATCH_BYTES));
             if (c.ws_bytes < p.fixed_end + per_wg) return 0;
             long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
             if (grid > FUSED_GRID) grid = FUSED_GRID;
@@ -444,7 +449,8 @@ struct Host {
             }
             if (nsteps == 0) return 0;
             if (grid > nsteps) grid = nsteps;
-            if constexpr (WIDTH > 64) *out = fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
+            if constexpr (WIDTH == 160) *out = fused_launch<6, NS>(c, p, (int)grid, nterms, nsteps);
+            else if constexpr (WIDTH > 64) *out = fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
             else if (c.fast_state && SPLIT == 3 && NS == 4 && c.net.nl == 8) *out = fused_launch<8, NS, true>(c, p, (int)grid, nterms, nsteps);   // the collocation kernel of the 8-layer nets
             else *out = c.net.nl == 4 ? fused_launch<4, NS>(c, p, (int)grid, nterms, nsteps) : fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
             return 1;

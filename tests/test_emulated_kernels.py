@@ -604,3 +604,17 @@ def test_fused_nc3d_emulated(emu):
             assert rel(loss[:12], ss) < 2e-6 and rel(grad, g) < 5e-6, (fused, n, rel(loss[:12], ss), rel(grad, g))
         emu.set_fused(True)
         assert rel(res[True][1], res[False][1].astype(np.float64)) < 5e-6
+
+
+def test_fused_width160_emulated(emu):
+    """Padded width 160 -- the reference's confined-domain net, 6 x 140 (CONF:891) -- through the LDS-operand layout of the fused kernel
+    (round 3): ten blocks per side, five per chain half (two record pairs + a single), 40 KB images with the state in one slot, net
+    constants from memory, and the weight gradient STREAMING its running sums in three passes over the out-blocks.  Against the oracle
+    and the two-kernel path; several workgroup steps, a ragged count, raw inputs as the script feeds them (CONF:235)."""
+    layers = [3] + 6 * [140] + [7]
+    e_loss, e_grad = run_wave(emu, layers, 50, "f16x3", fused=True)
+    assert e_loss < 2e-6 and e_grad < 3e-6, (e_loss, e_grad)
+    e_loss, e_grad = run_wave(emu, layers, 50, "f16x3", fused=False)
+    assert e_loss < 2e-6 and e_grad < 2e-6
+    e_loss, e_grad = run_wave(emu, layers, 150, "f16x3", min_ws=True, fused=True, normalize=False, seed=4)      # several steps per workgroup
+    assert e_loss < 2e-6 and e_grad < 5e-6, (e_loss, e_grad)
