@@ -1074,6 +1074,23 @@ struct Fused {
             for (int kk = 0; kk < KSF; ++kk) *reinterpret_cast<u32x4*>(img + (s * KS + kk) * SP * 1024) = F[s][0][kk][0];
     }
 
+    // Issue order of a forward block step: N groups of (one MFMA, V vector instructions).  A wave issues in order, and left to itself the
+    // compiler puts the MFMAs of a block step in bursts of 8..24 (the matrix pipe then runs 16 cycles per instruction with the issue port
+    // idle) and the vector part in runs of 40..80 (the pipe idle): tools/isa_model.py.  Two waves of a SIMD barely co-execute MFMA and
+    // vector work (tools/probes/coexec_probe.hip: 0.83 of the serial time); inside ONE wave a 1 : 2 interleave runs at the pipe's rate.
+    // Measured (round 3, same box, interleaved timing): forward 1 : 2 -> -1 % of the launch; the same in the reverse step +2 % (its
+    // bursts time-share the pipe with the weight-gradient wave of the SIMD better than a fine interleave does), so the reverse keeps
+    // the compiler's order.
+    template <int N, int V>
+    static __device__ __forceinline__ void interleave() {
+#if defined(__AMDGCN__)
+        if constexpr (N > 0) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, V, 0);
+            interleave<N - 1, V>();
+        }
+#endif
+    }
     // weight fragments of one feature block (NPARTS = 2: forward parts [V_hi, V_lo]; 3: reverse, plus [w_hi])
     template <int KSB, int NPARTS>
     static __device__ __forceinline__ void load_afrags(const Ctx& x, int frag0, u32x4 (&Af)[KSB][NPARTS]) {
@@ -1289,6 +1306,7 @@ struct Fused {
             }
             fwd_ksteps<0, KS, KS>(A[MB + 1], in, anxt);
             fwd_valu<MB>(acur, out);
+            if constexpr (NS == 4 && NP == 2) interleave<NS * KS * P3, 2>();
         } else {
             // last block: the next layer's block 0 starts on the finished half of `out`
             acc_init(bb[0], anxt);
