@@ -150,8 +150,9 @@ class PinnLib:
                 return False
         return _Ctx()
 
-    def set_fused(self, enable: bool) -> bool:
-        return bool(self.lib.pinn_debug_set_fused(int(bool(enable))))
+    def set_fused(self, enable) -> int:
+        """0: two-kernel path, 1: fused kernel where it applies (default), 2: as 1 with the one-wave-per-SIMD variant of the 8 x 64 wave kernel"""
+        return int(self.lib.pinn_debug_set_fused(2 if enable == 2 else int(bool(enable))))
 
     def supported_width(self, h: int) -> int:
         return self.lib.pinn_supported_width(int(h))

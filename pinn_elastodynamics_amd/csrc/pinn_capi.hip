@@ -74,7 +74,10 @@ static void input_map(const double* lb, const double* ub, int normalize, Call& c
 
 using namespace pinn;
 
-static int g_use_fused = 1;
+#ifndef PINN_X_FUSED_DEFAULT
+#define PINN_X_FUSED_DEFAULT 1
+#endif
+static int g_use_fused = PINN_X_FUSED_DEFAULT;
 static unsigned long long* g_dbg_stamps = nullptr;
 static float* g_prof_ms = nullptr;
 
@@ -87,7 +90,7 @@ void pinn_debug_set_profile_buffer(float* host_ms4) { g_prof_ms = host_ms4; }
 
 int pinn_debug_set_fused(int enable) {
     const int old = g_use_fused;
-    g_use_fused = enable ? 1 : 0;
+    g_use_fused = enable == 2 ? 2 : (enable ? 1 : 0);
     return old;
 }
 

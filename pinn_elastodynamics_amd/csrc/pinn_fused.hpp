@@ -100,9 +100,13 @@ __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int sl
 // a 2^-12 state rounding that cancellation amplifies at trained weights (see STATE_LO below).  Not the default.
 // DIN_ = 4 (round 3): the 3-D Navier-Cauchy extension of BASELINE configs[4] -- inputs (x, y, z, t), five FIRST-order streams (value, x, y, z,
 // t), 12 outputs and the 3-D residual head (oracle/nc3d_oracle.py); built for the LDS-operand layout of padded width 128.
-template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4, bool FASTSTATE = false, int DIN_ = 3>
+// MERGE_ (round 3, experimental): ONE wave per SIMD -- four waves per workgroup, each a chain wave that ALSO owns one quadrant of every
+// weight gradient (512 registers per wave: all weight-gradient sums stay in registers, none in memory) -- instead of two waves per SIMD in
+// two roles.  Narrow four-stream layout only.
+template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4, bool FASTSTATE = false, int DIN_ = 3, bool MERGE_ = false>
 struct Fused {
     static constexpr int NS = NS_, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1, DIN = DIN_;
+    static constexpr bool MERGE = MERGE_;
     static_assert(NS == 4 || NS == 1 || NS == 5, "wave residual head (4 streams), value-only data head (1 stream) or plate / 3-D head (5 streams)");
     static_assert(DIN == 3 || (DIN == 4 && NS == 5), "4 inputs: the five-stream 3-D head only");
     // NS = 5, 3 inputs: streams (value, x, y, t, tt) -- the fifth carries the second time derivative (PLATE:417-419) -- and the plate head:
@@ -189,7 +193,7 @@ struct Fused {
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
     // (two-slot wide layout: layer 1's nine blocks stay in registers -- one layer less of the sums' round trip through L2: 6.39 -> 6.28 ms;
     // a second layer spills 82 registers)
-    static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? 5 : (NL >= 4 ? 2 : 0));      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
+    static constexpr int NG = MERGE_ ? 0 : LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? 5 : (NL >= 4 ? 2 : 0));      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
     // Padded width 160: 5 x 5 blocks per wave do not fit the register file next to their running sums (100 + 100 registers), so the
     // weight gradient walks its out-blocks in three passes (2 + 2 + 1) and STREAMS the sums: a pass starts from its ten (five) records,
@@ -926,7 +930,10 @@ struct Fused {
             }
             WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend, ld);
         }
-        // ---- write this workgroup's partial gradient
+        write_partial(a, A, quad, c, q, accr, lane16);
+    }
+    // ---- write this workgroup's partial gradient
+    static __device__ __forceinline__ void write_partial(const FusedArgs& a, Acc& A, int quad, int c, int q, __amdgpu_buffer_rsrc_t accr, unsigned lane16) {
         float* part = a.partial + (long)blockIdx.x * a.net.nparams;
         const int H = a.net.h, NO = a.net.nout, wi = quad >> 1, wo = quad & 1;
         auto put_block = [&](const f32x4& v, int l, int ib, int ob, int n_in, int n_out) {
@@ -1808,6 +1815,147 @@ struct Fused {
         }
     }
 
+    // ---------------------------------------------------------------------------------------------
+    // MERGE: chain wave + weight-gradient quadrant in one wave (see the template parameter)
+    // ---------------------------------------------------------------------------------------------
+    struct MCtx {                      // the weight-gradient side of a merged wave
+        WgCtx w;
+        DmaSrc scr;
+        char* tile_lds;
+        int quad;
+    };
+    template <int L>
+    struct MDown {
+        // entry: Zc = Z_L in chain fragment order (as Down<L>); the wave's own LDS-DMA of S_L was issued during layer L + 1
+        static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const MCtx& m, Acc& A, const float (&xin)[4], const u32x4 (&Zc)[NS][1][KS][NP]) {
+            static_assert(MERGE && !LDSOP && !SLDS && NS == 4, "merged role: narrow four-stream layout");
+            u32x4 Aa[KS][RP], Ab[KS][RP];
+            u32x2 sla[NS], slb[NS];
+            constexpr bool RECOMP = RECOMP1 && L == 1;
+            u32x4 S1[NS][1][KS][NP];
+            if constexpr (L >= 1) {
+                load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 0, 0), Aa);
+                load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 1, 0), Ab);
+                if constexpr (!RECOMP) lo_from_scratch<0>(x, L, sla);
+            }
+            hand_barrier();                                    // A: every wave is done with the images of layer L + 1 (its weight-gradient reads included)
+            fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
+            put_zimage<KS>(x.imgZ(), Zc);
+            if constexpr (L == 0) put_input_state(a, x, xin);
+            if constexpr (RECOMP) {
+                first_mb<0>(a, x, xin, S1);
+                put_image<KS>(x.imgS(1), S1);
+            }
+            // the LDS-DMA of S_L (this wave's tile) has landed: everything this wave has in flight is waited for (its fragment and
+            // low-part requests of this layer are needed right behind the barrier anyway)
+            wait_vmcnt<0>();
+            hand_barrier();                                    // B: images of layer L complete
+            fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
+            // weight gradient of layer L, this wave's quadrant (the LDS-DMA of S_{L-1} rides inside, as in the two-role layout)
+            {
+                Sums none_a, none_b;
+                wgrad_narrow<L>(m.w, A, m.quad, none_a.blk, none_b.blk, DmaJob{&m.scr, x.lane16, m.tile_lds, m.quad, x.scr});
+            }
+            if constexpr (L >= 1) {
+                u32x4 Zn[NS][1][KS][NP];
+                f32x4 acca[NS], accb[NS];
+                acc_zero(acca);
+                bwd_ksteps<0, KS, KS>(Aa, Zc, acca);
+                if constexpr (RECOMP) bwd_step<0, KS, true>(x, FI::bwd_mid(NL, L, 0, 0), L, nullptr, S1, Zc, Zn, Aa, Ab, acca, accb, sla, slb);
+                else bwd_step<0, KS, false>(x, FI::bwd_mid(NL, L, 0, 0), L, x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb, sla, slb);
+                pin<KS>(Zn);
+                fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
+                MDown<L - 1>::run(a, x, m, A, xin, Zn);
+            }
+        }
+    };
+    static __device__ __forceinline__ void merged_role(const FusedArgs& a, char* lds, int wave, int lane, int c, int q) {
+        const long gwave = (long)blockIdx.x * TILES + wave;
+        Ctx x;
+        x.init(a, lds, wave, lane, c, q);
+        x.set_tile(a, gwave);
+        MCtx m;
+        {
+            const char* wave0 = lds + (q >> 1) * WAVE_B;
+            const int p0 = 8 * (q & 1) + (c >> 2), sub = c & 3;
+            m.w.z0 = wave0 + img_record(p0, sub);
+            m.w.z1 = wave0 + img_record(p0 + 4, sub);
+            m.w.s0 = m.w.z0 + TENSOR_Z_B;
+            m.w.s1 = m.w.z1 + TENSOR_Z_B;
+        }
+        m.scr.init(reinterpret_cast<char*>(a.scratch) + gwave * (long)SCRATCH_BYTES, SCRATCH_BYTES);
+        m.tile_lds = lds + wave * WAVE_B;
+        m.quad = wave;
+        Acc A;
+#pragma unroll
+        for (int l = 0; l < NREG; ++l)
+#pragma unroll
+            for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                for (int o = 0; o < OBW; ++o) A.mid[l][i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        A.first = A.first2 = A.first3 = f32x4{0.f, 0.f, 0.f, 0.f};
+        A.last = A.last2 = A.last3 = f32x4{0.f, 0.f, 0.f, 0.f};
+        A.bias0b = A.bias0c = 0.0f;
+#pragma unroll
+        for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
+        float lsum[LT];
+#pragma unroll
+        for (int i = 0; i < LT; ++i) lsum[i] = 0.0f;
+        for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
+            float xin[4];
+            bool valid;
+            long pidx;
+            load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + wave, c, xin, valid, pidx);
+            x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0 && step == 2 * (long)gridDim.x;
+            fused_stamp(a, x.tracer, 0);
+            u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
+            forward_tile(a, x, xin, valid, pidx, 0, lsum, B, ZL);
+            // ---- top weight layer NL (as reverse_tile), then the merged sweep
+            fused_stamp(a, x.tracer, 2);
+            u32x4 Aa[1][RP], Ab[1][RP];
+            load_afrags<1, RP>(x, FI::bwd_last(NL, 0), Aa);
+            load_afrags<1, RP>(x, FI::bwd_last(NL, 1), Ab);
+            __syncthreads();              // the one full drain: this forward's park stores have landed before an LDS-DMA reads them
+            fused_stamp(a, x.tracer, 3);
+            put_zimage<1>(x.imgZ(), ZL);
+            if constexpr (TOP_IN_Z) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int kk = 0; kk < KS; ++kk) *reinterpret_cast<u32x4*>(x.imgZ() + TOPZ_OFF + s * TOPZ_STRIDE + kk * 1024) = B[s][0][kk][0];
+            } else {
+                put_image<KS>(x.imgS(NL), B);
+            }
+            hand_barrier();
+            fused_stamp(a, x.tracer, 4);
+            {
+                Sums none_a, none_b;
+                wgrad_narrow<NL>(m.w, A, m.quad, none_a.blk, none_b.blk, DmaJob{&m.scr, x.lane16, m.tile_lds, m.quad, x.scr});
+            }
+            u32x4 Zn[NS][1][KS][NP];
+            {
+                f32x4 acca[NS], accb[NS];
+                acc_zero(acca);
+                bwd_ksteps<0, 1, 1>(Aa, ZL, acca);
+                u32x2 sla[NS], slb[NS];
+                bwd_step<0, 1, true>(x, FI::bwd_last(NL, 0), NL, nullptr, B, ZL, Zn, Aa, Ab, acca, accb, sla, slb);
+                pin<KS>(Zn);
+            }
+            fused_stamp(a, x.tracer, 5);
+            MDown<NL - 1>::run(a, x, m, A, xin, Zn);
+        }
+#pragma unroll
+        for (int i = 0; i < LT; ++i) {
+            float v = lsum[i];
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            v += __shfl_xor(v, 4);
+            v += __shfl_xor(v, 8);
+            if (lane == 0) a.loss_part[gwave * LT + i] = v;
+        }
+        write_partial(a, A, wave, c, q, x.scr /*unused: no in-memory sums*/, x.lane16);
+    }
+
     // forward + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
     // parks S_1..S_{NL-1} (scratch image or LDS slots), returns S_NL (fragments) and the head's adjoint Z_NL, adds the loss sums
     static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[4], bool valid, long pidx, int set, float (&lsum)[LT],
@@ -2177,7 +2325,7 @@ struct Fused {
         const int wave8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // provably wave-uniform
         if constexpr (CONST_LDS) {
             float* cst = reinterpret_cast<float*>(lds + CONST_OFF);
-            for (int i = threadIdx.x; i < CONST_F; i += 512) {
+            for (int i = threadIdx.x; i < CONST_F; i += (MERGE ? 256 : 512)) {
                 float v;
                 if (i < (NL - 1) * WIDTH) v = a.pw.bias_mid[i] * WS;
                 else if (i < CONST_BIAS_F) v = a.pw.bias_last[i - (NL - 1) * WIDTH] * WS;
@@ -2186,7 +2334,9 @@ struct Fused {
             }
             __syncthreads();
         }
-        if (wave8 >= 4) {
+        if constexpr (MERGE) {
+            merged_role(a, lds, wave8, lane, c, q);
+        } else if (wave8 >= 4) {
             wgrad_role(a, lds, wave8 - 4, lane, c, q);
         } else {
             __builtin_amdgcn_s_setprio(2);          // the chain wave is the critical path of its SIMD: issue it first
@@ -2198,6 +2348,12 @@ struct Fused {
 template <class Op, int SPLIT, int WIDTH, int NL, int NS, bool FASTSTATE, int DIN = 3>
 __global__ __launch_bounds__(512) void fused_wave_kernel(const FusedArgs a) {
     Fused<Op, SPLIT, WIDTH, NL, NS, FASTSTATE, DIN>::run(a);
+}
+
+// one wave per SIMD (see Fused<>::MERGE): 256 threads, up to 512 registers per wave
+template <class Op, int SPLIT, int WIDTH, int NL>
+__global__ __launch_bounds__(256) void fused_merged_kernel(const FusedArgs a) {
+    Fused<Op, SPLIT, WIDTH, NL, 4, false, 3, true>::run(a);
 }
 
 }  // namespace pinn

@@ -392,7 +392,15 @@ struct Host {
             EventPair evp(c.prof_ms != nullptr);
             hipEvent_t (&ev)[2] = evp.ev;
             if (c.prof_ms) hipEventRecord(ev[0], c.stream);
-            hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL, NS, FS, DIN>), dim3(grid), dim3(512), 0, c.stream, a);
+            bool merged = false;
+            if constexpr (SPLIT == 3 && WIDTH == 64 && NL == 8 && NS == 4 && !FS && DIN == 3) {
+                if (c.use_fused == 2) {        // one wave per SIMD (Fused<>::MERGE): experimental, pinn_debug_set_fused(2)
+                    hipLaunchKernelGGL((fused_merged_kernel<Op, SPLIT, WIDTH, NL>), dim3(grid), dim3(256), 0, c.stream, a);
+                    merged = true;
+                    if (getenv("PINN_TRACE_MERGED")) fprintf(stderr, "[pinn] merged kernel grid=%d nsteps=%ld\n", grid, nsteps);
+                }
+            }
+            if (!merged) hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL, NS, FS, DIN>), dim3(grid), dim3(512), 0, c.stream, a);
             if ((rc = (int)hipGetLastError())) return rc;
             if (c.prof_ms) {
                 hipEventRecord(ev[1], c.stream);
