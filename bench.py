@@ -239,7 +239,9 @@ def main():
         step = lambda k: model.train(k, 1e-3, 1)
         workload = (f"3D Navier-Cauchy half space (build-side extension, not in the reference; parity unpinned), 10x128 tanh MLP on (x,y,z,t), 12 outputs, "
                     f"{pts_per_rank} collocation pts per GPU + IC/TOP 20000 each + SRC 20000, Adam step incl. gradient all-reduce (BASELINE configs[4]: "
-                    f"32 M pts on 8 GPUs); 'fp32' is served by f16x3 (fp32-class: sums and gradient within 2e-5 of the float64 oracle); two-kernel path")
+                    f"32 M pts on 8 GPUs); 'fp32' is served by f16x3 (fp32-class: sums and gradient within 2e-5 of the float64 oracle; exact-fp32 device mode exists "
+                    f"for checks); collocation set through the fused LDS-operand kernel (padded width 128, five first-order streams, four inputs), side sets "
+                    f"through the two-kernel path")
     flop_pt = flop_per_point(layers, streams)
 
     def barrier():
@@ -342,6 +344,32 @@ def main():
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; the hole-traction set (9960 points) runs on the "
                                        "two-kernel path.  traffic not measured in this run"}
+            out["kernel_ms_per_step"] = acc
+        elif cfg == "nc3d" and args.precision == "f16x3" and layers[1:-1] == [128] * 10:
+            # ---- the 3-D instantiation of the fused kernel (Fused<..., NL = 10, NS = 5, DIN = 4>): HIP events around the collocation launch
+            x, y, z, t = model._rows(0, model._n_collo)
+            tw = [1.0 / pts_per_rank] * 12
+            prof = eng.lib.set_profile_buffer(True)
+            acc = {"repack": 0.0, "chain": 0.0, "wgrad": 0.0, "reduce": 0.0}
+            reps = 3
+            for i in range(reps + 1):
+                eng.nc3d_loss_grad(model.theta, x, y, z, t, model.lb, model.ub, model.normalize, tw, model.E, model.mu, model.rho)
+                if i > 0:
+                    for j, k in enumerate(acc):
+                        acc[k] += float(prof[j]) / reps
+            eng.lib.set_profile_buffer(False)
+            fused = acc["wgrad"] == 0.0
+            n_launch = 1 if fused else -(-pts_per_rank // min(args.chunk_points, 1 << 17))
+            t_ms = acc["chain"] if fused else acc["chain"] + acc["wgrad"]
+            tflops = flop_pt * pts_per_rank / (t_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "fused_wave_kernel<OpF16, 3, 128, 10, 5, false, 4> (3-D: forward with four tangent streams + 12-residual head + reverse "
+                                         "chain + weight gradient)" if fused else "chain_kernel + wgrad_kernel (two-kernel path)",
+                               "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
+                               "traffic": None, "launches_per_step": n_launch, "avg_launch_ms": t_ms / n_launch, "algorithmic_flop_per_point": flop_pt,
+                               "issued_mfma_tflops": tflops * issued,
+                               "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
+                                       "gradient) / HIP-event launch time of the collocation launch; measured limiter of the LDS-operand layouts: the bytes "
+                                       "of parked states and in-memory weight-gradient sums through L2 (DESIGN.md section 6).  traffic not measured in this run"}
             out["kernel_ms_per_step"] = acc
         else:
             # two-kernel path: the step is a sequence of chain + weight-gradient launches over workspace passes; report the whole step

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Dev tool (GPU box): everything a round commits under profiles/ -- rocprofv3 stats + PMC (tools/collect_profiles.sh) and the bench lines.
+#   tools/collect_round.sh TAG      -> gpurun_out/TAG_*.{csv,json}
+TAG=${1:-r03}
+OUT=gpurun_out
+mkdir -p $OUT
+bash tools/collect_profiles.sh $TAG > $OUT/collect_$TAG.log 2>&1
+python bench.py > $OUT/${TAG}_bench_wave.json 2> $OUT/bench_wave.err
+python bench.py --config plate > $OUT/${TAG}_bench_plate.json 2> $OUT/bench_plate.err
+python bench.py --config plate --width 70 --no-cpu-baseline > $OUT/${TAG}_bench_plate70.json 2> $OUT/bench_plate70.err
+python bench.py --config nc3d > $OUT/${TAG}_bench_nc3d.json 2> $OUT/bench_nc3d.err
+python bench.py --width 80 --points-per-gpu 1000000 --no-cpu-baseline --extra-modes none > $OUT/${TAG}_bench_wave80.json 2> $OUT/bench_wave80.err
+python bench.py --width 100 --points-per-gpu 1000000 --no-cpu-baseline --extra-modes none > $OUT/${TAG}_bench_wave100.json 2> $OUT/bench_wave100.err
+python bench.py --points-per-gpu 250000 --no-cpu-baseline --extra-modes none > $OUT/${TAG}_bench_250k.json 2> $OUT/bench_250k.err
+python tools/conf_time.py > $OUT/${TAG}_conf_time.txt 2>&1
+tail -n 3 $OUT/${TAG}_bench_*.json $OUT/${TAG}_conf_time.txt
