@@ -930,10 +930,9 @@ struct Fused {
             }
             WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend, ld);
         }
-        write_partial(a, A, quad, c, q, accr, lane16);
-    }
-    // ---- write this workgroup's partial gradient
-    static __device__ __forceinline__ void write_partial(const FusedArgs& a, Acc& A, int quad, int c, int q, __amdgpu_buffer_rsrc_t accr, unsigned lane16) {
+        // ---- write this workgroup's partial gradient
+        // (kept in the body of the role: as a separate function taking the accumulators by reference the same statements cost the
+        // default kernel 17 more spilled registers and 6 % of its time)
         float* part = a.partial + (long)blockIdx.x * a.net.nparams;
         const int H = a.net.h, NO = a.net.nout, wi = quad >> 1, wo = quad & 1;
         auto put_block = [&](const f32x4& v, int l, int ib, int ob, int n_in, int n_out) {
@@ -1953,7 +1952,39 @@ struct Fused {
             v += __shfl_xor(v, 8);
             if (lane == 0) a.loss_part[gwave * LT + i] = v;
         }
-        write_partial(a, A, wave, c, q, x.scr /*unused: no in-memory sums*/, x.lane16);
+        // ---- write this workgroup's partial gradient (the narrow branch of the weight-gradient role's epilogue; all sums in registers)
+        float* part = a.partial + (long)blockIdx.x * a.net.nparams;
+        const int H = a.net.h, NO = a.net.nout, quad = wave, wi = quad >> 1, wo = quad & 1;
+        auto put_block = [&](const f32x4& v, int l, int ib, int ob, int n_in, int n_out) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int in = 16 * ib + 4 * q + r, out = 16 * ob + c;
+                if (in < n_in && out < n_out) part[a.net.w_off[l] + in * n_out + out] = v[r];
+            }
+        };
+        {
+            f32x4 lo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lo[r] = __shfl_xor(A.first[r], 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A.first[r] += lo[r] * INV_LS;
+        }
+        if (quad < WB) {
+            put_block(A.first, 0, 0, quad, DIN, H);
+            put_block(A.last, NL, quad, 0, H, NO);
+            if (q == 0 && 16 * quad + c < H) part[a.net.b_off[0] + 16 * quad + c] = A.bias[0];
+        }
+        if (quad == 0 && q == 0 && c < NO) part[a.net.b_off[NL] + c] = A.bias[NL];
+#pragma unroll
+        for (int l = 1; l < NL; ++l) {
+#pragma unroll
+            for (int i = 0; i < IBW; ++i)
+#pragma unroll
+                for (int o = 0; o < OBW; ++o) put_block(A.mid[l - 1][i][o], l, wi * IBW + i, wo * OBW + o, H, H);
+            const bool owner = OBW == 1 ? wi == 0 : true;
+            const int ob = wo * OBW + (OBW == 1 ? 0 : wi);
+            if (owner && q == 0 && 16 * ob + c < H) part[a.net.b_off[l] + 16 * ob + c] = A.bias[l];
+        }
     }
 
     // forward + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
