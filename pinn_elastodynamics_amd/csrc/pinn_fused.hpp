@@ -925,7 +925,15 @@ struct Fused {
                 // this wave parks its share of it (the records it will bring back by LDS-DMA: same wave, same addresses, program order)
                 for (int l = 0; l < NL; ++l) {
                     lds_barrier();
+#ifdef PINN_X_FSTAMP
+                    fused_stamp(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, 106 + 2 * l);
+#endif
+#ifndef PINN_X_NOPARK
                     if (l + 1 <= NL - 1 && !kept_in_lds(l + 1)) park_image(scr_st, lane16, tile_lds, l + 1, quad);
+#endif
+#ifdef PINN_X_FSTAMP
+                    fused_stamp(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, 107 + 2 * l);
+#endif
                 }
             }
             WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend, ld);
@@ -1038,6 +1046,9 @@ struct Fused {
         const float* blast;                        // output-layer bias (constants not in LDS)
         int c, q;
         bool tracer;                               // workgroup 0, chain wave 0, lane 0
+#ifdef PINN_X_FSTAMP
+        long long* dbgp;
+#endif
         __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile) {
             scr = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES, 0x00020000);
         }
@@ -1053,6 +1064,9 @@ struct Fused {
             cbias = lds + CONST_OFF + q_ * 16;
             cw0 = lds + CONST_OFF + CONST_BIAS_F * 4 + q_ * 64;
             imgoff = img_record(c_, q_);
+#ifdef PINN_X_FSTAMP
+            dbgp = (long long*)a.dbg;
+#endif
             c = c_;
             q = q_;
             tracer = false;
@@ -1606,6 +1620,9 @@ struct Fused {
         u32x4 Bk[NS][1][1][NP];
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
+#ifdef PINN_X_FSTAMP
+            if (t % HB == 0 && x.tracer && x.dbgp && (l == 6 || l == 7)) x.dbgp[97 + 4 * (l - 6) + t / HB] = __builtin_readcyclecounter();
+#endif
             if (t % HB == 0) op_load(in, t / HB, Bk);
             fwd_kstep<0, 1>(Ar[(T0 + t) % RING], Bk, acc[t % HB]);
             fwd_request<PAR>(x, l, h, t + RING, Ar);
@@ -1639,11 +1656,31 @@ struct Fused {
     template <int PAR>
     static __device__ __forceinline__ void wide_fwd_layer(const Ctx& x, int l, int h, const char* in, char* outimg, u32x4 (&Af)[RING][1][FP]) {
         f32x4 acc[HB][NS];
+        if constexpr (CONST_LDS) {
 #pragma unroll
-        for (int j = 0; j < HB; ++j) acc_init(load_bias(x, l, half_block(h, j)), acc[j]);
-        half_gemm_fwd<PAR>(x, l, h, in, Af, acc);
+            for (int j = 0; j < HB; ++j) acc_init(load_bias(x, l, half_block(h, j)), acc[j]);
+            half_gemm_fwd<PAR>(x, l, h, in, Af, acc);
+        } else {
+            // constants from memory: as the accumulators' start value the biases are consumed right behind their request -- a full L2 round
+            // trip in front of every layer, behind everything the ring has in flight.  Requested here, added behind the layer's MFMAs.
+            f32x4 bias[HB];
+#pragma unroll
+            for (int j = 0; j < HB; ++j) {
+                bias[j] = load_bias(x, l, half_block(h, j));
+                acc_zero(acc[j]);
+            }
+            half_gemm_fwd<PAR>(x, l, h, in, Af, acc);
+#pragma unroll
+            for (int j = 0; j < HB; ++j) acc[j][0] += bias[j];
+        }
+#ifdef PINN_X_FSTAMP
+        if (x.tracer && x.dbgp) x.dbgp[44 + 2 * (l - 1)] = __builtin_readcyclecounter();
+#endif
         u32x4 out[NS][1][HR][NP];
         wide_fwd_epilogue<0>(acc, out);
+#ifdef PINN_X_FSTAMP
+        if (x.tracer && x.dbgp) x.dbgp[45 + 2 * (l - 1)] = __builtin_readcyclecounter();
+#endif
         half_store(outimg, h, out);
         if (kept_in_lds(l + 1)) half_store(x.imgS(l + 1), h, out);       // S_{NL-1} also into its reverse slot (KEEP_W)
     }
