@@ -184,7 +184,13 @@ struct Fused {
     // reference's trained weights is 5e-3 off in the first-layer blocks -- fp32: 2e-4 --, amplified by cancellation)
     static constexpr bool STATE_LO = !LDSOP && NP == 2 && !FASTSTATE;
     static constexpr unsigned SCRATCH_LO = (unsigned)((NL - 1) * IMG_B);          // byte offset of the low-part images
-    static constexpr unsigned SCRATCH_BYTES = (unsigned)((STATE_LO ? 2 : 1) * (NL - 1) * IMG_B);
+    // LSUM_MEM (the 3-D kernel): the per-lane loss sums live in a 4 KB tail of the tile's scratch image instead of 16 registers per lane.
+    // As registers they are live through the whole step and touched once: the compiler spilled them, and reloaded them in the head ONE BY
+    // ONE behind a full vmcnt(0) each -- 20 memory round trips, 21 k cycles of a 419 k step (tools/phase_trace_3d.py).  In memory: 12 loads
+    // in flight together, 12 adds, 12 stores per step (same wave, same addresses: program order).
+    static constexpr bool LSUM_MEM = LDSOP && DIN_ == 4;
+    static constexpr unsigned LSUM_OFF = (unsigned)((STATE_LO ? 2 : 1) * (NL - 1) * IMG_B);
+    static constexpr unsigned SCRATCH_BYTES = LSUM_OFF + (LSUM_MEM ? 16u * 256u : 0u);
     static __device__ __forceinline__ constexpr int slot_of(int L) { return (SLDS || WSLDS) ? L : (ONE_SLOT ? 0 : (L & 1)); }
 
     // The NG mid weight layers that the reverse sweep reaches first (L = NL-1 .. NL-NG) keep their accumulator blocks in memory
@@ -2325,6 +2331,12 @@ struct Fused {
 #pragma unroll
             for (int i = 0; i < LT; ++i) lsum[k][i] = 0.0f;
 
+        if constexpr (LSUM_MEM) {
+            if (half == 0) {
+#pragma unroll
+                for (int i = 0; i < LT; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, x.scr, x.lane16 >> 2, LSUM_OFF + i * 256, 0);
+            }
+        }
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
             float xin[4];
             bool valid;
@@ -2356,10 +2368,22 @@ struct Fused {
 #pragma unroll
                 for (int i = 0; i < LT; ++i) ls[i] = 0.0f;
                 fwd_head(a, x, valid, pidx, set, ls, acca, ZL);          // both halves: the same Z_NL; the loss sums count once
+                if constexpr (LSUM_MEM) {
+                    if (half == 0) {
+                        float run[LT];
 #pragma unroll
-                for (int k = 0; k < NSETS; ++k)
+                        for (int i = 0; i < LT; ++i) run[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x.scr, x.lane16 >> 2, LSUM_OFF + i * 256, 0));
 #pragma unroll
-                    for (int i = 0; i < LT; ++i) lsum[k][i] += (k == set && half == 0) ? ls[i] : 0.0f;
+                        for (int i = 0; i < LT; ++i) run[i] += ls[i];
+#pragma unroll
+                        for (int i = 0; i < LT; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, run[i]), x.scr, x.lane16 >> 2, LSUM_OFF + i * 256, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NSETS; ++k)
+#pragma unroll
+                        for (int i = 0; i < LT; ++i) lsum[k][i] += (k == set && half == 0) ? ls[i] : 0.0f;
+                }
                 wide_reverse(a, x, xin, half, ZL);
             } else {
                 u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
@@ -2372,6 +2396,12 @@ struct Fused {
 #pragma unroll
                     for (int i = 0; i < LT; ++i) lsum[k][i] += (k == set) ? ls[i] : 0.0f;
                 reverse_tile(a, x, xin, B, ZL);
+            }
+        }
+        if constexpr (LSUM_MEM) {
+            if (half == 0) {
+#pragma unroll
+                for (int i = 0; i < LT; ++i) lsum[0][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x.scr, x.lane16 >> 2, LSUM_OFF + i * 256, 0));
             }
         }
 #pragma unroll

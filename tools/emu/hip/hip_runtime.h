@@ -233,6 +233,17 @@ inline void __builtin_amdgcn_raw_buffer_store_b64(emu_u32x2 v, emu_buffer_rsrc r
     memcpy(r.base + voff + soff, &v, 8);
 }
 
+inline unsigned __builtin_amdgcn_raw_buffer_load_b32(emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
+    if (voff + soff + 4u > r.bytes) { fprintf(stderr, "emu: buffer load out of range (%u + %u > %u)\n", voff, soff, r.bytes); abort(); }
+    unsigned v;
+    memcpy(&v, r.base + voff + soff, 4);
+    return v;
+}
+inline void __builtin_amdgcn_raw_buffer_store_b32(unsigned v, emu_buffer_rsrc r, unsigned voff, unsigned soff, int) {
+    if (voff + soff + 4u > r.bytes) { fprintf(stderr, "emu: buffer store out of range (%u + %u > %u)\n", voff, soff, r.bytes); abort(); }
+    memcpy(r.base + voff + soff, &v, 4);
+}
+
 inline unsigned long long emu_cycle_counter() { static unsigned long long t = 0; return t += 100; }
 #define __builtin_readcyclecounter emu_cycle_counter
 
