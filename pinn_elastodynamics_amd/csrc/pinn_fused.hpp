@@ -188,7 +188,7 @@ struct Fused {
     // As registers they are live through the whole step and touched once: the compiler spilled them, and reloaded them in the head ONE BY
     // ONE behind a full vmcnt(0) each -- 20 memory round trips, 21 k cycles of a 419 k step (tools/phase_trace_3d.py).  In memory: 12 loads
     // in flight together, 12 adds, 12 stores per step (same wave, same addresses: program order).
-    static constexpr bool LSUM_MEM = LDSOP && DIN_ == 4;
+    static constexpr bool LSUM_MEM = NS_ == 5 && DIN_ == 4;      // (the plate's five-stream kernels, 8 sums: measured no gain at width 64, slower at 96)
     static constexpr unsigned LSUM_OFF = (unsigned)((STATE_LO ? 2 : 1) * (NL - 1) * IMG_B);
     static constexpr unsigned SCRATCH_BYTES = LSUM_OFF + (LSUM_MEM ? 16u * 256u : 0u);
     static __device__ __forceinline__ constexpr int slot_of(int L) { return (SLDS || WSLDS) ? L : (ONE_SLOT ? 0 : (L & 1)); }
@@ -2316,6 +2316,17 @@ struct Fused {
         }
     }
 
+    // this step's loss terms onto the tile's in-memory running sums (LSUM_MEM): all loads in flight together, then the adds, then the stores
+    static __device__ __forceinline__ void lsum_add(const Ctx& x, const float (&ls)[LT]) {
+        float run[LT];
+#pragma unroll
+        for (int i = 0; i < LT; ++i) run[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x.scr, x.lane16 >> 2, LSUM_OFF + i * 256, 0));
+#pragma unroll
+        for (int i = 0; i < LT; ++i) run[i] += ls[i];
+#pragma unroll
+        for (int i = 0; i < LT; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, run[i]), x.scr, x.lane16 >> 2, LSUM_OFF + i * 256, 0);
+    }
+
     static __device__ __forceinline__ void chain_role(const FusedArgs& a, char* lds, int wave4, int lane, int c, int q) {
         // LDSOP: two waves per tile (tile = wave & 1, half = wave >> 1); otherwise one wave per tile
         const int wave = LDSOP ? (wave4 & 1) : wave4, half = LDSOP ? (wave4 >> 1) : 0;
@@ -2369,15 +2380,7 @@ struct Fused {
                 for (int i = 0; i < LT; ++i) ls[i] = 0.0f;
                 fwd_head(a, x, valid, pidx, set, ls, acca, ZL);          // both halves: the same Z_NL; the loss sums count once
                 if constexpr (LSUM_MEM) {
-                    if (half == 0) {
-                        float run[LT];
-#pragma unroll
-                        for (int i = 0; i < LT; ++i) run[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(x.scr, x.lane16 >> 2, LSUM_OFF + i * 256, 0));
-#pragma unroll
-                        for (int i = 0; i < LT; ++i) run[i] += ls[i];
-#pragma unroll
-                        for (int i = 0; i < LT; ++i) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, run[i]), x.scr, x.lane16 >> 2, LSUM_OFF + i * 256, 0);
-                    }
+                    if (half == 0) lsum_add(x, ls);
                 } else {
 #pragma unroll
                     for (int k = 0; k < NSETS; ++k)
@@ -2391,10 +2394,14 @@ struct Fused {
 #pragma unroll
                 for (int i = 0; i < LT; ++i) ls[i] = 0.0f;
                 forward_tile(a, x, xin, valid, pidx, set, ls, B, ZL);
+                if constexpr (LSUM_MEM) {
+                    lsum_add(x, ls);
+                } else {
 #pragma unroll
-                for (int k = 0; k < NSETS; ++k)
+                    for (int k = 0; k < NSETS; ++k)
 #pragma unroll
-                    for (int i = 0; i < LT; ++i) lsum[k][i] += (k == set) ? ls[i] : 0.0f;
+                        for (int i = 0; i < LT; ++i) lsum[k][i] += (k == set) ? ls[i] : 0.0f;
+                }
                 reverse_tile(a, x, xin, B, ZL);
             }
         }
