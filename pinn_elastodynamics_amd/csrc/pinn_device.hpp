@@ -122,6 +122,44 @@ __device__ __forceinline__ void split2u<OpF16>(float a, float b, uint32_t& hi, u
     lo = l;
 }
 #endif
+// Two pairs at once.  v_fma_mixhi_f16 writes the other half of the register its v_fma_mixlo_f16 has just written: issued right behind it, it
+// waits for that result -- a dependent vector instruction issues after 8.3 cycles, an independent one after 5 (tools/probes/
+// valu_dep_probe.hip) -- and inside one asm statement the compiler cannot put anything in between.  With two pairs the statement
+// alternates them: lo, lo, hi, hi.
+template <class Op>
+__device__ __forceinline__ void split4(float a, float b, float c, float d, uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
+    split2<Op>(a, b, h0, l0);
+    split2<Op>(c, d, h1, l1);
+}
+template <class Op>
+__device__ __forceinline__ void split4u(float a, float b, float c, float d, uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
+    split2u<Op>(a, b, h0, l0);
+    split2u<Op>(c, d, h1, l1);
+}
+#if defined(__AMDGCN__) && !defined(PINN_GENERIC_SPLIT) && !defined(PINN_X_SPLIT2)
+template <>
+__device__ __forceinline__ void split4<OpF16>(float a, float b, float c, float d, uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
+    const uint32_t ha = pack2<OpF16>(a, b), hb = pack2<OpF16>(c, d);
+    const float nls = -OpF16::LO_SCALE;
+    const float ta = a * OpF16::LO_SCALE, tb = b * OpF16::LO_SCALE, tc = c * OpF16::LO_SCALE, td = d * OpF16::LO_SCALE;
+    uint32_t la, lb;
+    asm("v_fma_mixlo_f16 %0, %2, %4, %5 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %1, %3, %4, %7 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, %4, %6 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %1, %3, %4, %8 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(la), "=&v"(lb)
+        : "v"(ha), "v"(hb), "s"(nls), "v"(ta), "v"(tb), "v"(tc), "v"(td));
+    h0 = ha; h1 = hb; l0 = la; l1 = lb;
+}
+template <>
+__device__ __forceinline__ void split4u<OpF16>(float a, float b, float c, float d, uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
+    const uint32_t ha = pack2<OpF16>(a, b), hb = pack2<OpF16>(c, d);
+    uint32_t la, lb;
+    asm("v_fma_mixlo_f16 %0, %2, -1.0, %4 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %1, %3, -1.0, %6 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %2, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %1, %3, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(la), "=&v"(lb)
+        : "v"(ha), "v"(hb), "v"(a), "v"(b), "v"(c), "v"(d));
+    h0 = ha; h1 = hb; l0 = la; l1 = lb;
+}
+#endif
 // fp16 operands read straight out of a packed dword by the mixed-precision FMA (HALF = 0 / 1 selects the low / high half):
 //   fma<HALF>(w, b, c) = float(half(w)) * b + c        one_minus_sq<HALF>(w) = 1 - float(half(w))^2        sum2<HALF>(hi, lo)
 // Only the gfx950 build of the fp16 operand type has it; everything else converts first.
@@ -409,8 +447,7 @@ struct Chain {
                 const float* v = vals[s][nb];
                 uint32_t h0, h1, l0 = 0, l1 = 0;
                 if (NP == 2) {
-                    split2<Op>(v[0], v[1], h0, l0);
-                    split2<Op>(v[2], v[3], h1, l1);
+                    split4<Op>(v[0], v[1], v[2], v[3], h0, h1, l0, l1);
                     Bn[s][nb][MB >> 1][NP - 1][(MB & 1) * 2 + 0] = l0;
                     Bn[s][nb][MB >> 1][NP - 1][(MB & 1) * 2 + 1] = l1;
                 } else {

@@ -1194,8 +1194,7 @@ struct Fused {
         for (int s = 0; s < NS; ++s) {
             uint32_t h0, h1, l0 = 0, l1 = 0;
             if constexpr (NP == 2) {
-                split2u<Op>(vals[s][0], vals[s][1], h0, l0);
-                split2u<Op>(vals[s][2], vals[s][3], h1, l1);
+                split4u<Op>(vals[s][0], vals[s][1], vals[s][2], vals[s][3], h0, h1, l0, l1);
                 Bn[s][0][MB >> 1][1][(MB & 1) * 2 + 0] = l0;
                 Bn[s][0][MB >> 1][1][(MB & 1) * 2 + 1] = l1;
             } else {
@@ -1210,8 +1209,13 @@ struct Fused {
     // tanh and the scaled derivative from a scaled pre-activation  zs = WS * z :
     //   e = 2^(zs * 2 log2(e) / WS),  r = 1/(1 + e),  h = 1 - 2r,  sds = (1 - h^2)/WS = (4/WS) r (1 - r)
     static __device__ __forceinline__ void tanh_scaled(float zs, float& h, float& sds) {
+#ifdef PINN_X_NOTRANS      // (timing ablation: no transcendental instructions; results garbage but finite)
+        const float e = zs * (2.8853900817779268f * INV_WS);
+        const float r = 0.25f + 0.001f * e;
+#else
         const float e = __builtin_amdgcn_exp2f(zs * (2.8853900817779268f * INV_WS));
         const float r = __builtin_amdgcn_rcpf(1.0f + e);
+#endif
         h = 1.0f - 2.0f * r;
         const float c4 = r * (4.0f * INV_WS);
         sds = c4 - c4 * r;
@@ -1330,17 +1334,27 @@ struct Fused {
             if constexpr (MB == 0) {
                 if (!next_is_out) bb[1] = load_bias(x, l + 1, 1);       // behind its use just above
             }
+#ifndef PINN_X_NOFWDMFMA
             fwd_ksteps<0, KS, KS>(A[MB + 1], in, anxt);
+#endif
+#ifndef PINN_X_NOFWDVALU
             fwd_valu<MB>(acur, out);
+#endif
             if constexpr (NS == 4 && NP == 2) interleave<NS * KS * P3, 2>();
         } else {
             // last block: the next layer's block 0 starts on the finished half of `out`
             acc_init(bb[0], anxt);
+#ifndef PINN_X_NOFWDMFMA
             fwd_ksteps<0, KOVL, KS>(A[0], out, anxt);
+#endif
+#ifndef PINN_X_NOFWDVALU
             fwd_valu<MB>(acur, out);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             operands_ready<KS>(out, KS - 1);
+#ifndef PINN_X_NOFWDMFMA
             fwd_ksteps<KOVL, KS, KS>(A[0], out, anxt);
+#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MB + 1 < WB) fwd_step<MB + 1>(x, l, nfrag0, next_is_out, in, out, A, acca, accb, bb);
