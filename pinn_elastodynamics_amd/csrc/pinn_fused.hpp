@@ -1246,6 +1246,31 @@ struct Fused {
     template <int MB, int KSF = KS>
     static __device__ __forceinline__ void fwd_valu(const f32x4 (&acc)[NS], u32x4 (&Bn)[NS][1][KSF][NP]) {
         float vals[NS][4];
+#ifdef PINN_X_STAGED      // (experiment: stage-major source order -- four independent chains side by side -- for builds without the machine scheduler)
+        {
+            float e[4], rr[4], c4[4], sds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = acc[0][r] * (2.8853900817779268f * INV_WS);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(e[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e[r] = 1.0f + e[r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rr[r] = __builtin_amdgcn_rcpf(e[r]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vals[0][r] = 1.0f - 2.0f * rr[r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) c4[r] = rr[r] * (4.0f * INV_WS);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sds[r] = c4[r] - c4[r] * rr[r];
+#pragma unroll
+            for (int s = 1; s <= NT; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vals[s][r] = sds[r] * acc[s][r];
+            emit_state<MB, KSF>(Bn, vals);
+            return;
+        }
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float h, sds;
@@ -2455,6 +2480,13 @@ struct Fused {
         }
         if constexpr (MERGE) {
             merged_role(a, lds, wave8, lane, c, q);
+#if defined(PINN_X_8CHAIN)      // timing experiment: waves 4..7 run the chain role too (on the LDS / scratch of tiles 0..3: results garbage)
+        } else if (wave8 >= 4) {
+            chain_role(a, lds, wave8 - 4, lane, c, q);
+#elif defined(PINN_X_4CHAIN)    // ... its reference: the four chain waves alone, no weight-gradient role
+        } else if (wave8 >= 4) {
+            return;
+#endif
         } else if (wave8 >= 4) {
             wgrad_role(a, lds, wave8 - 4, lane, c, q);
         } else {

@@ -1,7 +1,11 @@
+#!/bin/bash
+# Dev tool (GPU box): instruction-fetch counters of the fused launch (tools/exp_run.py prod): requests / hits / misses of the instruction cache
+# and the accumulated number of fetches in flight (SQ_IFETCH_LEVEL / SQ_IFETCH = average fetch latency in cycles of the counter).
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --list-avail 2>/dev/null | grep -i -o "SQC_ICACHE[A-Z_]*\|SQ_IFETCH[A-Z_]*\|SQC_INST[A-Z_]*\|SQ_INST_CYCLES[A-Z_]*\|SQ_WAIT_IFETCH[A-Z_]*\|SQ_[A-Z_]*IFETCH[A-Z_]*" | sort -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/icache; mkdir -p $OUT
 rocprofv3 --pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE --kernel-trace --output-format csv -d $OUT/p1 -o p -- python $GRAFT_REPO_ROOT/tools/exp_run.py prod > $OUT/p1.log 2>&1
+rocprofv3 --pmc SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVE_CYCLES SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/p2 -o p -- python $GRAFT_REPO_ROOT/tools/exp_run.py prod > $OUT/p2.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace --output-format csv -d $OUT/p3 -o p -- python $GRAFT_REPO_ROOT/tools/exp_run.py prod > $OUT/p3.log 2>&1
 python - <<PY
 import csv, glob, collections
 acc = collections.defaultdict(list)
@@ -13,4 +17,3 @@ for k in sorted(acc):
     v = sorted(acc[k])[len(acc[k]) // 2:]
     print(k, '%.4e' % v[len(v)//2], len(acc[k]))
 PY
-tail -3 $OUT/p1.log
