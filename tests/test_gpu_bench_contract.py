@@ -32,8 +32,10 @@ def test_bench_line(cfg, extra):
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    if cfg in ("wave", "plate"):        # the fused kernel's own launch time, measured with HIP events in this run
-        assert r["avg_launch_ms"] > 0 and r["avg_launch_ms"] <= d["ms_per_step"] * 1.05
+    # the fused kernel's own launch time, measured with HIP events in this run (nc3d: the fused 3-D kernel since round 3)
+    assert r["avg_launch_ms"] > 0 and r["avg_launch_ms"] <= d["ms_per_step"] * 1.05
+    if cfg == "nc3d":
+        assert "fused_wave_kernel" in r["kernel"] and r["launches_per_step"] == 1 and "fused" in d["config"]["workload"]
     # at least one second of timed work whatever --steps is: the K-step block is repeated, the median block is reported
     tb = d["timed_blocks"]
     assert tb["steps_per_block"] == 4 and tb["count"] >= 1 and tb["count"] * tb["block_ms_median"] >= 900.0 or tb["count"] == 64
