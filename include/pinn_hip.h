@@ -224,7 +224,9 @@ int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_fla
                    double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 
 /* Testing hook (process-wide): 0 forces the two-kernel path (chain + wgrad kernels) even where the
- * fused kernel applies; returns the previous setting.  Both paths compute the same numbers. */
+ * fused kernel applies; 1 (default) prefers the fused kernel; 2 = as 1, with the experimental
+ * one-wave-per-SIMD variant of the 8 x 64 wave kernel (slower: DESIGN.md section 6).  Returns the previous
+ * setting.  All paths compute the same numbers. */
 int pinn_debug_set_fused(int enable);
 /* Profiling hook (process-wide): device buffer of 128 uint64 that the fused kernel fills with shader-clock
  * stamps of its phases (workgroup 0 only); NULL turns it off. */
