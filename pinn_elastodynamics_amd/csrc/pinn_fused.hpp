@@ -91,7 +91,9 @@ __device__ __forceinline__ unsigned in_loop(unsigned v) {
 }
 
 __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int slot) {
+#ifndef PINN_X_NOSTAMP
     if (a.dbg != nullptr && who) a.dbg[slot] = __builtin_readcyclecounter();
+#endif
 }
 
 // NS = 4: value + three tangent streams, residual head of net_f_sig (the collocation set).  NS = 1: value stream only, head
