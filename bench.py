@@ -2,8 +2,9 @@
 """Benchmark of the hot path: collocation points per second through the PDE-residual loss +
 parameter gradient (+ all-reduce + Adam).
 
-  python bench.py --gpus N --steps K --warmup W [--config wave|plate|nc3d] [--scaling weak|strong]
-  (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W [--config wave|plate|nc3d] [--scaling weak|strong] [--always-reduce]
+  (N>1: one rank per GPU.  Started under torch.distributed.run the ranks read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+  environment; started plainly -- the way the N = 1 bench is started -- it launches its own N ranks on this node.)
 
 --config wave  (default) BASELINE.json configs[1] / configs[3]: 2-D elastic wave (infinite domain), 8x64 tanh MLP, 2 M collocation
                points per GPU (weak scaling; x8 GPUs = 16 M = configs[3]) or --global-points in total (--scaling strong, the north
@@ -135,17 +136,31 @@ def cpu_baseline_plate(c, sample_pts=65536, reps=2):
                       f"{dt:.2f} s per pass"}
 
 
+def kernel_source_sha():
+    """sha256 (16 hex digits) of the kernel sources: tools/pmc_collect.sh stamps it into every PMC summary it writes"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("pinn_fused.hpp", "pinn_device.hpp", "pinn_host.hpp"):
+        h.update(open(os.path.join(ROOT, "pinn_elastodynamics_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def traffic_from_profiles(name):
     """HBM-side bytes per launch of the dominant kernel from this round's committed PMC passes (separate rocprofv3 --pmc runs of the
-    same command, profiles/README.md) -- NOT measured in this run, hence its own key."""
-    for rnd in ("r03", "r02", "r01"):
+    same launches, profiles/README.md) -- NOT measured in this run, hence its own key.  A summary collected on other kernel sources than
+    the ones in this tree (kernel_source_sha) is refused: the key then says which file is stale instead of quoting its bytes."""
+    sha = kernel_source_sha()
+    for rnd in ("r04",):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_summary.json")))
-            return {"bytes_per_launch": pm.get("hbm_bytes_per_launch"), "source": f"profiles/{rnd}_{name}_pmc_summary.json",
+            if pm.get("kernel_source_sha") != sha:
+                return {"bytes_per_launch": None, "stale": f"profiles/{rnd}_{name}_pmc_summary.json was collected on kernel sources "
+                                                            f"{pm.get('kernel_source_sha')}, this tree is {sha}"}
+            return {"bytes_per_launch": pm.get("hbm_bytes_per_launch"), "source": f"profiles/{rnd}_{name}_pmc_summary.json", "kernel_source_sha": sha,
                     "ea_read_bytes": pm.get("ea_read_bytes_per_launch"), "ea_write_bytes": pm.get("ea_write_bytes_per_launch"),
                     "note": "L2<->fabric request bytes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE; ea_*: TCC_EA0 request counters of the same "
-                            "passes at 64 B per request -- a read request fetches a 128-byte line); parked states (high and low parts) 28.7 GB + "
-                            "in-memory accumulators 5 GB + weights / inputs / partials; MALL vs HBM is not observable from the L2 (profiles/README.md)"}
+                            "passes at 64 B per request -- a read request fetches a 128-byte line); the kernel's own parked states and in-memory "
+                            "weight-gradient sums (DESIGN.md section 6); MALL vs HBM is not observable from the L2 (profiles/README.md)"}
         except Exception:
             continue
     return None
@@ -166,23 +181,46 @@ def main():
     ap.add_argument("--chunk-points", type=int, default=1 << 18, help="points held in the spill workspace per pass (two-kernel path)")
     ap.add_argument("--ramp-steps", type=int, default=None, help="untimed clock-ramp steps before the warm-up steps")
     ap.add_argument("--min-timed-seconds", type=float, default=1.0, help="repeat the K-step timed block until this much timed work has run (0: one block)")
+    ap.add_argument("--always-reduce", action="store_true", help="run the step's gradient all-reduce (and the buffer handling around it) also in a "
+                    "process group of ONE rank: what one of N GPUs does per step, collective included, measured on a single GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-config", action="store_true")
     ap.add_argument("--extra-modes", default="bf16,f16x3_fp16state",
                     help="comma list of other modes to time briefly (wave, rank 0 / N=1): precision modes, or f16x3_fp16state = f16x3 with PINN_FLAG_STATE_FP16")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started without a launcher (`python bench.py --gpus N ...`, the form of the N = 1 run): become the launcher -- N ranks on this
+        # node under torch.distributed.run, one per GPU, rendezvous on 127.0.0.1; rank 0's JSON line is this process's output.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if torch.cuda.device_count() < args.gpus:
+            env.setdefault("PINN_BENCH_BACKEND", "gloo")         # fewer GPUs than ranks (a 1-GPU box): dry run, ranks share the devices
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=env))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     backend = os.environ.get("PINN_BENCH_BACKEND", "nccl")        # "gloo": dry run of the multi-process path on a 1-GPU box
     if backend != "nccl":
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    if world > 1:
+    if world > 1 or args.always_reduce:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:                                            # --always-reduce on one GPU: a process group of one rank
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             torch.distributed.init_process_group("nccl", device_id=dev)
         else:
@@ -205,7 +243,8 @@ def main():
         Collo = synth_points(n_global, 1111)
         SRC, IC = ricker_source(), ic_grid()
         eng = HipEngine(layers, precision=args.precision, device=dev, max_points=args.chunk_points)
-        model = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, case="infinite", engine=eng, seed=1111, verbose=False)
+        model = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, case="infinite", engine=eng, seed=1111, verbose=False,
+                        always_reduce=args.always_reduce)
         step = lambda k: model.train(k, 1e-3, 1)
         workload = (f"2D elastic wave (infinite), 8x{args.width} tanh MLP, {pts_per_rank} collocation pts per GPU + IC 10201 + SRC 70400, Adam (TF1 rule) step "
                     f"incl. gradient all-reduce ({'BASELINE configs[1]; x8 GPUs weak = configs[3]' if args.width == 64 else 'a net width of the reference scripts, not a BASELINE config'}); {PRECISION_NOTE}")
@@ -223,7 +262,7 @@ def main():
         layers = c["uv_layers"]
         streams, label = 5, f"8x{args.width} plate"
         model = PINN(c["Collo"], c["HOLE"], c["IC"], c["LF"], c["RT"], c["UP"], c["LW"], c["DIST"], c["uv_layers"], c["dist_layers"], c["part_layers"],
-                     c["lb"], c["ub"], precision=args.precision, seed=1111, verbose=False)
+                     c["lb"], c["ub"], precision=args.precision, seed=1111, verbose=False, always_reduce=args.always_reduce)
         eng = model.eng["uv"]
         step = lambda k: model.train(k, 1e-3)
         workload = (f"2D plate with hole (hard BC: composite P + D*N, nested u_tt, plane stress), 8x{args.width} tanh MLP + frozen 4x20 distance / particular "
@@ -235,7 +274,8 @@ def main():
         layers = c["uv_layers"]
         streams, label = 5, "10x128 3-D"
         eng = HipEngine(layers, precision=args.precision, device=dev, max_points=min(args.chunk_points, 1 << 17))
-        model = NavierCauchy3D(c["Collo"], c["SRC"], c["IC"], c["TOP"], layers, c["lb"], c["ub"], engine=eng, seed=1111, verbose=False)
+        model = NavierCauchy3D(c["Collo"], c["SRC"], c["IC"], c["TOP"], layers, c["lb"], c["ub"], engine=eng, seed=1111, verbose=False,
+                               always_reduce=args.always_reduce)
         step = lambda k: model.train(k, 1e-3, 1)
         workload = (f"3D Navier-Cauchy half space (build-side extension, not in the reference; parity unpinned), 10x128 tanh MLP on (x,y,z,t), 12 outputs, "
                     f"{pts_per_rank} collocation pts per GPU + IC/TOP 20000 each + SRC 20000, Adam step incl. gradient all-reduce (BASELINE configs[4]: "
@@ -281,6 +321,16 @@ def main():
         dts.append(d)
     dt = float(np.median(dts))
     value = n_global * steps / dt
+
+    # ---- launch time of the dominant kernel under the SAME conditions as the timed steps: one more block of `steps` steps with the
+    # library's asynchronous event ring armed (HIP events around every fused launch on its own stream, in stream order, no
+    # synchronisation between the steps: include/pinn_hip.h).  Every rank runs the block (the steps hold collectives).
+    eng.lib.profile_ring_arm(4096)
+    step(steps)
+    barrier()
+    ring_ms, ring_streams = eng.lib.profile_ring_read()
+    collo_ms = ring_ms[ring_streams >= 4]
+    side_ms = ring_ms[ring_streams == 1]
     final_loss = float(losses[-1][-1]) if isinstance(losses, (tuple, list)) and len(losses[-1]) else None
 
     out = {
@@ -297,16 +347,20 @@ def main():
     if rank == 0:
         issued = (8 * 3 + 4 * 2) / 12.0 if args.precision in ("f16x3", "bf16x3") else 1.0
         if cfg == "wave":
-            # ---- roofline of the dominant kernel, HIP events on the launch stream (pinn_wave2d_loss_grad_profile)
-            x, y, t = (a[:pts_per_rank] for a in model._collo)
-            tw = [1.0 / pts_per_rank] * 7
-            eng.wave_loss_grad_profile(model.theta, x, y, t, LB, UB, True, tw)
-            reps = 5
+            # ---- roofline of the dominant kernel: HIP events around its launches in the running step loop (the ring block above); on
+            # the two-kernel path (no fused launch recorded) the synchronous per-kernel profile of one call
             acc = {"repack": 0.0, "chain": 0.0, "wgrad": 0.0, "reduce": 0.0}
-            for _ in range(reps):
-                ms = eng.wave_loss_grad_profile(model.theta, x, y, t, LB, UB, True, tw)
-                for k in acc:
-                    acc[k] += ms[k] / reps
+            if collo_ms.size:
+                acc["chain"] = float(collo_ms.mean())
+            else:
+                x, y, t = (a[:pts_per_rank] for a in model._collo)
+                tw = [1.0 / pts_per_rank] * 7
+                eng.wave_loss_grad_profile(model.theta, x, y, t, LB, UB, True, tw)
+                reps = 5
+                for _ in range(reps):
+                    ms = eng.wave_loss_grad_profile(model.theta, x, y, t, LB, UB, True, tw)
+                    for k in acc:
+                        acc[k] += ms[k] / reps
             fused = acc["wgrad"] == 0.0          # the fused persistent kernel reports its whole time in the "chain" slot
             n_launch = 1 if fused else -(-pts_per_rank // args.chunk_points)
             kflop = flop_pt if fused else flop_pt * 8 // 12
@@ -315,8 +369,11 @@ def main():
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
                                "traffic": None, "traffic_from_profiles": traffic_from_profiles("fused") if fused and args.precision == "f16x3" and args.width == 64 else None,
                                "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch, "algorithmic_flop_per_point": kflop,
+                               "launches_timed": int(collo_ms.size), "launch_ms_min_max": [float(collo_ms.min()), float(collo_ms.max())] if collo_ms.size else None,
+                               "side_sets_launch_ms": float(side_ms.mean()) if side_ms.size else None,
                                "issued_mfma_tflops": tflops * issued,
-                               "note": "achieved = algorithmic flops (one product per contraction) / HIP-event launch time; the f16x3 mode issues 3 MFMAs per "
+                               "note": "achieved = algorithmic flops (one product per contraction) / mean HIP-event duration of the launches of one "
+                                       "more block of steps behind the timed ones (events in stream order, nothing synchronises in between); the f16x3 mode issues 3 MFMAs per "
                                        "product in the forward / reverse chain and 2 in the weight gradient, so a 100 %-busy matrix pipe is frac 0.375. "
                                        "Measured limiter: the SIMD's instruction issue, not a pipe (DESIGN.md section 6). traffic is not measured in this "
                                        "run (PMC counters need rocprofv3); see traffic_from_profiles"}
@@ -324,17 +381,7 @@ def main():
         elif cfg == "plate" and eng.lib.supported_width(layers[1]) <= 96 and len(layers) - 2 in (4, 8):
             # ---- the five-stream instantiation of the fused kernel: HIP events around the kernel on the launch stream (process-wide
             # profiling hook of the library, include/pinn_hip.h)
-            x, y, t = model._collo
-            tw = [1.0 / pts_per_rank] * 5
-            prof = eng.lib.set_profile_buffer(True)
-            acc = {"repack": 0.0, "chain": 0.0, "wgrad": 0.0, "reduce": 0.0}
-            reps = 5
-            for i in range(reps + 1):
-                eng.plate_loss_grad(model.theta["uv"], x, y, t, model.lb, model.ub, False, model._frozen_collo, tw, model.E, model.mu, model.rho)
-                if i > 0:
-                    for j, k in enumerate(acc):
-                        acc[k] += float(prof[j]) / reps
-            eng.lib.set_profile_buffer(False)
+            acc = {"repack": 0.0, "chain": float(collo_ms.mean()) if collo_ms.size else 0.0, "wgrad": 0.0 if collo_ms.size else 1.0, "reduce": 0.0}
             fused = acc["wgrad"] == 0.0
             tflops = flop_pt * pts_per_rank / (acc["chain"] * 1e-3) / 1e12 if fused else 0.0
             out["roofline"] = {"kernel": "fused_wave_kernel<..., NS = 5> (forward with the second time derivative + plate head + reverse chain + weight gradient)",
@@ -347,17 +394,20 @@ def main():
             out["kernel_ms_per_step"] = acc
         elif cfg == "nc3d" and args.precision == "f16x3" and layers[1:-1] == [128] * 10:
             # ---- the 3-D instantiation of the fused kernel (Fused<..., NL = 10, NS = 5, DIN = 4>): HIP events around the collocation launch
-            x, y, z, t = model._rows(0, model._n_collo)
-            tw = [1.0 / pts_per_rank] * 12
-            prof = eng.lib.set_profile_buffer(True)
             acc = {"repack": 0.0, "chain": 0.0, "wgrad": 0.0, "reduce": 0.0}
-            reps = 3
-            for i in range(reps + 1):
-                eng.nc3d_loss_grad(model.theta, x, y, z, t, model.lb, model.ub, model.normalize, tw, model.E, model.mu, model.rho)
-                if i > 0:
-                    for j, k in enumerate(acc):
-                        acc[k] += float(prof[j]) / reps
-            eng.lib.set_profile_buffer(False)
+            if collo_ms.size:
+                acc["chain"] = float(collo_ms.mean())
+            else:
+                x, y, z, t = model._rows(0, model._n_collo)
+                tw = [1.0 / pts_per_rank] * 12
+                prof = eng.lib.set_profile_buffer(True)
+                reps = 3
+                for i in range(reps + 1):
+                    eng.nc3d_loss_grad(model.theta, x, y, z, t, model.lb, model.ub, model.normalize, tw, model.E, model.mu, model.rho)
+                    if i > 0:
+                        for j, k in enumerate(acc):
+                            acc[k] += float(prof[j]) / reps
+                eng.lib.set_profile_buffer(False)
             fused = acc["wgrad"] == 0.0
             n_launch = 1 if fused else -(-pts_per_rank // min(args.chunk_points, 1 << 17))
             t_ms = acc["chain"] if fused else acc["chain"] + acc["wgrad"]

@@ -224,9 +224,8 @@ int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_fla
                    double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
 
 /* Testing hook (process-wide): 0 forces the two-kernel path (chain + wgrad kernels) even where the
- * fused kernel applies; 1 (default) prefers the fused kernel; 2 = as 1, with the experimental
- * one-wave-per-SIMD variant of the 8 x 64 wave kernel (slower: DESIGN.md section 6).  Returns the previous
- * setting.  All paths compute the same numbers. */
+ * fused kernel applies; 1 (default) prefers the fused kernel.  Returns the previous setting.  Both paths
+ * compute the same numbers to the precision mode's accuracy (tests/test_gpu_parity.py). */
 int pinn_debug_set_fused(int enable);
 /* Profiling hook (process-wide): device buffer of 128 uint64 that the fused kernel fills with shader-clock
  * stamps of its phases (workgroup 0 only); NULL turns it off. */
@@ -236,6 +235,13 @@ void pinn_debug_set_stamp_buffer(void* device_u64x128);
  * reductions} of that call (what pinn_wave2d_loss_grad_profile does for one entry point, here for all of them: bench.py's
  * roofline of the plate / 3-D kernels).  NULL turns it off. */
 void pinn_debug_set_profile_buffer(float* host_ms4);
+/* Profiling hook (process-wide), asynchronous: _arm(k) starts recording the next k (<= 4096) launches of the fused kernel: each is
+ * bracketed by HIP events on its call's stream and nothing synchronises, so a running step loop keeps its back-to-back stream order
+ * (bench.py's roofline leg: the launch time under the same conditions as the timed steps).  _read() stops the recording, waits for the
+ * recorded launches, writes their milliseconds and stream counts (4 / 5: a collocation set, 1: the value-only side sets) in launch
+ * order and returns how many there were.  Either output may be NULL. */
+int pinn_debug_profile_ring_arm(int max_launches);
+int pinn_debug_profile_ring_read(float* ms_out, int* streams_out, int capacity);
 
 const char* pinn_error_string(int code);
 int pinn_abi_version(void);

@@ -97,6 +97,10 @@ class PinnLib:
         L.pinn_debug_set_profile_buffer.restype = None
         L.pinn_debug_set_fused.argtypes = [i32]
         L.pinn_debug_set_fused.restype = i32
+        L.pinn_debug_profile_ring_arm.argtypes = [i32]
+        L.pinn_debug_profile_ring_arm.restype = i32
+        L.pinn_debug_profile_ring_read.argtypes = [vp, vp, i32]
+        L.pinn_debug_profile_ring_read.restype = i32
 
     # -- helpers -------------------------------------------------------------------------------
     @staticmethod
@@ -137,6 +141,19 @@ class PinnLib:
         self.lib.pinn_debug_set_profile_buffer(None)      # (the module-level buffer stays allocated: a launch in flight may still write to it)
         return None
 
+    def profile_ring_arm(self, max_launches: int) -> int:
+        """Start recording the next launches of the fused kernel with HIP events in stream order, nothing synchronises (include/pinn_hip.h)"""
+        return int(self.lib.pinn_debug_profile_ring_arm(int(max_launches)))
+
+    def profile_ring_read(self):
+        """Stop the recording and return (milliseconds, streams) of the recorded launches, in launch order"""
+        import numpy as _np
+        cap = 4096
+        ms = (C.c_float * cap)()
+        tags = (C.c_int * cap)()
+        m = int(self.lib.pinn_debug_profile_ring_read(C.cast(ms, C.c_void_p), C.cast(tags, C.c_void_p), cap))
+        return _np.array(ms[:m], dtype=_np.float64), _np.array(tags[:m], dtype=_np.int64)
+
     def profiling(self):
         """Context manager around set_profile_buffer: the hook is always reset, whatever the body raises."""
         lib = self
@@ -151,8 +168,8 @@ class PinnLib:
         return _Ctx()
 
     def set_fused(self, enable) -> int:
-        """0: two-kernel path, 1: fused kernel where it applies (default), 2: as 1 with the one-wave-per-SIMD variant of the 8 x 64 wave kernel"""
-        return int(self.lib.pinn_debug_set_fused(2 if enable == 2 else int(bool(enable))))
+        """0: two-kernel path, 1: fused kernel where it applies (default)"""
+        return int(self.lib.pinn_debug_set_fused(int(bool(enable))))
 
     def supported_width(self, h: int) -> int:
         return self.lib.pinn_supported_width(int(h))

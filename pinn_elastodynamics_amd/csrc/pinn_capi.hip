@@ -74,12 +74,10 @@ static void input_map(const double* lb, const double* ub, int normalize, Call& c
 
 using namespace pinn;
 
-#ifndef PINN_X_FUSED_DEFAULT
-#define PINN_X_FUSED_DEFAULT 1
-#endif
-static int g_use_fused = PINN_X_FUSED_DEFAULT;
+static int g_use_fused = 1;
 static unsigned long long* g_dbg_stamps = nullptr;
 static float* g_prof_ms = nullptr;
+static ProfRing g_ring;
 
 extern "C" {
 
@@ -88,9 +86,32 @@ int pinn_abi_version(void) { return 1; }
 void pinn_debug_set_stamp_buffer(void* device_u64x128) { g_dbg_stamps = static_cast<unsigned long long*>(device_u64x128); }
 void pinn_debug_set_profile_buffer(float* host_ms4) { g_prof_ms = host_ms4; }
 
+int pinn_debug_profile_ring_arm(int max_launches) {
+    if (max_launches < 0) max_launches = 0;
+    g_ring.limit = max_launches > ProfRing::CAP ? ProfRing::CAP : max_launches;
+    g_ring.n = 0;
+    g_ring.armed = g_ring.limit > 0;
+    return g_ring.limit;
+}
+
+int pinn_debug_profile_ring_read(float* ms_out, int* streams_out, int capacity) {
+    g_ring.armed = false;
+    int m = 0;
+    for (int i = 0; i < g_ring.n && m < capacity; ++i) {
+        if (hipEventSynchronize(g_ring.ev[i][1]) != hipSuccess) break;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, g_ring.ev[i][0], g_ring.ev[i][1]) != hipSuccess) break;
+        if (ms_out) ms_out[m] = ms;
+        if (streams_out) streams_out[m] = g_ring.tag[i];
+        ++m;
+    }
+    g_ring.n = 0;
+    return m;
+}
+
 int pinn_debug_set_fused(int enable) {
     const int old = g_use_fused;
-    g_use_fused = enable == 2 ? 2 : (enable ? 1 : 0);
+    g_use_fused = enable ? 1 : 0;
     return old;
 }
 
@@ -163,6 +184,7 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     for (int i = 0; i < 5; ++i)
         for (int o = 0; o < 8; ++o) c.w5[i][o] = 0.0f;
     c.prof_ms = g_prof_ms;
+    c.ring = g_ring.armed ? &g_ring : nullptr;
     c.use_fused = g_use_fused;
     c.dbg_stamps = g_dbg_stamps;
     return PINN_OK;

@@ -136,7 +136,7 @@ __device__ __forceinline__ void split4u(float a, float b, float c, float d, uint
     split2u<Op>(a, b, h0, l0);
     split2u<Op>(c, d, h1, l1);
 }
-#if defined(__AMDGCN__) && !defined(PINN_GENERIC_SPLIT) && !defined(PINN_X_SPLIT2)
+#if defined(__AMDGCN__) && !defined(PINN_GENERIC_SPLIT)
 template <>
 __device__ __forceinline__ void split4<OpF16>(float a, float b, float c, float d, uint32_t& h0, uint32_t& h1, uint32_t& l0, uint32_t& l1) {
     const uint32_t ha = pack2<OpF16>(a, b), hb = pack2<OpF16>(c, d);

@@ -91,9 +91,7 @@ __device__ __forceinline__ unsigned in_loop(unsigned v) {
 }
 
 __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int slot) {
-#ifndef PINN_X_NOSTAMP
     if (a.dbg != nullptr && who) a.dbg[slot] = __builtin_readcyclecounter();
-#endif
 }
 
 // NS = 4: value + three tangent streams, residual head of net_f_sig (the collocation set).  NS = 1: value stream only, head
@@ -102,13 +100,9 @@ __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int sl
 // a 2^-12 state rounding that cancellation amplifies at trained weights (see STATE_LO below).  Not the default.
 // DIN_ = 4 (round 3): the 3-D Navier-Cauchy extension of BASELINE configs[4] -- inputs (x, y, z, t), five FIRST-order streams (value, x, y, z,
 // t), 12 outputs and the 3-D residual head (oracle/nc3d_oracle.py); built for the LDS-operand layout of padded width 128.
-// MERGE_ (round 3, experimental): ONE wave per SIMD -- four waves per workgroup, each a chain wave that ALSO owns one quadrant of every
-// weight gradient (512 registers per wave: all weight-gradient sums stay in registers, none in memory) -- instead of two waves per SIMD in
-// two roles.  Narrow four-stream layout only.
-template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4, bool FASTSTATE = false, int DIN_ = 3, bool MERGE_ = false>
+template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4, bool FASTSTATE = false, int DIN_ = 3>
 struct Fused {
     static constexpr int NS = NS_, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1, DIN = DIN_;
-    static constexpr bool MERGE = MERGE_;
     static_assert(NS == 4 || NS == 1 || NS == 5, "wave residual head (4 streams), value-only data head (1 stream) or plate / 3-D head (5 streams)");
     static_assert(DIN == 3 || (DIN == 4 && NS == 5), "4 inputs: the five-stream 3-D head only");
     // NS = 5, 3 inputs: streams (value, x, y, t, tt) -- the fifth carries the second time derivative (PLATE:417-419) -- and the plate head:
@@ -129,15 +123,7 @@ struct Fused {
     // registers), so the chain wave keeps it in its LDS image -- the register image IS the MFMA operand layout -- and reads one k-step
     // at a time (one ds_read_b128 per stream and part); every layer is "all output blocks accumulate, then the vector part block by
     // block".  The images are 24 KB (hi + lo) per tensor and tile: two tiles per workgroup.
-#ifdef PINN_X_PLATE_LDSOP
-    // (experiment, round 3: the plate's five streams at padded width 64 through the LDS-operand layout -- the narrow five-stream instantiation is
-    // register-starved (43 spilled registers, constants from memory, no recomputed S_1); here: two tiles, two state slots, constants in LDS, no
-    // spills, the weight gradient with both state parts (gradient 4e-7 from the oracle instead of 1e-5).  Parity-green in the emulator and
-    // on the GPU -- and 12 % SLOWER: 2.26 against 2.02 ms per 500 k points.  Off.)
-    static constexpr bool LDSOP = WB > 4 || (WB == 4 && NS_ == 5 && DIN_ == 3 && !MERGE_);
-#else
     static constexpr bool LDSOP = WB > 4;
-#endif
     static_assert(!LDSOP || NP == 2, "the LDS-operand layout is built for the split-precision cases");
     // One stream at these widths (the value-only side sets loss_IC / loss_SRC / loss_NB / loss_FIX of the reference's 8 x 80 / 8 x 100 nets,
     // round 3): images of 6 / 8 KB, so ALL layer states S_0..S_NL of both tiles stay in LDS (NL + 1 slots) -- nothing is parked, no LDS-DMA.
@@ -209,7 +195,7 @@ struct Fused {
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
     // (two-slot wide layout: layer 1's nine blocks stay in registers -- one layer less of the sums' round trip through L2: 6.39 -> 6.28 ms;
     // a second layer spills 82 registers)
-    static constexpr int NG = MERGE_ ? 0 : LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? 5 : (NL >= 4 ? 2 : 0));      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
+    static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? 5 : (NL >= 4 ? 2 : 0));      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
     // Padded width 160: 5 x 5 blocks per wave do not fit the register file next to their running sums (100 + 100 registers), so the
     // weight gradient walks its out-blocks in three passes (2 + 2 + 1) and STREAMS the sums: a pass starts from its ten (five) records,
@@ -870,18 +856,12 @@ struct Fused {
             }
             if constexpr (DMA_IN_WINDOW) dma_state(scr, lane16, tile_lds, L - 1, quad);      // S_{L-1} streams in while layer L is worked on
             if constexpr (DMA_OWN) dma_state(scr, lane16, tile_lds, L, quad);
-#ifdef PINN_X_WSTAMP
-            fused_stamp(a, tracer, 96 + 2 * (NL - L));
-#endif
             // Second barrier: the tensors of layer L are complete.  This wave's contribution is the LDS-DMA of S_L, issued one layer
             // ago; everything issued since (the sums of layer L+1 stored, those of layer L requested, the window's DMA) may stay in flight,
             // so the drain is a COUNTED one.  (A surplus operation the compiler might add only makes the wait more conservative:
             // completion is in issue order.)
             __builtin_amdgcn_sched_barrier(0);
             wait_vmcnt<DMA_OWN ? 0 : N_STORE + N_LOAD + N_DMA>();
-#ifdef PINN_X_WSTAMP
-            fused_stamp(a, tracer, 97 + 2 * (NL - L));
-#endif
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             fused_stamp(a, tracer, 65 + 3 * (NL - L));
@@ -944,15 +924,7 @@ struct Fused {
                 // this wave parks its share of it (the records it will bring back by LDS-DMA: same wave, same addresses, program order)
                 for (int l = 0; l < NL; ++l) {
                     lds_barrier();
-#ifdef PINN_X_FSTAMP
-                    fused_stamp(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, 106 + 2 * l);
-#endif
-#ifndef PINN_X_NOPARK
                     if (l + 1 <= NL - 1 && !kept_in_lds(l + 1)) park_image(scr_st, lane16, tile_lds, l + 1, quad);
-#endif
-#ifdef PINN_X_FSTAMP
-                    fused_stamp(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, 107 + 2 * l);
-#endif
                 }
             }
             WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend, ld);
@@ -1065,9 +1037,6 @@ struct Fused {
         const float* blast;                        // output-layer bias (constants not in LDS)
         int c, q;
         bool tracer;                               // workgroup 0, chain wave 0, lane 0
-#ifdef PINN_X_FSTAMP
-        long long* dbgp;
-#endif
         __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile) {
             scr = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES, 0x00020000);
         }
@@ -1083,9 +1052,6 @@ struct Fused {
             cbias = lds + CONST_OFF + q_ * 16;
             cw0 = lds + CONST_OFF + CONST_BIAS_F * 4 + q_ * 64;
             imgoff = img_record(c_, q_);
-#ifdef PINN_X_FSTAMP
-            dbgp = (long long*)a.dbg;
-#endif
             c = c_;
             q = q_;
             tracer = false;
@@ -1222,13 +1188,8 @@ struct Fused {
     // tanh and the scaled derivative from a scaled pre-activation  zs = WS * z :
     //   e = 2^(zs * 2 log2(e) / WS),  r = 1/(1 + e),  h = 1 - 2r,  sds = (1 - h^2)/WS = (4/WS) r (1 - r)
     static __device__ __forceinline__ void tanh_scaled(float zs, float& h, float& sds) {
-#ifdef PINN_X_NOTRANS      // (timing ablation: no transcendental instructions; results garbage but finite)
-        const float e = zs * (2.8853900817779268f * INV_WS);
-        const float r = 0.25f + 0.001f * e;
-#else
         const float e = __builtin_amdgcn_exp2f(zs * (2.8853900817779268f * INV_WS));
         const float r = __builtin_amdgcn_rcpf(1.0f + e);
-#endif
         h = 1.0f - 2.0f * r;
         const float c4 = r * (4.0f * INV_WS);
         sds = c4 - c4 * r;
@@ -1259,31 +1220,6 @@ struct Fused {
     template <int MB, int KSF = KS>
     static __device__ __forceinline__ void fwd_valu(const f32x4 (&acc)[NS], u32x4 (&Bn)[NS][1][KSF][NP]) {
         float vals[NS][4];
-#ifdef PINN_X_STAGED      // (experiment: stage-major source order -- four independent chains side by side -- for builds without the machine scheduler)
-        {
-            float e[4], rr[4], c4[4], sds[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = acc[0][r] * (2.8853900817779268f * INV_WS);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = __builtin_amdgcn_exp2f(e[r]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) e[r] = 1.0f + e[r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rr[r] = __builtin_amdgcn_rcpf(e[r]);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) vals[0][r] = 1.0f - 2.0f * rr[r];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) c4[r] = rr[r] * (4.0f * INV_WS);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sds[r] = c4[r] - c4[r] * rr[r];
-#pragma unroll
-            for (int s = 1; s <= NT; ++s)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) vals[s][r] = sds[r] * acc[s][r];
-            emit_state<MB, KSF>(Bn, vals);
-            return;
-        }
-#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float h, sds;
@@ -1372,27 +1308,17 @@ struct Fused {
             if constexpr (MB == 0) {
                 if (!next_is_out) bb[1] = load_bias(x, l + 1, 1);       // behind its use just above
             }
-#ifndef PINN_X_NOFWDMFMA
             fwd_ksteps<0, KS, KS>(A[MB + 1], in, anxt);
-#endif
-#ifndef PINN_X_NOFWDVALU
             fwd_valu<MB>(acur, out);
-#endif
             if constexpr (NS == 4 && NP == 2) interleave<NS * KS * P3, 2>();
         } else {
             // last block: the next layer's block 0 starts on the finished half of `out`
             acc_init(bb[0], anxt);
-#ifndef PINN_X_NOFWDMFMA
             fwd_ksteps<0, KOVL, KS>(A[0], out, anxt);
-#endif
-#ifndef PINN_X_NOFWDVALU
             fwd_valu<MB>(acur, out);
-#endif
             __builtin_amdgcn_sched_barrier(0);
             operands_ready<KS>(out, KS - 1);
-#ifndef PINN_X_NOFWDMFMA
             fwd_ksteps<KOVL, KS, KS>(A[0], out, anxt);
-#endif
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MB + 1 < WB) fwd_step<MB + 1>(x, l, nfrag0, next_is_out, in, out, A, acca, accb, bb);
@@ -1678,9 +1604,6 @@ struct Fused {
         u32x4 Bk[NS][1][1][NP];
 #pragma unroll
         for (int t = 0; t < NIT; ++t) {
-#ifdef PINN_X_FSTAMP
-            if (t % HB == 0 && x.tracer && x.dbgp && (l == 6 || l == 7)) x.dbgp[97 + 4 * (l - 6) + t / HB] = __builtin_readcyclecounter();
-#endif
             if (t % HB == 0) op_load(in, t / HB, Bk);
             fwd_kstep<0, 1>(Ar[(T0 + t) % RING], Bk, acc[t % HB]);
             fwd_request<PAR>(x, l, h, t + RING, Ar);
@@ -1731,14 +1654,8 @@ struct Fused {
 #pragma unroll
             for (int j = 0; j < HB; ++j) acc[j][0] += bias[j];
         }
-#ifdef PINN_X_FSTAMP
-        if (x.tracer && x.dbgp) x.dbgp[44 + 2 * (l - 1)] = __builtin_readcyclecounter();
-#endif
         u32x4 out[NS][1][HR][NP];
         wide_fwd_epilogue<0>(acc, out);
-#ifdef PINN_X_FSTAMP
-        if (x.tracer && x.dbgp) x.dbgp[45 + 2 * (l - 1)] = __builtin_readcyclecounter();
-#endif
         half_store(outimg, h, out);
         if (kept_in_lds(l + 1)) half_store(x.imgS(l + 1), h, out);       // S_{NL-1} also into its reverse slot (KEEP_W)
     }
@@ -1892,9 +1809,6 @@ struct Fused {
             wide_first<0>(a, x, xin, h, S1);
             half_store(x.imgS(1), h, S1);
         }
-#ifdef PINN_X_WSTAMP
-        fused_stamp(a, x.tracer, 44 + (NL - L));
-#endif
         lds_barrier();                                          // B(L)
         fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
         if constexpr (L >= 1) {
@@ -1910,178 +1824,6 @@ struct Fused {
     }
 
     // ---------------------------------------------------------------------------------------------
-    // MERGE: chain wave + weight-gradient quadrant in one wave (see the template parameter)
-    // ---------------------------------------------------------------------------------------------
-    struct MCtx {                      // the weight-gradient side of a merged wave
-        WgCtx w;
-        DmaSrc scr;
-        char* tile_lds;
-        int quad;
-    };
-    template <int L>
-    struct MDown {
-        // entry: Zc = Z_L in chain fragment order (as Down<L>); the wave's own LDS-DMA of S_L was issued during layer L + 1
-        static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const MCtx& m, Acc& A, const float (&xin)[4], const u32x4 (&Zc)[NS][1][KS][NP]) {
-            static_assert(MERGE && !LDSOP && !SLDS && NS == 4, "merged role: narrow four-stream layout");
-            u32x4 Aa[KS][RP], Ab[KS][RP];
-            u32x2 sla[NS], slb[NS];
-            constexpr bool RECOMP = RECOMP1 && L == 1;
-            u32x4 S1[NS][1][KS][NP];
-            if constexpr (L >= 1) {
-                load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 0, 0), Aa);
-                load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 1, 0), Ab);
-                if constexpr (!RECOMP) lo_from_scratch<0>(x, L, sla);
-            }
-            hand_barrier();                                    // A: every wave is done with the images of layer L + 1 (its weight-gradient reads included)
-            fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
-            put_zimage<KS>(x.imgZ(), Zc);
-            if constexpr (L == 0) put_input_state(a, x, xin);
-            if constexpr (RECOMP) {
-                first_mb<0>(a, x, xin, S1);
-                put_image<KS>(x.imgS(1), S1);
-            }
-            // the LDS-DMA of S_L (this wave's tile) has landed: everything this wave has in flight is waited for (its fragment and
-            // low-part requests of this layer are needed right behind the barrier anyway)
-            wait_vmcnt<0>();
-            hand_barrier();                                    // B: images of layer L complete
-            fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
-            // weight gradient of layer L, this wave's quadrant (the LDS-DMA of S_{L-1} rides inside, as in the two-role layout)
-            {
-                Sums none_a, none_b;
-                wgrad_narrow<L>(m.w, A, m.quad, none_a.blk, none_b.blk, DmaJob{&m.scr, x.lane16, m.tile_lds, m.quad, x.scr});
-            }
-            if constexpr (L >= 1) {
-                u32x4 Zn[NS][1][KS][NP];
-                f32x4 acca[NS], accb[NS];
-                acc_zero(acca);
-                bwd_ksteps<0, KS, KS>(Aa, Zc, acca);
-                if constexpr (RECOMP) bwd_step<0, KS, true>(x, FI::bwd_mid(NL, L, 0, 0), L, nullptr, S1, Zc, Zn, Aa, Ab, acca, accb, sla, slb);
-                else bwd_step<0, KS, false>(x, FI::bwd_mid(NL, L, 0, 0), L, x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb, sla, slb);
-                pin<KS>(Zn);
-                fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
-                MDown<L - 1>::run(a, x, m, A, xin, Zn);
-            }
-        }
-    };
-    static __device__ __forceinline__ void merged_role(const FusedArgs& a, char* lds, int wave, int lane, int c, int q) {
-        const long gwave = (long)blockIdx.x * TILES + wave;
-        Ctx x;
-        x.init(a, lds, wave, lane, c, q);
-        x.set_tile(a, gwave);
-        MCtx m;
-        {
-            const char* wave0 = lds + (q >> 1) * WAVE_B;
-            const int p0 = 8 * (q & 1) + (c >> 2), sub = c & 3;
-            m.w.z0 = wave0 + img_record(p0, sub);
-            m.w.z1 = wave0 + img_record(p0 + 4, sub);
-            m.w.s0 = m.w.z0 + TENSOR_Z_B;
-            m.w.s1 = m.w.z1 + TENSOR_Z_B;
-        }
-        m.scr.init(reinterpret_cast<char*>(a.scratch) + gwave * (long)SCRATCH_BYTES, SCRATCH_BYTES);
-        m.tile_lds = lds + wave * WAVE_B;
-        m.quad = wave;
-        Acc A;
-#pragma unroll
-        for (int l = 0; l < NREG; ++l)
-#pragma unroll
-            for (int i = 0; i < IBW; ++i)
-#pragma unroll
-                for (int o = 0; o < OBW; ++o) A.mid[l][i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-        A.first = A.first2 = A.first3 = f32x4{0.f, 0.f, 0.f, 0.f};
-        A.last = A.last2 = A.last3 = f32x4{0.f, 0.f, 0.f, 0.f};
-        A.bias0b = A.bias0c = 0.0f;
-#pragma unroll
-        for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
-        float lsum[LT];
-#pragma unroll
-        for (int i = 0; i < LT; ++i) lsum[i] = 0.0f;
-        for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
-            float xin[4];
-            bool valid;
-            long pidx;
-            load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + wave, c, xin, valid, pidx);
-            x.tracer = blockIdx.x == 0 && wave == 0 && lane == 0 && step == 2 * (long)gridDim.x;
-            fused_stamp(a, x.tracer, 0);
-            u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
-            forward_tile(a, x, xin, valid, pidx, 0, lsum, B, ZL);
-            // ---- top weight layer NL (as reverse_tile), then the merged sweep
-            fused_stamp(a, x.tracer, 2);
-            u32x4 Aa[1][RP], Ab[1][RP];
-            load_afrags<1, RP>(x, FI::bwd_last(NL, 0), Aa);
-            load_afrags<1, RP>(x, FI::bwd_last(NL, 1), Ab);
-            __syncthreads();              // the one full drain: this forward's park stores have landed before an LDS-DMA reads them
-            fused_stamp(a, x.tracer, 3);
-            put_zimage<1>(x.imgZ(), ZL);
-            if constexpr (TOP_IN_Z) {
-#pragma unroll
-                for (int s = 0; s < NS; ++s)
-#pragma unroll
-                    for (int kk = 0; kk < KS; ++kk) *reinterpret_cast<u32x4*>(x.imgZ() + TOPZ_OFF + s * TOPZ_STRIDE + kk * 1024) = B[s][0][kk][0];
-            } else {
-                put_image<KS>(x.imgS(NL), B);
-            }
-            hand_barrier();
-            fused_stamp(a, x.tracer, 4);
-            {
-                Sums none_a, none_b;
-                wgrad_narrow<NL>(m.w, A, m.quad, none_a.blk, none_b.blk, DmaJob{&m.scr, x.lane16, m.tile_lds, m.quad, x.scr});
-            }
-            u32x4 Zn[NS][1][KS][NP];
-            {
-                f32x4 acca[NS], accb[NS];
-                acc_zero(acca);
-                bwd_ksteps<0, 1, 1>(Aa, ZL, acca);
-                u32x2 sla[NS], slb[NS];
-                bwd_step<0, 1, true>(x, FI::bwd_last(NL, 0), NL, nullptr, B, ZL, Zn, Aa, Ab, acca, accb, sla, slb);
-                pin<KS>(Zn);
-            }
-            fused_stamp(a, x.tracer, 5);
-            MDown<NL - 1>::run(a, x, m, A, xin, Zn);
-        }
-#pragma unroll
-        for (int i = 0; i < LT; ++i) {
-            float v = lsum[i];
-            v += __shfl_xor(v, 1);
-            v += __shfl_xor(v, 2);
-            v += __shfl_xor(v, 4);
-            v += __shfl_xor(v, 8);
-            if (lane == 0) a.loss_part[gwave * LT + i] = v;
-        }
-        // ---- write this workgroup's partial gradient (the narrow branch of the weight-gradient role's epilogue; all sums in registers)
-        float* part = a.partial + (long)blockIdx.x * a.net.nparams;
-        const int H = a.net.h, NO = a.net.nout, quad = wave, wi = quad >> 1, wo = quad & 1;
-        auto put_block = [&](const f32x4& v, int l, int ib, int ob, int n_in, int n_out) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int in = 16 * ib + 4 * q + r, out = 16 * ob + c;
-                if (in < n_in && out < n_out) part[a.net.w_off[l] + in * n_out + out] = v[r];
-            }
-        };
-        {
-            f32x4 lo;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) lo[r] = __shfl_xor(A.first[r], 16);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) A.first[r] += lo[r] * INV_LS;
-        }
-        if (quad < WB) {
-            put_block(A.first, 0, 0, quad, DIN, H);
-            put_block(A.last, NL, quad, 0, H, NO);
-            if (q == 0 && 16 * quad + c < H) part[a.net.b_off[0] + 16 * quad + c] = A.bias[0];
-        }
-        if (quad == 0 && q == 0 && c < NO) part[a.net.b_off[NL] + c] = A.bias[NL];
-#pragma unroll
-        for (int l = 1; l < NL; ++l) {
-#pragma unroll
-            for (int i = 0; i < IBW; ++i)
-#pragma unroll
-                for (int o = 0; o < OBW; ++o) put_block(A.mid[l - 1][i][o], l, wi * IBW + i, wo * OBW + o, H, H);
-            const bool owner = OBW == 1 ? wi == 0 : true;
-            const int ob = wo * OBW + (OBW == 1 ? 0 : wi);
-            if (owner && q == 0 && 16 * ob + c < H) part[a.net.b_off[l] + 16 * ob + c] = A.bias[l];
-        }
-    }
-
     // forward + output layer + residual head (net_f_sig INF:221-265) of the tile addressed by x:
     // parks S_1..S_{NL-1} (scratch image or LDS slots), returns S_NL (fragments) and the head's adjoint Z_NL, adds the loss sums
     static __device__ __forceinline__ void forward_tile(const FusedArgs& a, const Ctx& x, const float (&xin)[4], bool valid, long pidx, int set, float (&lsum)[LT],
@@ -2482,7 +2224,7 @@ struct Fused {
         const int wave8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // provably wave-uniform
         if constexpr (CONST_LDS) {
             float* cst = reinterpret_cast<float*>(lds + CONST_OFF);
-            for (int i = threadIdx.x; i < CONST_F; i += (MERGE ? 256 : 512)) {
+            for (int i = threadIdx.x; i < CONST_F; i += 512) {
                 float v;
                 if (i < (NL - 1) * WIDTH) v = a.pw.bias_mid[i] * WS;
                 else if (i < CONST_BIAS_F) v = a.pw.bias_last[i - (NL - 1) * WIDTH] * WS;
@@ -2491,16 +2233,7 @@ struct Fused {
             }
             __syncthreads();
         }
-        if constexpr (MERGE) {
-            merged_role(a, lds, wave8, lane, c, q);
-#if defined(PINN_X_8CHAIN)      // timing experiment: waves 4..7 run the chain role too (on the LDS / scratch of tiles 0..3: results garbage)
-        } else if (wave8 >= 4) {
-            chain_role(a, lds, wave8 - 4, lane, c, q);
-#elif defined(PINN_X_4CHAIN)    // ... its reference: the four chain waves alone, no weight-gradient role
-        } else if (wave8 >= 4) {
-            return;
-#endif
-        } else if (wave8 >= 4) {
+        if (wave8 >= 4) {
             wgrad_role(a, lds, wave8 - 4, lane, c, q);
         } else {
             __builtin_amdgcn_s_setprio(2);          // the chain wave is the critical path of its SIMD: issue it first
@@ -2512,12 +2245,6 @@ struct Fused {
 template <class Op, int SPLIT, int WIDTH, int NL, int NS, bool FASTSTATE, int DIN = 3>
 __global__ __launch_bounds__(512) void fused_wave_kernel(const FusedArgs a) {
     Fused<Op, SPLIT, WIDTH, NL, NS, FASTSTATE, DIN>::run(a);
-}
-
-// one wave per SIMD (see Fused<>::MERGE): 256 threads, up to 512 registers per wave
-template <class Op, int SPLIT, int WIDTH, int NL>
-__global__ __launch_bounds__(256) void fused_merged_kernel(const FusedArgs a) {
-    Fused<Op, SPLIT, WIDTH, NL, 4, false, 3, true>::run(a);
 }
 
 }  // namespace pinn

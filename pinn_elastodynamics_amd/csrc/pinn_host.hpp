@@ -19,6 +19,29 @@ struct DataSet {                // one value-only point set of pinn_data_loss_gr
     float* loss_out;
 };
 
+// Asynchronous launch timing (pinn_debug_profile_ring_arm / _read): while armed, every launch of a fused kernel is bracketed by HIP
+// events on the call's stream and NOTHING synchronises -- the launches keep their place in the stream order of a running step loop, so the
+// durations are those of the warm, back-to-back launches the step time is made of.  Read once, after the loop.
+struct ProfRing {
+    static constexpr int CAP = 4096;
+    hipEvent_t ev[CAP][2];
+    int tag[CAP];              // streams of the recorded launch (4 / 5: a collocation set, 1: the value-only side sets)
+    int created = 0, n = 0, limit = 0;
+    bool armed = false;
+    // slot for the next launch, or -1 (not armed / full)
+    int begin(hipStream_t st, int tag_) {
+        if (!armed || n >= limit) return -1;
+        if (n >= created) {
+            if (hipEventCreate(&ev[n][0]) != hipSuccess || hipEventCreate(&ev[n][1]) != hipSuccess) return -1;
+            created = n + 1;
+        }
+        tag[n] = tag_;
+        hipEventRecord(ev[n][0], st);
+        return n++;
+    }
+    void end(int slot, hipStream_t st) { if (slot >= 0) hipEventRecord(ev[slot][1], st); }
+};
+
 struct Call {
     NetDesc net;
     const float* params;
@@ -48,6 +71,7 @@ struct Call {
     float w5[5][8];
     // optional per-kernel timing (host pointer, 4 floats: repack, chain, wgrad, reductions) -- makes the call synchronous
     float* prof_ms;
+    ProfRing* ring;            // optional asynchronous launch timing (see ProfRing)
     unsigned long long* dbg_stamps;   // optional device buffer for the fused kernel's phase timestamps (128 x u64)
     int adj_shift;             // PINN_ADJOINT_SHIFT(k): adjoint seeds scaled by 2^-k inside the kernels, the gradient by 2^k at the reduction
     int weights_packed;        // skip the repack: the workspace already holds the packed form of `params` (same net / precision mode)
@@ -94,11 +118,7 @@ struct Host {
     static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
     static constexpr int FUSED_GRID = 256;    // persistent workgroups of the fused kernel (one per MI355X CU)
     static constexpr int FUSED_MAX_WIDTH = 160;     // widest padded net the fused kernel takes (160: 4 streams, 6 layers = CONF:891; 128: 4 and 1 streams (+ the 3-D head); 96 also 5 streams)
-#ifdef PINN_X_PLATE_LDSOP
-    static constexpr size_t FUSED_ACC_W64 = 40 * 1024;
-#else
     static constexpr size_t FUSED_ACC_W64 = 32 * 1024;
-#endif
     static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? FUSED_ACC_W64 : (WIDTH <= 96 ? 72 * 1024 : 160 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
     template <int NS>
     static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5 || NS == 1)) || (WIDTH <= 128 && (NS == 4 || NS == 1)) || (WIDTH == 160 && NS == 4))); }
@@ -397,15 +417,9 @@ struct Host {
             EventPair evp(c.prof_ms != nullptr);
             hipEvent_t (&ev)[2] = evp.ev;
             if (c.prof_ms) hipEventRecord(ev[0], c.stream);
-            bool merged = false;
-            if constexpr (SPLIT == 3 && WIDTH == 64 && NL == 8 && NS == 4 && !FS && DIN == 3) {
-                if (c.use_fused == 2) {        // one wave per SIMD (Fused<>::MERGE): experimental, pinn_debug_set_fused(2)
-                    hipLaunchKernelGGL((fused_merged_kernel<Op, SPLIT, WIDTH, NL>), dim3(grid), dim3(256), 0, c.stream, a);
-                    merged = true;
-                    if (getenv("PINN_TRACE_MERGED")) fprintf(stderr, "[pinn] merged kernel grid=%d nsteps=%ld\n", grid, nsteps);
-                }
-            }
-            if (!merged) hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL, NS, FS, DIN>), dim3(grid), dim3(512), 0, c.stream, a);
+            const int ring_slot = c.ring ? c.ring->begin(c.stream, NS) : -1;
+            hipLaunchKernelGGL((fused_wave_kernel<Op, SPLIT, WIDTH, NL, NS, FS, DIN>), dim3(grid), dim3(512), 0, c.stream, a);
+            if (c.ring) c.ring->end(ring_slot, c.stream);
             if ((rc = (int)hipGetLastError())) return rc;
             if (c.prof_ms) {
                 hipEventRecord(ev[1], c.stream);

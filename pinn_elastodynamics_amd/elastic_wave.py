@@ -15,11 +15,12 @@ follows, and the identical fused Adam step runs on every rank, so the weights st
 """
 from __future__ import annotations
 
-import pickle
 from typing import Optional, Sequence
 
 import numpy as np
 import torch
+
+from .net_api import NetApi, read_checkpoint, truncated_normal, write_checkpoint
 
 # multipliers of (loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss_NB, loss_FIX) in the total loss
 LOSS_LAYOUT = {
@@ -42,18 +43,13 @@ def _col(a):
 
 
 def xavier_init(layers: Sequence[int], rng: np.random.Generator):
-    """initialize_NN / xavier_init (INF:141-156): truncated normal (|z| <= 2) times
+    """initialize_NN / xavier_init (INF:141-156) as one function of a layer list and a generator: truncated normal (|z| <= 2) times
     sqrt(2/(in+out)), zero biases of shape [1, out].  The build's own seeded stream (TF1's is
-    not reproducible)."""
+    not reproducible).  The model classes also carry the reference's two METHODS (net_api.NetApi)."""
     Ws, bs = [], []
     for i in range(len(layers) - 1):
         n_in, n_out = layers[i], layers[i + 1]
-        W = rng.standard_normal((n_in, n_out))
-        bad = np.abs(W) > 2.0
-        while bad.any():
-            W[bad] = rng.standard_normal(int(bad.sum()))
-            bad = np.abs(W) > 2.0
-        Ws.append((W * np.sqrt(2.0 / (n_in + n_out))).astype(np.float32))
+        Ws.append(truncated_normal(rng, (n_in, n_out), float(np.sqrt(2.0 / (n_in + n_out)))))
         bs.append(np.zeros((1, n_out), dtype=np.float32))
     return Ws, bs
 
@@ -145,7 +141,7 @@ def lbfgs_on_device(theta, loss_and_grad, options, callback=None):
     return stats
 
 
-class DeepHPM:
+class DeepHPM(NetApi):
     """Drop-in for the reference's model class on the wave cases (INF:21-376)."""
 
     def __init__(self, Collo, SRC, IC, UP, uv_layers, lb, ub, ExistModel=0, modelDir='', *, case="infinite",
@@ -183,8 +179,9 @@ class DeepHPM:
         self.device = engine.device
 
         # ---- weights (INF:64-68)
+        self._init_rng = np.random.default_rng(seed)
         if ExistModel == 0:
-            W, b = xavier_init(self.uv_layers, np.random.default_rng(seed))
+            W, b = self.initialize_NN(self.uv_layers)
         else:
             W, b = self.load_NN(modelDir, self.uv_layers)
         self.n_params = sum(w.size for w in W) + sum(x.size for x in b)
@@ -237,26 +234,17 @@ class DeepHPM:
     # checkpoints: the reference's [W_list, b_list] pickle (INF:159-186); .npz is accepted too
     # ------------------------------------------------------------------------------------------
     def save_NN(self, fileDir, TYPE=''):
+        """INF:159-170.  A name ending in ``.npz`` writes plain arrays (the documented default of this package); any other name writes the
+        reference's pickle of [W_list, b_list] (net_api.py)."""
         W, b = unpack_params(self.theta.detach().cpu().numpy(), self.uv_layers)
-        if str(fileDir).endswith(".npz"):
-            np.savez(fileDir, layers=np.array(self.uv_layers), **{f"W{i}": w for i, w in enumerate(W)},
-                     **{f"b{i}": x for i, x in enumerate(b)})
-        else:
-            with open(fileDir, 'wb') as f:
-                pickle.dump([W, b], f)
+        write_checkpoint(fileDir, W, b, self.uv_layers)
         if self.verbose:
             print("Save NN parameters successfully...")
 
     def load_NN(self, fileDir, layers):
+        """INF:172-186: ``.npz`` or the reference's pickle (read by an arrays-only unpickler, net_api.py)"""
         num_layers = len(layers)
-        if str(fileDir).endswith(".npz"):
-            z = np.load(fileDir)
-            n = sum(1 for k in z.files if k.startswith("W"))
-            uv_weights = [z[f"W{i}"] for i in range(n)]
-            uv_biases = [z[f"b{i}"] for i in range(n)]
-        else:
-            with open(fileDir, 'rb') as f:
-                uv_weights, uv_biases = pickle.load(f, encoding="latin1")
+        uv_weights, uv_biases = read_checkpoint(fileDir)
         # Stored model must have the same number of layers (INF:178)
         assert num_layers == (len(uv_weights) + 1)
         weights = [np.asarray(w, dtype=np.float32) for w in uv_weights]
@@ -281,11 +269,13 @@ class DeepHPM:
     def _cols(T):
         return tuple(T[i].detach().cpu().numpy().reshape(-1, 1) for i in range(T.shape[0]))
 
-    def neural_net(self, X, weights=None, biases=None):
-        """INF:188-199 on X [N,3] -> Y [N,n_out] with the model's current weights."""
-        X = np.asarray(X)
-        F = self._fields(X[:, 0], X[:, 1], X[:, 2])
-        return F[0].T.detach().cpu().numpy()
+    # neural_net(X, weights, biases): net_api.NetApi, through these two
+    def _current_theta(self):
+        return self.theta
+
+    def _net_fields(self, eng, theta, X):
+        xs = [torch.from_numpy(np.ascontiguousarray(_col(X[:, k]), dtype=np.float32)).to(eng.device) for k in range(3)]
+        return eng.fields(theta, xs[0], xs[1], xs[2], self.lb, self.ub, self.normalize)[0]
 
     def net_uv(self, x, y, t):                       # INF:201-211
         return self._cols(self._fields(x, y, t)[0])
@@ -559,8 +549,7 @@ class DeepHPMConfined(DeepHPM):
             return super().save_NN(fileDir)
         if TYPE in ('DIST', 'PART') and TYPE in self._aux_nets:
             W, b = self._aux_nets[TYPE]
-            with open(fileDir, 'wb') as f:
-                pickle.dump([W, b], f)
+            write_checkpoint(fileDir, W, b, self.dist_layers if TYPE == 'DIST' else self.part_layers)
             if self.verbose:
                 print("Save %s NN parameters successfully..." % TYPE)
 

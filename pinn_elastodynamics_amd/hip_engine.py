@@ -52,6 +52,13 @@ class HipEngine:
         self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=self.device)
         self._ws_ptr = (self.ws.data_ptr() + 255) // 256 * 256
 
+        self._lib_path = lib_path
+
+    def for_layers(self, layers: Sequence[int]) -> "HipEngine":
+        """A sibling engine for a net of other layer sizes (same precision mode, device and library): neural_net(X, weights, biases) of
+        the model classes on weights that are not the model's own net (INF:188-199 takes any weight list)."""
+        return HipEngine(layers, precision=self.precision, device=self.device, max_points=1 << 16, lib_path=self._lib_path, fast_state=self.fast_state)
+
     # ------------------------------------------------------------------------------------------
     def _mode(self, packed: bool) -> int:
         """precision_mode argument of the loss / gradient calls: the precision, PINN_FLAG_WEIGHTS_PACKED when the previous call of this

@@ -17,14 +17,15 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .elastic_wave import _col, evaluate_with_finite_gradient, pack_params, unpack_params, xavier_init
+from .elastic_wave import _col, evaluate_with_finite_gradient, pack_params, unpack_params, xavier_init  # noqa: F401
+from .net_api import NetApi, read_checkpoint, write_checkpoint
 
 OUT = ("u", "v", "w", "ut", "vt", "wt", "s11", "s22", "s33", "s12", "s13", "s23")
 _SLOTS = ("collo", "IC", "SRC", "NB")          # 16 floats each in the loss-sum buffer
 LOSS_LAYOUT_3D = dict(f_uv=5.0, f_s=5.0, IC=2.0, SRC=2.0, NB=2.0)        # the semi-infinite script's weights (SEMI:127)
 
 
-class NavierCauchy3D:
+class NavierCauchy3D(NetApi):
     """NavierCauchy3D(Collo[N,4], SRC[Ns,7], IC[Ni,4], TOP[Nt,4], uv_layers, lb[4], ub[4], ExistModel=0, modelDir='')
 
     Collo: collocation points (x, y, z, t); SRC: points with prescribed displacement (x, y, z, t, u, v, w) -- the source;
@@ -60,8 +61,9 @@ class NavierCauchy3D:
             engine = HipEngine(self.uv_layers, precision=precision, max_points=n_max)
         self.engine = engine
         self.device = engine.device
+        self._init_rng = np.random.default_rng(seed)
         if ExistModel == 0:
-            W, b = xavier_init(self.uv_layers, np.random.default_rng(seed))
+            W, b = self.initialize_NN(self.uv_layers)
         else:
             W, b = self.load_NN(modelDir, self.uv_layers)
         self.n_params = sum(w.size for w in W) + sum(x.size for x in b)
@@ -106,23 +108,11 @@ class NavierCauchy3D:
 
     # ---- checkpoints: the reference's [W_list, b_list] pickle / npz (INF:159-186) ---------------------------------
     def save_NN(self, fileDir, TYPE=''):
-        import pickle
         W, b = unpack_params(self.theta.detach().cpu().numpy(), self.uv_layers)
-        if str(fileDir).endswith(".npz"):
-            np.savez(fileDir, layers=np.array(self.uv_layers), **{f"W{i}": w for i, w in enumerate(W)}, **{f"b{i}": x for i, x in enumerate(b)})
-        else:
-            with open(fileDir, 'wb') as f:
-                pickle.dump([W, b], f)
+        write_checkpoint(fileDir, W, b, self.uv_layers)        # .npz: plain arrays (documented default); otherwise the reference's pickle
 
     def load_NN(self, fileDir, layers):
-        import pickle
-        if str(fileDir).endswith(".npz"):
-            z = np.load(fileDir)
-            n = sum(1 for k in z.files if k.startswith("W"))
-            W, b = [z[f"W{i}"] for i in range(n)], [z[f"b{i}"] for i in range(n)]
-        else:
-            with open(fileDir, 'rb') as f:
-                W, b = pickle.load(f, encoding="latin1")
+        W, b = read_checkpoint(fileDir)                        # .npz, or the reference's pickle through the arrays-only unpickler
         assert len(layers) == len(W) + 1                   # INF:178
         W = [np.asarray(w, dtype=np.float32) for w in W]
         b = [np.asarray(x, dtype=np.float32).reshape(1, -1) for x in b]
@@ -139,9 +129,13 @@ class NavierCauchy3D:
     def _cols(T):
         return tuple(T[i].detach().cpu().numpy().reshape(-1, 1) for i in range(T.shape[0]))
 
-    def neural_net(self, X, weights=None, biases=None):
-        X = np.asarray(X)
-        return self._fields(X[:, 0], X[:, 1], X[:, 2], X[:, 3])[0].T.detach().cpu().numpy()
+    # neural_net(X, weights, biases): net_api.NetApi, through these two
+    def _current_theta(self):
+        return self.theta
+
+    def _net_fields(self, eng, theta, X):
+        xs = [torch.from_numpy(np.ascontiguousarray(_col(X[:, k]), dtype=np.float32)).to(eng.device) for k in range(4)]
+        return eng.nc3d_fields(theta, *xs, self.lb, self.ub, self.normalize)[0]
 
     def net_uv(self, x, y, z, t):
         """-> (u, v, w, ut, vt, wt, s11, s22, s33, s12, s13, s23), each [N,1]"""

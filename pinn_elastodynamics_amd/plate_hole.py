@@ -11,13 +11,13 @@ trains (PLATE:240-241).
 """
 from __future__ import annotations
 
-import pickle
 from typing import Optional
 
 import numpy as np
 import torch
 
-from .elastic_wave import _col, evaluate_with_finite_gradient, lbfgs_on_device, pack_params, relax_adjoint_shift, unpack_params, xavier_init
+from .elastic_wave import _col, evaluate_with_finite_gradient, lbfgs_on_device, pack_params, relax_adjoint_shift, unpack_params, xavier_init  # noqa: F401
+from .net_api import NetApi, read_checkpoint, write_checkpoint
 
 _EPS = float(np.finfo(float).eps)
 BFGS_OPTIONS = {   # PLATE:220-247
@@ -27,7 +27,7 @@ BFGS_OPTIONS = {   # PLATE:220-247
 }
 
 
-class PINN:
+class PINN(NetApi):
     def __init__(self, Collo, HOLE, IC, LF, RT, UP, LW, DIST, uv_layers, dist_layers, part_layers, lb, ub,
                  partDir='', distDir='', uvDir='', *, precision="f16x3", engines=None, seed=1111, process_group=None, verbose=True,
                  always_reduce=False):
@@ -56,10 +56,11 @@ class PINN:
         self.eng = engines
         self.device = engines["uv"].device
 
-        rng = np.random.default_rng(seed)
+        self.engine = engines["uv"]            # (net_api.NetApi's default engine; nets of other sizes find theirs in _engine_for)
+        self._init_rng = np.random.default_rng(seed)
         self.theta, self.adam_m, self.adam_v = {}, {}, {}
         for key, layers, d in (("dist", self.dist_layers, distDir), ("part", self.part_layers, partDir), ("uv", self.uv_layers, uvDir)):
-            W, b = xavier_init(layers, rng) if d == '' else self.load_NN(d, layers)      # PLATE:96-112
+            W, b = self.initialize_NN(layers) if d == '' else self.load_NN(d, layers)      # PLATE:96-112
             self.theta[key] = torch.from_numpy(pack_params(W, b)).to(self.device)
         self.adam_m = torch.zeros_like(self.theta["uv"])
         self.adam_v = torch.zeros_like(self.theta["uv"])
@@ -135,25 +136,30 @@ class PINN:
             return
         layers = {"uv": self.uv_layers, "dist": self.dist_layers, "part": self.part_layers}[key]
         W, b = unpack_params(self.theta[key].detach().cpu().numpy(), layers)
-        if str(fileDir).endswith(".npz"):
-            np.savez(fileDir, layers=np.array(layers), **{f"W{i}": w for i, w in enumerate(W)}, **{f"b{i}": x for i, x in enumerate(b)})
-        else:
-            with open(fileDir, 'wb') as f:
-                pickle.dump([W, b], f)
+        write_checkpoint(fileDir, W, b, layers)          # .npz: plain arrays (documented default); otherwise the reference's pickle
         if self.verbose:
             print("Save " + TYPE + " NN parameters successfully...")
 
     def load_NN(self, fileDir, layers):
-        if str(fileDir).endswith(".npz"):
-            z = np.load(fileDir)
-            n = sum(1 for k in z.files if k.startswith("W"))
-            uv_weights, uv_biases = [z[f"W{i}"] for i in range(n)], [z[f"b{i}"] for i in range(n)]
-        else:
-            with open(fileDir, 'rb') as f:
-                uv_weights, uv_biases = pickle.load(f, encoding="latin1")
+        uv_weights, uv_biases = read_checkpoint(fileDir)       # .npz, or the reference's pickle through the arrays-only unpickler
         assert len(layers) == (len(uv_weights) + 1)                                           # PLATE:299
         return ([np.asarray(w, dtype=np.float32) for w in uv_weights],
                 [np.asarray(b, dtype=np.float32).reshape(1, -1) for b in uv_biases])
+
+    # ---- neural_net(X, weights, biases) (PLATE:308-320; PLATE:322-356 runs all three nets through it): net_api.NetApi ------------
+    def _current_theta(self):
+        return self.theta["uv"]
+
+    def _engine_for(self, layers):
+        layers = [int(v) for v in layers]
+        for eng in self.eng.values():
+            if [int(v) for v in eng.layers] == layers:
+                return eng
+        return super()._engine_for(layers)
+
+    def _net_fields(self, eng, theta, X):
+        xs = [torch.from_numpy(np.ascontiguousarray(_col(X[:, k]), dtype=np.float32)).to(eng.device) for k in range(3)]
+        return eng.net_streams(theta, xs[0], xs[1], xs[2], self.lb, self.ub, False)[0]
 
     # ---- graph pieces on column arrays --------------------------------------------------------------------------------
     def _streams(self, key, x, y, t):

@@ -15,6 +15,9 @@ class OracleEngine:
         self.calls = []
         self.adjoint_shift = 0
 
+    def for_layers(self, layers):
+        return OracleEngine(layers)
+
     @staticmethod
     def _np(t):
         return t.detach().cpu().numpy().astype(np.float64)

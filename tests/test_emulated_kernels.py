@@ -77,19 +77,6 @@ def test_fused_kernel_emulated(emu, layers, n, prec, tol_loss, tol_grad):
     assert e_loss < tol_loss and e_grad < tol_grad
 
 
-def test_fused_one_wave_per_simd_variant_emulated(emu):
-    """set_fused(2): the experimental one-wave-per-SIMD variant of the 8 x 64 kernel (every wave chain + weight-gradient quadrant, all sums in
-    registers) -- the same arithmetic as the two-role kernel"""
-    layers = [3] + 8 * [64] + [7]
-    try:
-        e_loss, e_grad = run_wave(emu, layers, 200, "f16x3", fused=2)
-        e_loss1, e_grad1 = run_wave(emu, layers, 200, "f16x3", fused=1)
-    finally:
-        emu.set_fused(1)
-    assert e_loss < 2e-6 and e_grad < 1e-4
-    assert e_loss == e_loss1 and e_grad == e_grad1
-
-
 def test_fused_persistent_accumulation_emulated(emu):
     """minimum workspace => fewer workgroups than steps: accumulators persist across steps of a workgroup"""
     e_loss, e_grad = run_wave(emu, [3] + 4 * [32] + [7], 9000, "f16x3", min_ws=True, fused=True)

@@ -141,3 +141,67 @@ def test_device_lbfgs_backend_matches_scipy_objective():
     for backend, (l0, l1, count) in losses.items():
         assert l1 < 0.5 * l0 and count >= 10, backend
     assert losses["torch"][1] < 3.0 * losses["scipy"][1]
+
+
+def test_neural_net_honours_the_weights_it_is_given():
+    """INF:188-199 takes (X, weights, biases): another weight set of the model's net, and a net of other sizes (PLATE:322-356 runs three
+    nets through the one function), both against the oracle; no weights = the model's own."""
+    Collo, SRC, IC, UP = small_sets()
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), verbose=False, seed=3)
+    X = Collo[:40]
+    own = m.neural_net(X)
+    W0, b0 = unpack_params(m.theta.numpy(), LAYERS)
+    np.testing.assert_allclose(m.neural_net(X, W0, b0), own, rtol=0, atol=1e-7)
+    for layers in (LAYERS, [3, 8, 8, 8, 7]):
+        W, b = m.initialize_NN(layers)
+        b = [x + 0.1 * (i + 1) for i, x in enumerate(b)]
+        Y = m.neural_net(X, W, b)
+        ref = po.wave2d_fields(pack_params(W, b).astype(np.float64), layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, True)["Y"]
+        assert Y.shape == (40, layers[-1])
+        np.testing.assert_allclose(Y, ref, rtol=1e-5, atol=1e-6)
+    assert not np.allclose(m.neural_net(X, *m.initialize_NN(LAYERS)), own)
+    np.testing.assert_allclose(m.neural_net(X), own, rtol=0, atol=0)          # the model's weights were not touched
+
+
+def test_initialize_NN_and_xavier_init_are_methods_like_the_reference():
+    """INF:141-156: initialize_NN(layers) -> (weights, biases), xavier_init(size) -> one truncated-normal matrix"""
+    Collo, SRC, IC, UP = small_sets()
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), verbose=False, seed=3)
+    W, b = m.initialize_NN([3, 50, 40, 7])
+    assert [w.shape for w in W] == [(3, 50), (50, 40), (40, 7)] and [x.shape for x in b] == [(1, 50), (1, 40), (1, 7)]
+    assert all(float(np.abs(x).max()) == 0.0 for x in b)
+    M = m.xavier_init(size=[200, 300])
+    sd = np.sqrt(2.0 / 500)
+    assert M.shape == (200, 300) and M.dtype == np.float32
+    assert float(np.abs(M).max()) <= 2.0 * sd * (1 + 1e-6)                    # truncated at two standard deviations
+    assert 0.8 * sd < float(M.std()) < 0.95 * sd                              # (a normal truncated at 2 sigma has std 0.88 sigma)
+    # the constructor's weights are initialize_NN's first draw of the model's seeded stream
+    m2 = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), verbose=False, seed=3)
+    np.testing.assert_array_equal(m.theta.numpy(), m2.theta.numpy())
+
+
+def test_reference_pickle_is_read_by_an_arrays_only_unpickler(tmp_path):
+    """the reference's [W_list, b_list] pickle loads; a pickle that names anything but numpy's array reconstruction is refused
+    (pickle.load would execute it); .npz is the plain-data default"""
+    from pinn_elastodynamics_amd.net_api import read_checkpoint
+    Collo, SRC, IC, UP = small_sets()
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), verbose=False, seed=3)
+    W, b = unpack_params(m.theta.numpy(), LAYERS)
+    good = tmp_path / "uvNN.pickle"
+    with open(good, "wb") as f:
+        pickle.dump([W, [x.astype(np.float64) for x in b]], f, protocol=2)      # the reference's python-2-era protocol
+    W2, b2 = m.load_NN(str(good), LAYERS)
+    for a_, b_ in zip(W + b, W2 + b2):
+        np.testing.assert_array_equal(a_, b_)
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("echo pwned > /dev/null",))
+    bad = tmp_path / "evil.pickle"
+    with open(bad, "wb") as f:
+        pickle.dump([[Evil()], []], f)
+    with pytest.raises(pickle.UnpicklingError):
+        read_checkpoint(str(bad))
+    m.save_NN(str(tmp_path / "uvNN.npz"))
+    W3, b3 = read_checkpoint(str(tmp_path / "uvNN.npz"))
+    np.testing.assert_array_equal(W3[1], W[1])

@@ -42,6 +42,11 @@ if g('TCC_EA0_RDREQ_sum') is not None and g('TCC_EA0_WRREQ_sum') is not None:
     # exact request sizes on the L2 <-> fabric interface: 32-byte and 64-byte requests counted separately
     js['ea_read_bytes_per_launch'] = 32.0 * g('TCC_EA0_RDREQ_32B_sum') + 64.0 * (g('TCC_EA0_RDREQ_sum') - g('TCC_EA0_RDREQ_32B_sum'))
     js['ea_write_bytes_per_launch'] = 64.0 * g('TCC_EA0_WRREQ_64B_sum') + 32.0 * (g('TCC_EA0_WRREQ_sum') - g('TCC_EA0_WRREQ_64B_sum'))
+import hashlib
+h = hashlib.sha256()
+for f in ('pinn_fused.hpp', 'pinn_device.hpp', 'pinn_host.hpp'):
+    h.update(open('$GRAFT_REPO_ROOT/pinn_elastodynamics_amd/csrc/' + f, 'rb').read())
+js['kernel_source_sha'] = h.hexdigest()[:16]      # bench.py refuses to quote these bytes for other kernel sources
 js['note'] = ('$WHAT; tools/pmc_collect.sh: one rocprofv3 --pmc pass per '
               'group of <= 4 counters, --kernel-trace only. FETCH_SIZE/WRITE_SIZE are in KB; hbm_bytes = 2*FETCH (gfx950 correction) + WRITE. These '
               'L2<->fabric counters include Infinity-Cache hits.')
