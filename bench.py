@@ -341,7 +341,7 @@ def main():
         "timed_blocks": {"count": len(dts), "steps_per_block": steps, "block_ms_min": 1e3 * min(dts), "block_ms_median": 1e3 * dt, "block_ms_max": 1e3 * max(dts),
                          "note": "every block = `steps` steps between barrier + synchronize brackets (max over ranks); ms_per_step and value are the median block's"},
         "config": {"workload": workload, "bench_config": cfg, "collocation_points_global": n_global, "precision_mode": args.precision,
-                   "parallelism": f"dp{world}", "final_loss": final_loss, "algorithmic_flop_per_point": flop_pt},
+                   "parallelism": f"dp{world}", "always_reduce": bool(args.always_reduce), "final_loss": final_loss, "algorithmic_flop_per_point": flop_pt},
         "whole_path": {"achieved_tflops": flop_pt * value / 1e12, "frac_of_mfma_peak": flop_pt * value / 1e12 / (MFMA_PEAK_TFLOPS * world)},
     }
     if rank == 0:
@@ -387,7 +387,7 @@ def main():
             out["roofline"] = {"kernel": "fused_wave_kernel<..., NS = 5> (forward with the second time derivative + plate head + reverse chain + weight gradient)",
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
                                "traffic": None, "launches_per_step": 1, "avg_launch_ms": acc["chain"], "algorithmic_flop_per_point": flop_pt,
-                               "issued_mfma_tflops": tflops * issued,
+                               "launches_timed": int(collo_ms.size), "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; the hole-traction set (9960 points) runs on the "
                                        "two-kernel path.  traffic not measured in this run"}
@@ -416,7 +416,7 @@ def main():
                                          "chain + weight gradient)" if fused else "chain_kernel + wgrad_kernel (two-kernel path)",
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
                                "traffic": None, "launches_per_step": n_launch, "avg_launch_ms": t_ms / n_launch, "algorithmic_flop_per_point": flop_pt,
-                               "issued_mfma_tflops": tflops * issued,
+                               "launches_timed": int(collo_ms.size), "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; measured limiter of the LDS-operand layouts: the bytes "
                                        "of parked states and in-memory weight-gradient sums through L2 (DESIGN.md section 6).  traffic not measured in this run"}

@@ -68,8 +68,10 @@ enum {
 int pinn_supported_width(int h);
 
 /* Workspace sizing.  `recommended` holds all tiles of an n-point call in one pass; anything
- * >= `min` works (the call then walks the points in several chunks).  n_streams: 4 for the
- * residual path, 1 for the value-only data terms. */
+ * >= `min` works (the call then walks the points in several chunks).  The fused persistent kernel (one launch per call, what the
+ * published numbers are measured with) needs one scratch image per workgroup on top of the fixed part -- pinn_workspace_bytes() of a
+ * few hundred thousand points covers its 256 workgroups for every net --; a workspace that holds fewer than 64 of them makes the call
+ * take the two-kernel path instead (same results, slower), it never runs a persistent launch on a handful of CUs. */
 size_t pinn_workspace_bytes(const int* layers, int n_layers, int64_t n, int precision_mode);
 size_t pinn_min_workspace_bytes(const int* layers, int n_layers, int precision_mode);
 

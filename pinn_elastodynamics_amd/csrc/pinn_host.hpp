@@ -117,6 +117,15 @@ struct Host {
     static constexpr int FUSED_PARTS = SPLIT == 3 ? 3 : 1;   // ... of the fused kernel's format (repack_kernel)
     static constexpr int NCHUNK = 128;        // split-K slices of the weight-gradient kernel
     static constexpr int FUSED_GRID = 256;    // persistent workgroups of the fused kernel (one per MI355X CU)
+    // The fused kernel is a PERSISTENT launch: its grid is the number of per-workgroup scratch images the workspace holds.  A workspace
+    // that holds only a handful (pinn_min_workspace_bytes is sized for the two-kernel path) would run the whole call on a few CUs -- far
+    // slower than the two-kernel path, silently.  Below this many workgroups (unless the call has fewer steps anyway) the fused path
+    // declines and the two-kernel path runs.  (The x86 test build keeps 1: its tests use small workspaces to get several steps per workgroup.)
+#if defined(PINN_SIMT_EMULATOR)
+    static constexpr long FUSED_MIN_GRID = 1;
+#else
+    static constexpr long FUSED_MIN_GRID = 64;
+#endif
     static constexpr int FUSED_MAX_WIDTH = 160;     // widest padded net the fused kernel takes (160: 4 streams, 6 layers = CONF:891; 128: 4 and 1 streams (+ the 3-D head); 96 also 5 streams)
     static constexpr size_t FUSED_ACC_W64 = 32 * 1024;
     static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? FUSED_ACC_W64 : (WIDTH <= 96 ? 72 * 1024 : 160 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
@@ -476,6 +485,7 @@ struct Host {
             }
             if (nsteps == 0) return 0;
             if (grid > nsteps) grid = nsteps;
+            if (grid < FUSED_MIN_GRID && grid < nsteps) return 0;      // too few scratch images for a persistent launch: two-kernel path
             if constexpr (WIDTH == 160) *out = fused_launch<6, NS>(c, p, (int)grid, nterms, nsteps);
             else if constexpr (WIDTH > 64) *out = fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
             else if (c.fast_state && SPLIT == 3 && NS == 4 && c.net.nl == 8) *out = fused_launch<8, NS, true>(c, p, (int)grid, nterms, nsteps);   // the collocation kernel of the 8-layer nets
@@ -501,6 +511,7 @@ struct Host {
             const long nsteps = (c.n + 16 * F::TILES - 1) / (16 * F::TILES);
             if (nsteps == 0) return 0;
             if (grid > nsteps) grid = nsteps;
+            if (grid < FUSED_MIN_GRID && grid < nsteps) return 0;      // (see FUSED_MIN_GRID)
             *out = fused_launch<10, 5, false, 4>(c, p, (int)grid, 12, nsteps);
             return 1;
         } else {

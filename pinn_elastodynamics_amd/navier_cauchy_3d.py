@@ -181,12 +181,16 @@ class NavierCauchy3D(NetApi):
         if self._collo_full is not None:
             return tuple(a[s:e] for a in self._collo_full)
         key = (lo, hi)
-        if key not in self._collo_cache:
-            # a block that overlaps cached ones belongs to another batching (getloss() asks for (0, N) after train() walked the
-            # blocks): drop what it overlaps first, so a rank never keeps more than its shard of the set on the device
-            for k in [k for k in self._collo_cache if k[0] < hi and lo < k[1]]:
-                del self._collo_cache[k]
+        if key in self._collo_cache:
+            self._collo_cache[key] = self._collo_cache.pop(key)          # most recently used last
+        else:
+            # Bounded cache, least recently used out first: TWICE this rank's share of the set stays resident, so that train() walking
+            # its blocks and getloss() asking for (0, N) in between -- two batchings of the same rows -- alternate without re-uploading
+            # a shard from the host every time, and shifting windows still cannot grow the device footprint beyond that bound.
             self._collo_cache[key] = tuple(torch.from_numpy(h[s:e]).to(self.device) for h in self._collo_host)
+            cap = 2 * (-(-self._n_collo // self.world)) + 64
+            while len(self._collo_cache) > 1 and sum(v[0].numel() for v in self._collo_cache.values()) > cap:
+                del self._collo_cache[next(iter(self._collo_cache))]
         return self._collo_cache[key]
 
     def _loss_and_grad(self, idx_start, idx_end):

@@ -205,3 +205,24 @@ def test_reference_pickle_is_read_by_an_arrays_only_unpickler(tmp_path):
     m.save_NN(str(tmp_path / "uvNN.npz"))
     W3, b3 = read_checkpoint(str(tmp_path / "uvNN.npz"))
     np.testing.assert_array_equal(W3[1], W[1])
+
+
+def test_shard_cache_is_bounded_and_keeps_two_batchings_resident():
+    """a data-parallel rank's device cache of collocation rows: train() blocks and getloss()'s (0, N) alternate without re-uploading, and
+    shifting windows cannot grow it beyond twice the rank's share"""
+    Collo, SRC, IC, UP = small_sets(n=400)
+    m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), verbose=False, seed=3)
+    m.world, m.rank, m._collo_full = 2, 1, None                      # as rank 1 of 2 (no process group needed for the cache itself)
+    blocks = [(0, 200), (200, 400)]
+    first = {b: m._rows(*b)[0].data_ptr() for b in blocks}
+    full = m._rows(0, 400)[0].data_ptr()
+    assert m._rows(0, 400)[0].shape[0] == 200 and np.allclose(m._rows(0, 400)[0].numpy(), Collo[200:400, 0].astype(np.float32))
+    for _ in range(3):                                               # alternate the two batchings: the same device tensors every time
+        for b in blocks:
+            assert m._rows(*b)[0].data_ptr() == first[b]
+        assert m._rows(0, 400)[0].data_ptr() == full
+    for lo in range(0, 300, 7):                                      # shifting, non-aligned windows
+        x = m._rows(lo, lo + 100)[0]
+        s, e = m._shard(lo, lo + 100)
+        assert np.allclose(x.numpy(), Collo[s:e, 0].astype(np.float32))
+        assert sum(v[0].numel() for v in m._collo_cache.values()) <= 2 * 200 + 64

@@ -23,6 +23,7 @@
 #include <vector>
 #include <algorithm>
 
+#define PINN_SIMT_EMULATOR 1      // (the x86 test build of the kernel sources; never defined for gfx950)
 #define __global__
 #define __device__
 #define __host__

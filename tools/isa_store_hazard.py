@@ -2,6 +2,10 @@
 a 16-byte (or wider than 8-byte) buffer / global / scratch store whose data VGPRs are written by a VALU instruction within the next few
 issue slots.  hipcc pads this only for stores without a scalar offset register; on the MI355X a `buffer_store_dwordx4 ... sN offen` followed
 directly by a vector write of its data registers stored the NEW value in its last dword (pinn_fused.hpp, stream_pass).
+WINDOW: the ISA manual's requirement for "VMEM store of more than 8 bytes -> write of its data VGPRs" is 1-2 wait states and every
+instruction in between is at least one, so a writer three or more instructions behind the store is safe; the failure seen on the GPU was
+the immediate successor.  (The SOURCE fence, stores_issued() in pinn_fused.hpp, pads with s_nop 7 -- deliberately wider than the hazard:
+eight wait states cost nothing there.)
   python tools/isa_store_hazard.py file.s [...]      exit code 1 if an instance is found within WINDOW = 2 instructions"""
 import re, sys
 WINDOW = 2
