@@ -36,8 +36,11 @@ enum {
                              cancellation of O(1) outputs (the plate's hole traction at trained weights) the gradient error does
                              not fall with the number of points as host fp32's does; (2) the weight gradient of padded widths <= 64
                              takes the layer states as fp16 high parts: a rounding noise of 2^-12 / sqrt(points) relative to the
-                             gradient (2e-5 at 70 points, 1e-6 at 200 k) -- the wider layouts use both parts; (3) |w| < 2047 in the
-                             fused kernels' weight format (32 w must stay finite in fp16): larger weights give non-finite sums. */
+                             gradient (2e-5 at 70 points, 1e-6 at 200 k) -- the wider layouts use both parts; (3) |w| <= 2047 in the
+                             fused kernels' weight format (32 w must stay finite in fp16).  A larger weight is DETECTED when the weights
+                             are packed: the call then returns NaN in every gradient entry and every loss sum (never a plausible wrong
+                             number) -- pass PINN_FLAG_TWO_KERNEL to evaluate such weights (the two-kernel path holds |w| up to 65504);
+                             pinn_fused_weight_limit() returns the bound. */
     PINN_PREC_F16 = 2,    /* fp16 operands, one MFMA per product */
     PINN_PREC_BF16X3 = 3, /* bf16 hi/lo split, three MFMAs per product (16-bit significand) */
     PINN_PREC_FP32 = 4,   /* plain fp32 FMA arithmetic, no matrix pipe (the reference's own precision, INF:71-92): ~100x slower,
@@ -51,7 +54,10 @@ enum {
      * high parts only (no low parts): 17 % faster, but the activation reverse then sees states rounded to 2^-12, which cancellation at
      * TRAINED weights amplifies (first-layer gradient blocks 5e-3 off at the reference's trained nets, fp32 itself 2e-4).  Fine far
      * from an optimum (early Adam steps); not parity-grade.  Ignored where it does not apply. */
-    PINN_FLAG_STATE_FP16 = 0x200
+    PINN_FLAG_STATE_FP16 = 0x200,
+    /* OR this into precision_mode to keep this call off the fused persistent kernel: forward / reverse chain and weight gradient run as
+     * the two-kernel path (state and adjoint panels through the workspace): slower, no |w| <= 2047 bound (see PINN_PREC_F16X3). */
+    PINN_FLAG_TWO_KERNEL = 0x400
     /* PINN_ADJOINT_SHIFT(k), k = 0..24, may be OR'ed in as well: see below */
 };
 
@@ -66,6 +72,8 @@ enum {
 
 /* Padded hidden width the kernels use for a real hidden width h (0 if unsupported). */
 int pinn_supported_width(int h);
+/* Largest |w| the fused kernels' weight format holds (2047); see PINN_PREC_F16X3 (3) and PINN_FLAG_TWO_KERNEL. */
+float pinn_fused_weight_limit(void);
 
 /* Workspace sizing.  `recommended` holds all tiles of an n-point call in one pass; anything
  * >= `min` works (the call then walks the points in several chunks).  The fused persistent kernel (one launch per call, what the

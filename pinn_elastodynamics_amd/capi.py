@@ -10,6 +10,7 @@ import os
 
 PREC = {"bf16": 0, "f16x3": 1, "f16": 2, "bf16x3": 3, "fp32": 4}
 FLAG_WEIGHTS_PACKED = 0x100
+FLAG_TWO_KERNEL = 0x400            # PINN_FLAG_TWO_KERNEL: keep the call off the fused kernel (weights beyond its |w| <= 2047 format)
 FLAG_STATE_FP16 = 0x200            # PINN_FLAG_STATE_FP16: fused 8-layer collocation kernel parks fp16 states only (faster, not parity-grade)
 def adjoint_shift(k: int) -> int:
     """PINN_ADJOINT_SHIFT(k) of include/pinn_hip.h"""
@@ -97,6 +98,8 @@ class PinnLib:
         L.pinn_debug_set_profile_buffer.restype = None
         L.pinn_debug_set_fused.argtypes = [i32]
         L.pinn_debug_set_fused.restype = i32
+        L.pinn_fused_weight_limit.argtypes = []
+        L.pinn_fused_weight_limit.restype = C.c_float
         L.pinn_debug_profile_ring_arm.argtypes = [i32]
         L.pinn_debug_profile_ring_arm.restype = i32
         L.pinn_debug_profile_ring_read.argtypes = [vp, vp, i32]
@@ -170,6 +173,9 @@ class PinnLib:
     def set_fused(self, enable) -> int:
         """0: two-kernel path, 1: fused kernel where it applies (default)"""
         return int(self.lib.pinn_debug_set_fused(int(bool(enable))))
+
+    def fused_weight_limit(self) -> float:
+        return float(self.lib.pinn_fused_weight_limit())
 
     def supported_width(self, h: int) -> int:
         return self.lib.pinn_supported_width(int(h))

@@ -83,6 +83,8 @@ extern "C" {
 
 int pinn_abi_version(void) { return 1; }
 
+float pinn_fused_weight_limit(void) { return FUSED_OPERAND_MAX / FUSED_WEIGHT_SCALE; }
+
 void pinn_debug_set_stamp_buffer(void* device_u64x128) { g_dbg_stamps = static_cast<unsigned long long*>(device_u64x128); }
 void pinn_debug_set_profile_buffer(float* host_ms4) { g_prof_ms = host_ms4; }
 
@@ -152,8 +154,9 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     if (normalize && (!lb || !ub)) return PINN_ERR_NULL;
     c.weights_packed = (precision_mode & PINN_FLAG_WEIGHTS_PACKED) ? 1 : 0;
     c.fast_state = (precision_mode & PINN_FLAG_STATE_FP16) ? 1 : 0;
+    const bool two_kernel = (precision_mode & PINN_FLAG_TWO_KERNEL) != 0;
     c.adj_shift = (precision_mode >> 16) & 0x1f;
-    precision_mode &= ~(PINN_FLAG_WEIGHTS_PACKED | PINN_FLAG_STATE_FP16 | (0x1f << 16));
+    precision_mode &= ~(PINN_FLAG_WEIGHTS_PACKED | PINN_FLAG_STATE_FP16 | PINN_FLAG_TWO_KERNEL | (0x1f << 16));
     if (precision_mode < 0 || precision_mode > PINN_PREC_FP32) return PINN_ERR_PRECISION;
     int width = 0;
     const int rc = decode_net(layers, n_layers, c.net, width, din);
@@ -185,13 +188,13 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
         for (int o = 0; o < 8; ++o) c.w5[i][o] = 0.0f;
     c.prof_ms = g_prof_ms;
     c.ring = g_ring.armed ? &g_ring : nullptr;
-    c.use_fused = g_use_fused;
+    c.use_fused = two_kernel ? 0 : g_use_fused;
     c.dbg_stamps = g_dbg_stamps;
     return PINN_OK;
 }
 
 // the sizing entry points accept the same precision_mode word as the calls (flag and shift bits are ignored) and both input counts
-static int mode_only(int precision_mode) { return precision_mode & ~(PINN_FLAG_WEIGHTS_PACKED | PINN_FLAG_STATE_FP16 | (0x1f << 16)); }
+static int mode_only(int precision_mode) { return precision_mode & ~(PINN_FLAG_WEIGHTS_PACKED | PINN_FLAG_STATE_FP16 | PINN_FLAG_TWO_KERNEL | (0x1f << 16)); }
 
 size_t pinn_workspace_bytes(const int* layers, int n_layers, int64_t n, int precision_mode) {
     NetDesc net;

@@ -33,6 +33,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 // part of the scaled weight in the 16-bit normal range for |w| > 4e-3 (measured on the reference's trained nets: same field /
 // residual / gradient error as 2^11) and lets |w| reach 2047 before the high part overflows fp16.
 constexpr float FUSED_WEIGHT_SCALE = 32.0f;
+constexpr float FUSED_OPERAND_MAX = 65504.0f;      // largest finite 16-bit operand of the split formats (fp16): |w| <= 2047 in the fused weight format
 constexpr int MAX_WLAYERS = 16;   // weight matrices per net (hidden layers + 1)
 constexpr int NOUT_PAD = 16;      // network outputs are padded to one 16-row MFMA block
 
@@ -278,6 +279,7 @@ struct RepackArgs {
     float* bias_last;
     u32x4* frags;
     u32x4* frags_fused;        // second copy in the fused kernel's format (see repack_kernel), or nullptr
+    int* wflags;               // [gridDim.x]: 1 where this block met a weight the fused format cannot hold (|FUSED_WEIGHT_SCALE * w| beyond fp16), or nullptr
 };
 
 typedef short v4i16 __attribute__((ext_vector_type(4)));
@@ -329,6 +331,7 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackArgs a) {
     const int FM = FI::fm(nl), NF = FI::total(nl);
     const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long nthreads = (long)gridDim.x * blockDim.x;
+    bool out_of_range = false;      // a weight whose scaled value leaves fp16's range: the fused kernel would compute with +-inf
     for (long i = gid; i < (long)NF * 64; i += nthreads) {
         const int frag = (int)(i >> 6), lane = (int)(i & 63), c = lane & 15, q = lane >> 4;
         // decode the fragment kind
@@ -373,6 +376,7 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackArgs a) {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const float v0 = wv[2 * d] * FUSED_WEIGHT_SCALE, v1 = wv[2 * d + 1] * FUSED_WEIGHT_SCALE;
+                    out_of_range |= !(__builtin_fabsf(v0) <= FUSED_OPERAND_MAX) || !(__builtin_fabsf(v1) <= FUSED_OPERAND_MAX);      // (also true for NaN)
                     p0[d] = pack2<Op>(v0, v1);
                     p1[d] = pack2<Op>(v0 - round16<Op>(v0), v1 - round16<Op>(v1));
                     p2[d] = pack2<Op>(round16<Op>(v0) * (1.0f / Op::LO_SCALE), round16<Op>(v1) * (1.0f / Op::LO_SCALE));
@@ -406,6 +410,15 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackArgs a) {
         a.bias_mid[i] = f < H ? a.params[a.net.b_off[l] + f] : 0.0f;
     }
     for (long i = gid; i < NOUT_PAD; i += nthreads) a.bias_last[i] = i < NO ? a.params[a.net.b_off[nl] + i] : 0.0f;
+    // one flag per block, rewritten by every repack (no reset, no atomics): read by the fused path's reduction (reduce_grad_loss_kernel)
+    if (a.wflags != nullptr) {
+        __shared__ int any;
+        if (threadIdx.x == 0) any = 0;
+        __syncthreads();
+        if (out_of_range) any = 1;
+        __syncthreads();
+        if (threadIdx.x == 0) a.wflags[blockIdx.x] = any;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1211,7 +1224,16 @@ struct LossOuts { float* p[4]; };
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void reduce_grad_loss_kernel(const float* partial, int nchunks, int nparams, float scale, float* grad,
                                                                int accumulate, const float* loss_part, long nwaves, int nterms, int nsets,
-                                                               int slots, LossOuts loss_out) {
+                                                               int slots, LossOuts loss_out, const int* wflags = nullptr, int nflags = 0) {
+    // Weights outside the fused format's range (repack_kernel's flags): the launch computed with infinities.  Its results are replaced by
+    // NaN as a whole -- gradient and sums -- so that the condition is unmistakable (include/pinn_hip.h, PINN_FLAG_TWO_KERNEL).
+    __shared__ int bad_weights;
+    if (threadIdx.x == 0) bad_weights = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nflags; i += 256)
+        if (wflags[i]) bad_weights = 1;
+    __syncthreads();
+    const float poison = bad_weights ? __builtin_nanf("") : 0.0f;
     const int grad_blocks = (int)gridDim.x - nsets;
     if ((int)blockIdx.x >= grad_blocks) {
         const int k = (int)blockIdx.x - grad_blocks;
@@ -1225,7 +1247,7 @@ __global__ __launch_bounds__(256) void reduce_grad_loss_kernel(const float* part
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 8);
         v += __shfl_xor(v, 16);
-        if (sub == 0 && term < nterms && loss_out.p[k] != nullptr) loss_out.p[k][term] = v;
+        if (sub == 0 && term < nterms && loss_out.p[k] != nullptr) loss_out.p[k][term] = v + poison;
         return;
     }
     __shared__ float sub[4][64];
@@ -1246,7 +1268,7 @@ __global__ __launch_bounds__(256) void reduce_grad_loss_kernel(const float* part
     __syncthreads();
     if (sl == 0 && p < nparams) {
         const float s = (sub[0][pl] + sub[1][pl]) + (sub[2][pl] + sub[3][pl]);
-        grad[p] = (accumulate ? grad[p] : 0.0f) + scale * s;
+        grad[p] = (accumulate ? grad[p] : 0.0f) + scale * s + poison;
     }
 }
 

@@ -133,10 +133,11 @@ struct Host {
     static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5 || NS == 1)) || (WIDTH <= 128 && (NS == 4 || NS == 1)) || (WIDTH == 160 && NS == 4))); }
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
     static constexpr long MIN_TILES = 64;
+    static constexpr int MAX_REPACK_BLOCKS = 2048;
     typedef FragIndex<WIDTH> FI;
 
     struct Plan {
-        size_t w0p, bias_mid, bias_last, frags, frags_fused, loss_part, partial, wg_acc, panels, fixed_end;
+        size_t w0p, bias_mid, bias_last, wflags, frags, frags_fused, loss_part, partial, wg_acc, panels, fixed_end;
         long s_tile, z_tile;     // 16-bit elements per tile
         long ntiles;             // total tiles of the call (even)
         long chunk_tiles;        // tiles per workspace pass (even)
@@ -153,6 +154,8 @@ struct Host {
         o = align_up(o + (size_t)(net.nl > 1 ? net.nl - 1 : 1) * WIDTH * sizeof(float), 256);
         p.bias_last = o;
         o = align_up(o + NOUT_PAD * sizeof(float), 256);
+        p.wflags = o;           // repack_kernel's per-block weight-range flags
+        o = align_up(o + (size_t)MAX_REPACK_BLOCKS * sizeof(int), 256);
         p.frags = o;
         o = align_up(o + (size_t)FI::total(net.nl) * NPS * 64 * sizeof(u32x4), 256);
         p.frags_fused = o;      // second copy in the fused kernel's format (narrow nets only)
@@ -211,6 +214,11 @@ struct Host {
         return pw;
     }
 
+    static int repack_blocks(const NetDesc& net) {
+        const long items = (long)FI::total(net.nl) * 64;
+        const long blocks = (items + 255) / 256;
+        return (int)(blocks < MAX_REPACK_BLOCKS ? blocks : MAX_REPACK_BLOCKS);      // (the kernel strides: any grid covers all items)
+    }
     static int repack(const Call& c, const Plan& p) {
         if (c.weights_packed) return 0;      // PINN_FLAG_WEIGHTS_PACKED: the previous call on this workspace left them in place
         char* b = static_cast<char*>(c.ws);
@@ -222,8 +230,8 @@ struct Host {
         ra.bias_last = reinterpret_cast<float*>(b + p.bias_last);
         ra.frags = reinterpret_cast<u32x4*>(b + p.frags);
         ra.frags_fused = WIDTH <= FUSED_MAX_WIDTH ? reinterpret_cast<u32x4*>(b + p.frags_fused) : nullptr;
-        const long items = (long)FI::total(c.net.nl) * 64;
-        const int blocks = (int)((items + 255) / 256);
+        ra.wflags = reinterpret_cast<int*>(b + p.wflags);
+        const int blocks = repack_blocks(c.net);
         hipLaunchKernelGGL((repack_kernel<Op, SPLIT, WIDTH>), dim3(blocks), dim3(256), 0, c.stream, ra);
         return (int)hipGetLastError();
     }
@@ -441,14 +449,15 @@ struct Host {
             if constexpr (DIN == 4) {
                 // 12 terms in LOSS_SLOTS_3D slots per tile: the gradient blocks of the fused reduction, then the loss reduction of the two-kernel path
                 hipLaunchKernelGGL((reduce_grad_loss_kernel<0>), dim3((c.net.nparams + 63) / 64), dim3(256), 0, c.stream, (const float*)a.partial,
-                                   grid, c.net.nparams, twmax, c.grad_out, c.accumulate, (const float*)a.loss_part, (long)grid * F::TILES, 0, 0, SLOTS, lo);
+                                   grid, c.net.nparams, twmax, c.grad_out, c.accumulate, (const float*)a.loss_part, (long)grid * F::TILES, 0, 0, SLOTS, lo,
+                                   (const int*)(b + p.wflags), SPLIT == 3 ? repack_blocks(c.net) : 0);
                 hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * F::TILES, nterms,
                                    c.loss_out, 0, LOSS_SLOTS_3D);
                 return (int)hipGetLastError();
             }
             hipLaunchKernelGGL((reduce_grad_loss_kernel<0>), dim3((c.net.nparams + 63) / 64 + nsets), dim3(256), 0, c.stream, (const float*)a.partial,
                                grid, c.net.nparams, twmax, c.grad_out, c.accumulate, (const float*)a.loss_part, (long)grid * F::TILES, nterms, nsets,
-                               SLOTS, lo);
+                               SLOTS, lo, (const int*)(b + p.wflags), SPLIT == 3 ? repack_blocks(c.net) : 0);
             return (int)hipGetLastError();
         } else {
             return PINN_ERR_LAYERS;

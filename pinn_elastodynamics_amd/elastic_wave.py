@@ -92,6 +92,10 @@ def evaluate_with_finite_gradient(engine, evaluate, n_params, state, device_chec
             host = buf.cpu().numpy()
             if np.isfinite(host[:n_params]).all():
                 return host
+        # a weight beyond the fused kernels' format (|w| <= 2047) poisons the whole result with NaN: leave the fused path and repeat
+        leave = getattr(engine, "leave_fused_path_if_weights_out_of_range", None)
+        if leave is not None and state.get("theta") is not None and leave(state["theta"]):
+            continue
         if engine.adjoint_shift >= 24:
             break
         engine.adjoint_shift = min(engine.adjoint_shift + 4, 24)
@@ -186,6 +190,7 @@ class DeepHPM(NetApi):
             W, b = self.load_NN(modelDir, self.uv_layers)
         self.n_params = sum(w.size for w in W) + sum(x.size for x in b)
         self.theta = torch.from_numpy(pack_params(W, b)).to(self.device)
+        self._shift_state["theta"] = self.theta        # (updated in place: the weight-range check of evaluate_with_finite_gradient reads it)
         self.adam_m = torch.zeros_like(self.theta)
         self.adam_v = torch.zeros_like(self.theta)
         self.adam_t = 0

@@ -9,7 +9,7 @@ from typing import Optional, Sequence
 
 import torch
 
-from .capi import DEFAULT_LIB, FLAG_STATE_FP16, FLAG_WEIGHTS_PACKED, PREC, PinnLib, PinnLibError, adjoint_shift
+from .capi import DEFAULT_LIB, FLAG_STATE_FP16, FLAG_TWO_KERNEL, FLAG_WEIGHTS_PACKED, PREC, PinnLib, PinnLibError, adjoint_shift
 
 
 def param_count(layers: Sequence[int]) -> int:
@@ -37,6 +37,7 @@ class HipEngine:
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.n_params = param_count(self.layers)
         self.adjoint_shift = 0
+        self.two_kernel = False               # PINN_FLAG_TWO_KERNEL on every call (set by leave_fused_path_if_weights_out_of_range)
         self.needs_finite_probe = True        # 16-bit reverse pass: the model classes check the first gradient (PINN_ADJOINT_SHIFT)
         if self.lib.supported_width(self.layers[1]) == 0:
             raise PinnLibError(f"hidden width {self.layers[1]} is not supported by the compiled kernels")
@@ -65,7 +66,18 @@ class HipEngine:
         engine used the same parameter values (skip the repack launch), and the current adjoint shift (``self.adjoint_shift``, see
         PINN_ADJOINT_SHIFT in include/pinn_hip.h; the model classes adapt it when a gradient comes back non-finite)."""
         return (PREC[self.precision] | (FLAG_WEIGHTS_PACKED if packed else 0) | (FLAG_STATE_FP16 if self.fast_state else 0)
-                | adjoint_shift(self.adjoint_shift))
+                | (FLAG_TWO_KERNEL if self.two_kernel else 0) | adjoint_shift(self.adjoint_shift))
+
+    def leave_fused_path_if_weights_out_of_range(self, params: torch.Tensor) -> bool:
+        """The fused kernels' weight format holds |w| <= 2047 (include/pinn_hip.h); beyond it a call returns NaN throughout.  Called by the
+        model classes when a result comes back non-finite: if a weight is out of range, this engine's calls switch to the two-kernel path
+        (PINN_FLAG_TWO_KERNEL) for good and True is returned -- the caller repeats its evaluation.  Synchronises (one reduction)."""
+        if self.two_kernel or self.precision not in ("f16x3", "bf16x3"):
+            return False
+        if float(params.detach().abs().max()) <= self.lib.fused_weight_limit():
+            return False
+        self.two_kernel = True
+        return True
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream

@@ -68,6 +68,7 @@ class NavierCauchy3D(NetApi):
             W, b = self.load_NN(modelDir, self.uv_layers)
         self.n_params = sum(w.size for w in W) + sum(x.size for x in b)
         self.theta = torch.from_numpy(pack_params(W, b)).to(self.device)
+        self._shift_state["theta"] = self.theta
         self.adam_m = torch.zeros_like(self.theta)
         self.adam_v = torch.zeros_like(self.theta)
         self.adam_t = 0

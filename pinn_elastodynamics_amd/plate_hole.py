@@ -62,6 +62,7 @@ class PINN(NetApi):
         for key, layers, d in (("dist", self.dist_layers, distDir), ("part", self.part_layers, partDir), ("uv", self.uv_layers, uvDir)):
             W, b = self.initialize_NN(layers) if d == '' else self.load_NN(d, layers)      # PLATE:96-112
             self.theta[key] = torch.from_numpy(pack_params(W, b)).to(self.device)
+        self._shift_state["theta"] = self.theta["uv"]
         self.adam_m = torch.zeros_like(self.theta["uv"])
         self.adam_v = torch.zeros_like(self.theta["uv"])
         self.adam_t = 0

@@ -618,3 +618,33 @@ def test_fused_width160_emulated(emu):
     assert e_loss < 2e-6 and e_grad < 2e-6
     e_loss, e_grad = run_wave(emu, layers, 150, "f16x3", min_ws=True, fused=True, normalize=False, seed=4)      # several steps per workgroup
     assert e_loss < 2e-6 and e_grad < 5e-6, (e_loss, e_grad)
+
+
+def test_weight_beyond_the_fused_format_is_detected_emulated(emu):
+    """|w| > 2047 does not fit the fused kernels' weight format (32 w as fp16): the call returns NaN in EVERY gradient entry and loss sum
+    (repack flags -> reduction), PINN_FLAG_TWO_KERNEL evaluates the same weights correctly, and weights inside the range are untouched"""
+    from pinn_elastodynamics_amd.capi import FLAG_TWO_KERNEL, PREC
+    layers, n = [3] + 4 * [32] + [7], 90
+    rng = np.random.default_rng(5)
+    Ws, bs = po.xavier_init(layers, rng)
+    Ws[2][3, 5] = 3000.0                       # one weight out of range (tanh saturates behind it: the oracle's result stays finite)
+    X = po.collocation_points(n, LB, UB, rng)
+    flat = po.pack_params(Ws, bs)
+    tw = np.ones(7) / n
+    ss, g, _ = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, True, term_weights=tw)
+    assert abs(emu.fused_weight_limit() - 2047.0) < 1e-3
+    p32 = flat.astype(np.float32)
+    x, y, t = (X[:, k].astype(np.float32).copy() for k in range(3))
+    wsb = emu.workspace_bytes(layers, n, "f16x3")
+    emu.set_fused(True)
+    out = {}
+    for name, mode in (("fused", PREC["f16x3"]), ("two_kernel", PREC["f16x3"] | FLAG_TWO_KERNEL)):
+        ws = aligned(wsb)
+        loss = np.zeros(8, np.float32)
+        grad = np.zeros(p32.size, np.float32)
+        emu.wave2d_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, True, 2.5, 0.25, 1.0, True,
+                             tw, loss.ctypes.data, grad.ctypes.data, False, mode, ws.ctypes.data, wsb)
+        out[name] = (loss[:7].copy(), grad.copy())
+    assert np.isnan(out["fused"][0]).all() and np.isnan(out["fused"][1]).all()
+    # (a weight of 3000 carries an absolute rounding error of 3000 * 2^-22 into its pre-activation: the gradient is good to ~1e-4 there)
+    assert rel(out["two_kernel"][0], ss) < 2e-6 and rel(out["two_kernel"][1], g) < 5e-4

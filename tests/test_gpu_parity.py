@@ -661,3 +661,38 @@ def test_fp16_state_flag_is_opt_in_and_close_at_fresh_weights(dev):
     e = HipEngine(layers, precision="f16x3", device=dev, max_points=m)
     l, g = e.wave_loss_grad(theta, *(v[:m].contiguous() for v in xs), lb, ub, True, np.ones(7) / m)
     assert rel(l.cpu().numpy(), ss) < 5e-6 and rel(g.cpu().numpy(), go) < 2e-5
+
+
+def test_weight_beyond_the_fused_format_is_detected_and_the_model_falls_back(dev):
+    """|w| = 3000 does not fit the fused kernels' weight format (32 w as fp16, |w| <= 2047): the raw call returns NaN in every gradient
+    entry and loss sum -- never a plausible wrong number --, PINN_FLAG_TWO_KERNEL evaluates the same weights, and the model classes'
+    evaluation (evaluate_with_finite_gradient) switches its engine to that path by itself and returns the oracle's numbers."""
+    from pinn_elastodynamics_amd.elastic_wave import DeepHPM, evaluate_with_finite_gradient
+    layers = [3] + 8 * [64] + [7]
+    Ws, bs, rng = make_net(layers, 21)
+    Ws[3][5, 7] = 3000.0
+    n = 6000
+    X = po.collocation_points(n, LB, UB, rng)
+    flat = po.pack_params(Ws, bs)
+    tw = np.ones(7) / n
+    ss, g, _ = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, True, term_weights=tw)
+    xs = [to_dev(X[:, k], dev) for k in range(3)]
+    eng = engine(layers, "f16x3", dev, n)
+    theta = to_dev(flat, dev)
+    assert abs(eng.lib.fused_weight_limit() - 2047.0) < 1e-3
+    l_f, g_f = eng.wave_loss_grad(theta, *xs, LB, UB, True, tw)
+    assert bool(torch.isnan(l_f).all()) and bool(torch.isnan(g_f).all())
+    eng.two_kernel = True
+    l_t, g_t = eng.wave_loss_grad(theta, *xs, LB, UB, True, tw)
+    assert rel(l_t.cpu().numpy(), ss) < 1e-5 and rel(g_t.cpu().numpy(), g) < 5e-4
+    # the model class: one synchronous evaluation notices, leaves the fused path for good, and repeats
+    eng2 = engine(layers, "f16x3", dev, n)
+    m = DeepHPM(X, None, None, None, layers, LB, UB, case="infinite", engine=eng2, seed=1, verbose=False)
+    m.set_weights(Ws, bs)
+
+    def evaluate():
+        m._loss_and_grad(0, n)
+        return m._buf
+    host = evaluate_with_finite_gradient(eng2, evaluate, m.n_params, m._shift_state)
+    assert eng2.two_kernel and eng2.adjoint_shift == 0
+    assert rel(host[:m.n_params], g) < 5e-4 and rel(host[m.n_params:m.n_params + 7], ss) < 1e-5
