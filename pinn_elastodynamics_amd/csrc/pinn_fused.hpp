@@ -182,6 +182,12 @@ struct Fused {
     static constexpr bool ZDB = !LDSOP && !SLDS && NS_ == 4 && KS == 2 && NP == 2;
     static constexpr float ZDB_SEED_SCALE = 16.0f;                  // host side: adjoint seeds x 16, gradient / 16 at the reduction (fused_launch)
     static constexpr int ZNP = ZDB ? 1 : NP;                         // parts of an adjoint image in LDS
+    // WGLO: the weight gradient also multiplies LOW parts (the adjoints' scaled low part; LDS-operand layouts: the states' too).  Off for ZDB
+    // only.  (Round 4, measured and NOT adopted: high parts only in the LDS-operand layouts as well -- 8 x 80 6.2 -> 5.5 ms per 1 M points, but
+    // 8 x 100 / 6 x 140 / the 3-D net within 1-4 %, and the reference's inf10s net then misses the per-layer fp32 bound of
+    // tests/test_gpu_parity.py in its FIRST layer, whose gradient fp32 itself gets to 1e-6: these layouts keep three MFMAs per product.)
+    static constexpr bool WG_HI = ZDB;
+    static constexpr bool WGLO = NP == 2 && !WG_HI;
     static constexpr int ZBUF_B = NS * KS * 1024;                    // ZDB: one high-part adjoint image
     static __device__ __forceinline__ constexpr int zbuf(int L) { return ZDB ? (L & 1) * ZBUF_B : 0; }      // Z_L lives in buffer L & 1
     static constexpr int S_SLOTS = SLDS ? NL + 1 : BASE_SLOTS;
@@ -210,7 +216,7 @@ struct Fused {
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
     // (two-slot wide layout: layer 1's nine blocks stay in registers -- one layer less of the sums' round trip through L2: 6.39 -> 6.28 ms;
     // a second layer spills 82 registers)
-    static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? 5 : (NL >= 4 ? 2 : 0));      // (measured for NL = 8: NG = 2..7 all within 1 %; 5 leaves the fewest spills)
+    static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? (ZDB ? 1 : 5) : (NL >= 4 ? 2 : 0));      // (NL = 8 before ZDB: NG = 2..7 within 1 %, 5 left the fewest spills; with ZDB the role has registers to spare -- no second accumulator set for the adjoints' low parts -- and every layer kept in registers is a round trip of sums less: NG = 5 / 4 / 3 / 2 / 1 / 0 -> 5.00 / 4.93 / 4.88 / 4.85 / 4.82 / 4.82 ms per 2 M points)
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
     // Padded width 160: 5 x 5 blocks per wave do not fit the register file next to their running sums (100 + 100 registers), so the
     // weight gradient walks its out-blocks in three passes (2 + 2 + 1) and STREAMS the sums: a pass starts from its ten (five) records,
@@ -299,12 +305,12 @@ struct Fused {
 #pragma unroll
             for (int a = 0; a < NA; ++a) {
                 f.Ah[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * SSTR + 8 * a);
-                if constexpr (SLO) f.Al[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * SSTR + 1024 + 8 * a);
+                if constexpr (SLO && WGLO) f.Al[a] = sfrag(s0, s1, 2 * j * WAVE_B + st * SSTR + 1024 + 8 * a);
             }
 #pragma unroll
             for (int b = 0; b < NBK; ++b) {
                 f.Bh[b] = sfrag(z0, z1, 2 * j * WAVE_B + (st * KS * ZNP) * 1024 + 8 * b);
-                if (ZNP == 2) f.Bl[b] = sfrag(z0, z1, 2 * j * WAVE_B + (st * KS * ZNP + 1) * 1024 + 8 * b);
+                if constexpr (WGLO) f.Bl[b] = sfrag(z0, z1, 2 * j * WAVE_B + (st * KS * ZNP + 1) * 1024 + 8 * b);
             }
         };
         auto work = [&](int g, const Frags& f) {
@@ -313,14 +319,14 @@ struct Fused {
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
                     acc[a][b] = Op::mfma(f.Ah[a], f.Bh[b], acc[a][b]);
-                    if (ZNP == 2) cc[a][b] = Op::mfma(f.Ah[a], f.Bl[b], cc[a][b]);
-                    if constexpr (SLO) acc[a][b] = Op::mfma(f.Al[a], f.Bh[b], acc[a][b]);
+                    if constexpr (WGLO) cc[a][b] = Op::mfma(f.Ah[a], f.Bl[b], cc[a][b]);
+                    if constexpr (SLO && WGLO) acc[a][b] = Op::mfma(f.Al[a], f.Bh[b], acc[a][b]);
                 }
             if (g % NS == 0) {                    // bias gradient = ones^T . Z (value stream)
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
                     bm[b] = Op::mfma(ones, f.Bh[b], bm[b]);
-                    if (ZNP == 2) bc[b] = Op::mfma(ones, f.Bl[b], bc[b]);
+                    if constexpr (WGLO) bc[b] = Op::mfma(ones, f.Bl[b], bc[b]);
                 }
             }
         };
@@ -341,8 +347,8 @@ struct Fused {
         }
 #pragma unroll
         for (int b = 0; b < NBK; ++b) {
-            bias_out[b] = ZNP == 2 ? bm[b][0] + bc[b][0] * INV_LS : bm[b][0];
-            if (ZNP == 2) {
+            bias_out[b] = WGLO ? bm[b][0] + bc[b][0] * INV_LS : bm[b][0];
+            if constexpr (WGLO) {
 #pragma unroll
                 for (int a = 0; a < NA; ++a)
 #pragma unroll
@@ -378,26 +384,30 @@ struct Fused {
             f.Bh[0] = sfrag(zp0, zp1, oz);
             f.Bh[1] = sfrag(zp0, zp1, oz + 8);
             f.Bh[2] = sfrag(zs0, zs1, oz);
-            f.Bl[0] = sfrag(zp0, zp1, oz + 1024);
-            f.Bl[1] = sfrag(zp0, zp1, oz + 1024 + 8);
-            f.Bl[2] = sfrag(zs0, zs1, oz + 1024);
-            f.Al[0] = sfrag(sp0, sp1, os + 1024);
-            f.Al[1] = sfrag(sp0, sp1, os + 1024 + 8);
-            f.Al[2] = sfrag(ss0, ss1, os + 1024);
+            if constexpr (WGLO) {
+                f.Bl[0] = sfrag(zp0, zp1, oz + 1024);
+                f.Bl[1] = sfrag(zp0, zp1, oz + 1024 + 8);
+                f.Bl[2] = sfrag(zs0, zs1, oz + 1024);
+                f.Al[0] = sfrag(sp0, sp1, os + 1024);
+                f.Al[1] = sfrag(sp0, sp1, os + 1024 + 8);
+                f.Al[2] = sfrag(ss0, ss1, os + 1024);
+            }
         };
         auto work = [&](const Frags& f) {
 #pragma unroll
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int b = 0; b < 3; ++b) acc[a][b] = Op::mfma(f.Ah[a], f.Bh[b], acc[a][b]);
+            if constexpr (WGLO) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+                for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) cc[a][b] = Op::mfma(f.Ah[a], f.Bl[b], cc[a][b]);
+                    for (int b = 0; b < 3; ++b) cc[a][b] = Op::mfma(f.Ah[a], f.Bl[b], cc[a][b]);
 #pragma unroll
-            for (int a = 0; a < 3; ++a)
+                for (int a = 0; a < 3; ++a)
 #pragma unroll
-                for (int b = 0; b < 3; ++b) acc[a][b] = Op::mfma(f.Al[a], f.Bh[b], acc[a][b]);
+                    for (int b = 0; b < 3; ++b) acc[a][b] = Op::mfma(f.Al[a], f.Bh[b], acc[a][b]);
+            }
         };
         Frags fa, fb;
         fetch(0, fa);
@@ -414,12 +424,14 @@ struct Fused {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if constexpr (WGLO) {
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int b = 0; b < 3; ++b)
+                for (int b = 0; b < 3; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[a][b][r] += cc[a][b][r] * INV_LS;
+                    for (int r = 0; r < 4; ++r) acc[a][b][r] += cc[a][b][r] * INV_LS;
+        }
     }
     // bias gradient of three out-blocks (pair zp | single zs):  ones^T . Z of the value stream, both parts
     static __device__ __forceinline__ void wg_bias3(const char* zp0, const char* zp1, const char* zs0, const char* zs1, float (&bias_out)[3]) {
@@ -434,12 +446,14 @@ struct Fused {
             bm[0] = Op::mfma(ones, sfrag(zp0, zp1, oz), bm[0]);
             bm[1] = Op::mfma(ones, sfrag(zp0, zp1, oz + 8), bm[1]);
             bm[2] = Op::mfma(ones, sfrag(zs0, zs1, oz), bm[2]);
-            bc[0] = Op::mfma(ones, sfrag(zp0, zp1, oz + 1024), bc[0]);
-            bc[1] = Op::mfma(ones, sfrag(zp0, zp1, oz + 1024 + 8), bc[1]);
-            bc[2] = Op::mfma(ones, sfrag(zs0, zs1, oz + 1024), bc[2]);
+            if constexpr (WGLO) {
+                bc[0] = Op::mfma(ones, sfrag(zp0, zp1, oz + 1024), bc[0]);
+                bc[1] = Op::mfma(ones, sfrag(zp0, zp1, oz + 1024 + 8), bc[1]);
+                bc[2] = Op::mfma(ones, sfrag(zs0, zs1, oz + 1024), bc[2]);
+            }
         }
 #pragma unroll
-        for (int b = 0; b < 3; ++b) bias_out[b] = bm[b][0] + bc[b][0] * INV_LS;
+        for (int b = 0; b < 3; ++b) bias_out[b] = WGLO ? bm[b][0] + bc[b][0] * INV_LS : bm[b][0];
     }
 
     struct WgCtx {                     // lane bases of a weight-gradient wave (chain wave 0's tensors + the lane part)
@@ -489,26 +503,28 @@ struct Fused {
 #pragma unroll
             for (int i = 0; i < IBW; ++i) {
                 Ah[i] = sfrag(s0 + ia[i], s1 + ia[i], st * KS * SP * 1024);
-                Al[i] = sfrag(s0 + ia[i], s1 + ia[i], st * KS * SP * 1024 + 1024);
+                if constexpr (WGLO) Al[i] = sfrag(s0 + ia[i], s1 + ia[i], st * KS * SP * 1024 + 1024);
             }
 #pragma unroll
             for (int b = 0; b < NBK; ++b) {
                 Bh[b] = sfrag(z0 + oz[O0 + b], z1 + oz[O0 + b], st * KS * NP * 1024);
-                Bl[b] = sfrag(z0 + oz[O0 + b], z1 + oz[O0 + b], st * KS * NP * 1024 + 1024);
+                if constexpr (WGLO) Bl[b] = sfrag(z0 + oz[O0 + b], z1 + oz[O0 + b], st * KS * NP * 1024 + 1024);
             }
 #pragma unroll
             for (int i = 0; i < IBW; ++i)
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
                     acc[i][b] = Op::mfma(Ah[i], Bh[b], acc[i][b]);
-                    cc[i][b] = Op::mfma(Ah[i], Bl[b], cc[i][b]);
-                    acc[i][b] = Op::mfma(Al[i], Bh[b], acc[i][b]);
+                    if constexpr (WGLO) {
+                        cc[i][b] = Op::mfma(Ah[i], Bl[b], cc[i][b]);
+                        acc[i][b] = Op::mfma(Al[i], Bh[b], acc[i][b]);
+                    }
                 }
             if (st == 0) {                    // bias gradient = ones^T . Z (value stream)
 #pragma unroll
                 for (int b = 0; b < NBK; ++b) {
                     bm[b] = Op::mfma(ones, Bh[b], bm[b]);
-                    bc[b] = Op::mfma(ones, Bl[b], bc[b]);
+                    if constexpr (WGLO) bc[b] = Op::mfma(ones, Bl[b], bc[b]);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -518,9 +534,9 @@ struct Fused {
 #pragma unroll
             for (int b = 0; b < NBK; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[i][b][r] += cc[i][b][r] * INV_LS;
+                for (int r = 0; r < 4; ++r) acc[i][b][r] += WGLO ? cc[i][b][r] * INV_LS : 0.0f;
 #pragma unroll
-        for (int b = 0; b < NBK; ++b) bias_out[b] = bm[b][0] + bc[b][0] * INV_LS;
+        for (int b = 0; b < NBK; ++b) bias_out[b] = WGLO ? bm[b][0] + bc[b][0] * INV_LS : bm[b][0];
         // A THIRD hazard hipcc does not see (found on the GPU, round 3; the x86 emulator cannot show it): a 16-byte buffer store whose data
         // registers a vector instruction overwrites in the NEXT issue slot stores the new value in its last dword.  The compiler pads that
         // hazard only for stores without a scalar offset register; ours have one.  Written as "store; fma into the same registers; store",
@@ -1260,6 +1276,10 @@ struct Fused {
 #endif
     }
 
+    // (Round 4, measured and NOT adopted: the elementwise work on PAIRS of accumulator rows with v_pk_mul / v_pk_add / v_pk_fma_f32.  Standing
+    // alone a packed instruction issues at the rate of its scalar form and does two values -- but next to an MFMA it does not issue in the
+    // MFMA's shadow: a group "1 MFMA + 1 v_pk_*" takes 33 cycles where "1 MFMA + 2 scalar" takes 17 (tools/probes/opcode_cost_probe.hip,
+    // profiles/r04_opcode_issue_costs.md).  10 % fewer vector instructions, the same launch time: tools/experiments/r4_chain_issue_experiments.patch.)
     // vector part of a forward block: activation of the value stream, tangent streams, split into the next layer's operand
     template <int MB, int KSF = KS>
     static __device__ __forceinline__ void fwd_valu(const f32x4 (&acc)[NS], u32x4 (&Bn)[NS][1][KSF][NP]) {
@@ -1352,14 +1372,18 @@ struct Fused {
             if constexpr (MB == 0) {
                 if (!next_is_out) bb[1] = load_bias(x, l + 1, 1);       // behind its use just above
             }
+            {
             fwd_ksteps<0, KS, KS>(A[MB + 1], in, anxt);
             fwd_valu<MB>(acur, out);
+            }
             if constexpr (NS == 4 && NP == 2) interleave<NS * KS * P3, 2>();
         } else {
             // last block: the next layer's block 0 starts on the finished half of `out`
             acc_init(bb[0], anxt);
+            {
             fwd_ksteps<0, KOVL, KS>(A[0], out, anxt);
             fwd_valu<MB>(acur, out);
+            }
             __builtin_amdgcn_sched_barrier(0);
             operands_ready<KS>(out, KS - 1);
             fwd_ksteps<KOVL, KS, KS>(A[0], out, anxt);

@@ -403,6 +403,7 @@ struct Host {
                 for (int k = 0; k < nsets; ++k)
                     for (int i = 0; i < 8; ++i) { const float v = sets[k].tw[i] < 0 ? -sets[k].tw[i] : sets[k].tw[i]; if (v > twmax) twmax = v; }
                 twmax *= (float)(1u << c.adj_shift);
+                if constexpr (F::WG_HI) twmax *= 1.0f / F::ZDB_SEED_SCALE;
                 long s0 = 0;
                 for (int k = 0; k < 4; ++k) {
                     const bool on = k < nsets;
@@ -421,7 +422,7 @@ struct Host {
             } else {
                 for (int i = 0; i < 16; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
                 twmax *= (float)(1u << c.adj_shift);
-                if constexpr (F::ZDB) twmax *= 1.0f / F::ZDB_SEED_SCALE;      // adjoint seeds x 16: the weight gradient's fp16 adjoints in the normal range (Fused::ZDB)
+                if constexpr (F::WG_HI) twmax *= 1.0f / F::ZDB_SEED_SCALE;      // adjoint seeds x 16: the weight gradient's fp16 adjoints in the normal range (Fused::ZDB)
                 for (int i = 0; i < 16; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
                 a.nsets = 1;
                 lo.p[0] = c.loss_out;

@@ -98,6 +98,44 @@ static void run_mfma(long* d_out) {
     }
 }
 
+// ---- which vector opcodes issue in the shadow of an MFMA?  group = 1 MFMA (16 rotating accumulators) + NV instructions of KIND (8 chains)
+template <int KIND, int NV>
+__global__ __launch_bounds__(512) void probe_mfma_x(long* out, int iters, float seed) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    f32x4 acc[16];
+    float v[8];
+    f32x2 p[8];
+    const f32x2 cc = {seed, seed};
+    for (int i = 0; i < 16; ++i) acc[i] = f32x4{seed, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 8; ++i) { v[i] = seed * (i + 1); p[i] = f32x2{seed, seed * i}; }
+    h8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (_Float16)(seed * 0.01f); b[i] = (_Float16)(seed * 0.02f); }
+    __syncthreads();
+    const long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[k % 16]) : "v"(a), "v"(b));
+#pragma unroll
+            for (int j = 0; j < NV; ++j) op<KIND>(v[(k * NV + j) % 8], p[(k * NV + j) % 8], seed, cc);
+        }
+    }
+    const long t1 = __builtin_readcyclecounter();
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) s += v[i] + p[i][0] + p[i][1];
+    for (int i = 0; i < 16; ++i) s += acc[i][0];
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * 8 + (threadIdx.x >> 6)] = (t1 - t0) + (s == 12345.f ? 1 : 0);
+}
+template <int KIND, int NV>
+static void run_mfma_x(long* d_out) {
+    const int iters = 200;
+    for (int waves : {4, 8}) {
+        for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((probe_mfma_x<KIND, NV>), dim3(256), dim3(64 * waves), 0, 0, d_out, iters, 1.0f);
+        printf("MFMAX %-28s per_mfma %d waves_per_simd %d cycles_per_group %.2f\n", NAMES[KIND], NV * (KIND == K_MIXLOHI ? 2 : 1), waves / 4, collect(d_out, waves, (double)iters * 32));
+    }
+}
+template <int KIND> static void all_x(long* d) { run_mfma_x<KIND, 1>(d); run_mfma_x<KIND, 2>(d); run_mfma_x<KIND, 3>(d); }
+
 // ---- LDS: reads / writes of the kinds the chain and weight-gradient waves issue, NQ in flight before the wait
 enum { L_READ_B64, L_READ_B128, L_WRITE_B128, L_READ2ST64, L_READ_TR, L_N };
 static const char* LNAMES[L_N] = {"ds_read_b64", "ds_read_b128", "ds_write_b128", "ds_read2st64_b64", "ds_read_b64_tr_b16"};
@@ -146,6 +184,8 @@ int main() {
     all<K_EXP>(d); all<K_RCP>(d); all<K_PKMUL>(d); all<K_PKFMA>(d); all<K_PERM>(d);
     run_mfma<1, 0>(d); run_mfma<2, 0>(d); run_mfma<4, 0>(d); run_mfma<16, 0>(d);
     run_mfma<16, 1>(d); run_mfma<16, 2>(d); run_mfma<16, 3>(d); run_mfma<16, 4>(d); run_mfma<4, 2>(d); run_mfma<4, 3>(d);
+    all_x<K_FMA>(d); all_x<K_MUL>(d); all_x<K_MOV>(d); all_x<K_MIXF32>(d); all_x<K_MIXLO>(d); all_x<K_MIXLOHI>(d); all_x<K_CVTPK>(d); all_x<K_EXP>(d);
+    all_x<K_RCP>(d); all_x<K_PKMUL>(d); all_x<K_PKFMA>(d); all_x<K_PERM>(d);
     all_lds<L_READ_B64>(d); all_lds<L_READ_B128>(d); all_lds<L_WRITE_B128>(d); all_lds<L_READ2ST64>(d); all_lds<L_READ_TR>(d);
     return 0;
 }
