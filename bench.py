@@ -470,7 +470,7 @@ def main():
                 else:
                     out["cpu_baseline"] = cpu_baseline([3] + 8 * [args.width] + [7], 32768, 3, f"8x{args.width}")
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()          # rank 0 is still profiling its kernel: leave together
         torch.distributed.destroy_process_group()
 

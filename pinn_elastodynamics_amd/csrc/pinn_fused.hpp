@@ -1318,27 +1318,39 @@ struct Fused {
     }
 
     // forward: park the high parts of state S_l as the tile's register image (scratch), or straight into its LDS slot
+    // Called in every block step MB of the layer that consumes S_l (it stays in registers as that layer's MFMA operand): the scratch stores
+    // are SPREAD over the layer's block steps -- stream MB's records in step MB (round 4).  Issued as one burst in step 0, the 16 stores of a
+    // layer filled the wave's vector-memory queue and each cost it ~50 cycles of issue (ablation: all parks 4.7 k cycles of a 78 k step).
+    // Every step issues its stores BEHIND its weight-fragment loads, and a load waited for in a later step was issued after at most one
+    // step's stores, long acknowledged by then (vector-memory operations complete in order on one counter).
+    static constexpr bool SPREAD_PARKS = !SLDS && !LDSOP && WB >= NS - 1;
+    template <int MB>
     static __device__ __forceinline__ void park_state(const Ctx& x, int l, const u32x4 (&Sf)[NS][1][KS][NP]) {
+        constexpr bool FIRST = MB == 0;
+        // streams parked in this step: all in step 0 (no spreading), or stream MB (+ the streams beyond WB - 1 in the last step)
+        auto mine = [&](int s) { return SPREAD_PARKS ? (s == MB || (MB == WB - 1 && s >= WB)) : FIRST; };
         if constexpr (SLDS) {
-            put_image<KS>(x.imgS(l), Sf);               // the tile's own records of slot l; nobody else touches them in the forward
+            if constexpr (FIRST) put_image<KS>(x.imgS(l), Sf);               // the tile's own records of slot l; nobody else touches them in the forward
         } else if (RECOMP1 && l == 1) {
             return;                                     // recomputed by the reverse (hi and lo)
         } else if (kept_in_lds(l)) {
-            if (l == FIRST_KEPT) lds_barrier();         // (see KEEP2)
-            put_image<KS>(x.imgS(l), Sf);
+            if constexpr (FIRST) {
+                if (l == FIRST_KEPT) lds_barrier();     // (see KEEP2)
+                put_image<KS>(x.imgS(l), Sf);
+            }
         } else {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk)
-                    __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][0], x.scr, x.imgoff, (l - 1) * IMG_B + (s * KS + kk) * 1024, 0);
+                    if (mine(s)) __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][0], x.scr, x.imgoff, (l - 1) * IMG_B + (s * KS + kk) * 1024, 0);
         }
         if constexpr (STATE_LO) {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int kk = 0; kk < KS; ++kk)
-                    __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][NP - 1], x.scr, x.imgoff, SCRATCH_LO + (l - 1) * IMG_B + (s * KS + kk) * 1024, 0);
+                    if (mine(s)) __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][NP - 1], x.scr, x.imgoff, SCRATCH_LO + (l - 1) * IMG_B + (s * KS + kk) * 1024, 0);
         }
     }
 
@@ -1359,7 +1371,7 @@ struct Fused {
         f32x4 (&acur)[NS] = (MB & 1) ? accb : acca;      // block MB, complete
         f32x4 (&anxt)[NS] = (MB & 1) ? acca : accb;      // block MB+1
         if (MB == 0 || !next_is_out) load_afrags<KS, FP>(x, nfrag0 + MB * KS, A[MB]);
-        if constexpr (MB == 0) park_state(x, l, in);
+        if constexpr (MB == 0 || SPREAD_PARKS) park_state<MB>(x, l, in);
         // accumulator start values (LDS table), requested a block step or more ahead of their use.  bb[m], m >= 1: block m of this
         // layer (bb[1] was requested during the previous layer); bb[0]: block 0 of the next layer.
         if constexpr (MB == 0) {

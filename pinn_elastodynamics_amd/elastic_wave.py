@@ -355,14 +355,25 @@ class DeepHPM(NetApi):
         all-reduces.  Returns nothing; everything stays on the device.  Single process only: ``sums_out`` (a view of
         8*len(_SLOTS) floats, zero where no set exists) receives the sums directly instead of the tail of the buffer."""
         P, lay, eng, buf = self.n_params, self.layout, self.engine, self._buf
+        n_blk = idx_end - idx_start
+        s, e = self._shard(idx_start, idx_end)
+        # slots this call's kernels (over)write: the collocation slot if this rank has rows of the block, every active non-empty side set
+        writes = {0} if e > s else set()
+        for k, name in enumerate(_SLOTS[1:], start=1):
+            if name in self._sides and lay[name] != 0.0 and self._sides[name][0].numel() > 0:
+                writes.add(k)
         if sums_out is None or self._reduce:
             sums = buf[P:]
-            sums.zero_()                    # slots of skipped sets must read zero (getloss toggles the NB weight)
+            # slots of skipped sets must read zero (getloss toggles the NB weight; a rank without rows of a set contributes nothing to the
+            # reduced sum).  The kernels overwrite their slots, so only a slot that was written before and is NOT written now needs zeroing
+            # -- in a training loop the same slots are written every step and no launch is spent here.
+            stale = getattr(self, "_slots_dirty", set(range(len(_SLOTS)))) - writes
+            for k in stale:
+                sums[8 * k:8 * k + 8].zero_()
+            self._slots_dirty = set(writes)
         else:
             sums = sums_out
         grad = buf[:P]
-        n_blk = idx_end - idx_start
-        s, e = self._shard(idx_start, idx_end)
         tw = [lay["f_uv"] / n_blk] * 4 + [lay["f_s"] / n_blk] * 3
         wrote = False
         if e > s:

@@ -13,4 +13,8 @@ python bench.py --width 80 --points-per-gpu 1000000 --no-cpu-baseline --extra-mo
 python bench.py --width 100 --points-per-gpu 1000000 --no-cpu-baseline --extra-modes none > $OUT/${TAG}_bench_wave100.json 2> $OUT/bench_wave100.err
 python bench.py --points-per-gpu 250000 --no-cpu-baseline --extra-modes none > $OUT/${TAG}_bench_250k.json 2> $OUT/bench_250k.err
 python tools/conf_time.py > $OUT/${TAG}_conf_time.txt 2>&1
-tail -n 3 $OUT/${TAG}_bench_*.json $OUT/${TAG}_conf_time.txt
+python bench.py --points-per-gpu 250000 --no-cpu-baseline --extra-modes none --no-small-config --always-reduce > $OUT/${TAG}_bench_250k_rccl.json 2> $OUT/bench_250k_rccl.err
+bash tools/pmc_collect.sh prod 80 > $OUT/pmc80.log 2>&1; cp $OUT/pmc_prod_80/summary.json $OUT/${TAG}_wide80_pmc_summary.json
+bash tools/pmc_collect.sh prod 100 > $OUT/pmc100.log 2>&1; cp $OUT/pmc_prod_100/summary.json $OUT/${TAG}_wide100_pmc_summary.json
+bash tools/pmc_collect.sh prod nc3d > $OUT/pmc_nc3d.log 2>&1; cp $OUT/pmc_prod_nc3d/summary.json $OUT/${TAG}_nc3d_pmc_summary.json
+tail -c 600 $OUT/${TAG}_bench_*.json; cat $OUT/${TAG}_conf_time.txt
