@@ -205,6 +205,12 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd, env=env))
 
+    # ONE JSON line on stdout: libraries that print banners on the C-level stdout (RCCL's version block, on first use of a communicator) get
+    # stderr for the duration of the run; file descriptor 1 is restored right before rank 0 prints its line
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -469,10 +475,13 @@ def main():
                     out["cpu_baseline"] = cpu_baseline_plate(c)
                 else:
                     out["cpu_baseline"] = cpu_baseline([3] + 8 * [args.width] + [7], 32768, 3, f"8x{args.width}")
-        print(json.dumps(out))
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()          # rank 0 is still profiling its kernel: leave together
         torch.distributed.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(stdout_fd, 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

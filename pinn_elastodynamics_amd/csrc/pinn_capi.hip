@@ -189,6 +189,7 @@ static int prepare(const float* params, const int* layers, int n_layers, const f
     c.prof_ms = g_prof_ms;
     c.ring = g_ring.armed ? &g_ring : nullptr;
     c.use_fused = two_kernel ? 0 : g_use_fused;
+    c.one_stream_head = 0;
     c.dbg_stamps = g_dbg_stamps;
     return PINN_OK;
 }

@@ -66,6 +66,8 @@ struct FusedArgs {
     const float* set_targets[4];
     long set_n[4];
     float set_tw[4][8];
+    int set_head[4];           // 0: data head (targets, output weights); 1: hole traction of the plate's composite fields (PLATE:452-461)
+    const float* set_aux[4];   // traction sets: [12][n] = D0[5], P0[5], nx, ny of the set's points
     u32x4* scratch;            // [gridDim.x * TILES][SCRATCH_BYTES]: per-tile images of the parked states
     float* loss_part;          // [gridDim.x * TILES][8]
     float* partial;            // [gridDim.x][nparams]
@@ -2129,6 +2131,26 @@ struct Fused {
             adj[3][1] = g[3];
             adj[3][2] = -a.rho * g[0];
             adj[3][3] = -a.rho * g[1];
+        } else if (a.set_head[set] == 1) {
+            // net_t PLATE:452-461 on the composite values F = P + D N (value stream only); the set's aux rows: D0[0..4], P0[5..9], nx[10], ny[11]
+            const float* aux = a.set_aux[set];
+            const long nn = a.set_n[set];
+            float Fv[5], D0[5];
+#pragma unroll
+            for (int o = 0; o < 5; ++o) {
+                D0[o] = aux[(long)o * nn + pidx];
+                Fv[o] = aux[(long)(5 + o) * nn + pidx] + D0[o] * Y[0][o];
+            }
+            const float nx = aux[10L * nn + pidx], ny = aux[11L * nn + pidx];
+            const float tx = Fv[2] * nx + Fv[4] * ny, ty = Fv[4] * nx + Fv[3] * ny;
+            if (q == 0) {
+                lsum[0] += vm * tx * tx;
+                lsum[1] += vm * ty * ty;
+            }
+            const float gx = 2.0f * in_loop(a.set_tw[set][0]) * tx * vm, gy = 2.0f * in_loop(a.set_tw[set][1]) * ty * vm;
+            adj[0][2] = gx * nx * D0[2];
+            adj[0][3] = gy * ny * D0[3];
+            adj[0][4] = (gx * ny + gy * nx) * D0[4];
         } else {
 #pragma unroll
             for (int o = 0; o < 8; ++o) {

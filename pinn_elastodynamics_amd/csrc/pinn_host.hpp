@@ -17,6 +17,8 @@ struct DataSet {                // one value-only point set of pinn_data_loss_gr
     long n;
     float tw[8];
     float* loss_out;
+    int head = 0;              // 0: sum_o w_o (Y_o - target_o)^2;  1: hole traction of the plate's composite fields (HEAD_TRACTION), `aux` = [12][n]
+    const float* aux = nullptr;
 };
 
 // Asynchronous launch timing (pinn_debug_profile_ring_arm / _read): while armed, every launch of a fused kernel is bracketed by HIP
@@ -76,6 +78,7 @@ struct Call {
     int adj_shift;             // PINN_ADJOINT_SHIFT(k): adjoint seeds scaled by 2^-k inside the kernels, the gradient by 2^k at the reduction
     int weights_packed;        // skip the repack: the workspace already holds the packed form of `params` (same net / precision mode)
     int use_fused;             // 1: prefer the fused kernel where it applies (default), 0: force the two-kernel path
+    int one_stream_head;       // single-set one-stream calls: 0 = data head, 1 = hole traction (fused one-stream kernel, see DataSet::head)
     int fast_state;            // PINN_FLAG_STATE_FP16: fused kernel parks its states as fp16 high parts only (faster, less accurate at trained weights)
 };
 
@@ -364,6 +367,8 @@ struct Host {
         sets[0].n = c.n;
         for (int i = 0; i < 8; ++i) sets[0].tw[i] = c.tw[i];
         sets[0].loss_out = c.loss_out;
+        sets[0].head = c.one_stream_head;
+        sets[0].aux = c.aux;
         return 1;
     }
 
@@ -413,6 +418,8 @@ struct Host {
                     a.set_t[k] = on ? sets[k].t : nullptr;
                     a.set_targets[k] = on ? sets[k].targets : nullptr;
                     a.set_n[k] = on ? sets[k].n : 0;
+                    a.set_head[k] = on ? sets[k].head : 0;
+                    a.set_aux[k] = on ? sets[k].aux : nullptr;
                     for (int i = 0; i < 8; ++i) a.set_tw[k][i] = on && twmax > 0.0f ? sets[k].tw[i] / twmax : 0.0f;
                     if (on) { s0 += (sets[k].n + 16 * F::TILES - 1) / (16 * F::TILES); lo.p[k] = sets[k].loss_out; }
                 }
@@ -587,7 +594,15 @@ struct Host {
         return PINN_ERR_PRECISION;
     }
     static int traction_loss_grad(const Call& c) {
-        if constexpr (SPLIT == 3) return loss_grad<1, HEAD_TRACTION>(c, 2);
+        if constexpr (SPLIT == 3) {
+            // the hole-traction set through the one-stream instantiation of the fused kernel (its head takes the set's kind from the set
+            // table: round 4; the plate's last user of the two-kernel path)
+            int rc = 0;
+            Call t = c;
+            t.one_stream_head = 1;
+            if (c.use_fused && try_fused<1>(t, &rc, 2)) return rc;
+            return loss_grad<1, HEAD_TRACTION>(c, 2);
+        }
         return PINN_ERR_PRECISION;
     }
     static int stream_loss_grad(const Call& c) {

@@ -648,3 +648,42 @@ def test_weight_beyond_the_fused_format_is_detected_emulated(emu):
     assert np.isnan(out["fused"][0]).all() and np.isnan(out["fused"][1]).all()
     # (a weight of 3000 carries an absolute rounding error of 3000 * 2^-22 into its pre-activation: the gradient is good to ~1e-4 there)
     assert rel(out["two_kernel"][0], ss) < 2e-6 and rel(out["two_kernel"][1], g) < 5e-4
+
+
+@pytest.mark.parametrize("lN,n", [([3] + 4 * [24] + [5], 150), ([3] + 8 * [64] + [5], 90), ([3] + 8 * [70] + [5], 70)])
+def test_hole_traction_through_the_fused_one_stream_kernel_emulated(emu, lN, n):
+    """round 4: the plate's hole-traction set (net_t, PLATE:452-461: composite values P + D N, normals) through the ONE-STREAM instantiation
+    of the fused kernel -- its head takes the set's kind from the set table -- against the oracle and the two-kernel path it replaces
+    (narrow layouts: all layer states in LDS; 8 x 70: the LDS-operand layout of padded width 96)"""
+    from oracle import plate_oracle as pl
+    prec, LBp, UBp = "f16x3", [0, 0, 0], [0.5, 0.5, 10]
+    lD = [3, 10, 10, 5]
+    rng = np.random.default_rng(3)
+
+    def mk(l):
+        W, b = po.xavier_init(l, rng)
+        return po.pack_params(W, [0.2 * rng.standard_normal(x.shape) for x in b])
+
+    fN, fD, fP = mk(lN), mk(lD), mk(lD)
+    th = rng.random(n) * np.pi / 2
+    H = np.stack([0.1 * np.cos(th), 0.1 * np.sin(th), rng.random(n) * 10], 1)
+    hx, hy, ht = (H[:, k].astype(np.float32).copy() for k in range(3))
+    DH, PH = pl.net_streams(fD, lD, H[:, 0], H[:, 1], H[:, 2])[0], pl.net_streams(fP, lD, H[:, 0], H[:, 1], H[:, 2])[0]
+    ssh, gh = pl.traction_loss_grad(fN, lN, H[:, 0], H[:, 1], H[:, 2], DH, PH, weight=10.0 / n)
+    aux = np.ascontiguousarray(np.concatenate([DH, PH, (-H[:, 0] / 0.1)[None], (-H[:, 1] / 0.1)[None]]).astype(np.float32))
+    pN = fN.astype(np.float32)
+    wsb = emu.workspace_bytes(lN, n, prec)
+    res = {}
+    try:
+        for fused in (1, 0):
+            emu.set_fused(fused)
+            ws = aligned(wsb)
+            loss, grad = np.full(8, np.nan, np.float32), np.full(pN.size, np.nan, np.float32)
+            emu.plate2d_traction_loss_grad(pN.ctypes.data, lN, hx.ctypes.data, hy.ctypes.data, ht.ctypes.data, n, LBp, UBp, False, aux.ctypes.data,
+                                           [10.0 / n] * 2, loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+            res[fused] = (loss[:2].copy(), grad.copy())
+            # (the narrow fused layouts take the layer states as fp16 high parts in the weight gradient: 2^-12 / sqrt(n) of noise)
+            assert rel(loss[:2], ssh) < 2e-6 and rel(grad, gh) < ((2e-4 if lN[1] <= 64 else 3e-6) if fused else 2e-6), (fused, rel(grad, gh))
+    finally:
+        emu.set_fused(1)
+    assert not np.array_equal(res[1][1], res[0][1])          # two different code paths ran
