@@ -479,6 +479,11 @@ def main():
         torch.distributed.barrier()          # rank 0 is still profiling its kernel: leave together
         torch.distributed.destroy_process_group()
     sys.stdout.flush()
+    try:                                     # (what such a library has buffered in C stdio goes where it was sent: stderr)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     os.dup2(stdout_fd, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -32,7 +32,9 @@
 // address the compiler can hoist costs a VGPR for the whole launch): weights, biases and scratch
 // go through buffer descriptors with ONE lane-offset VGPR and scalar (SGPR) offsets; LDS accesses
 // use one lane-base VGPR per tensor plus compile-time immediates.
-// Two workgroup barriers per weight layer.
+// Two workgroup barriers per weight layer -- ONE in the narrow four-stream layout since round 4 (ZDB below: the weight gradient takes the
+// adjoints as fp16 high parts, the Z area holds two high-part images, and the chain wave writes Z_{L-1} into the other one while the
+// weight-gradient waves read Z_L).
 #pragma once
 #include "pinn_device.hpp"
 
