@@ -273,7 +273,7 @@ def main():
         step = lambda k: model.train(k, 1e-3)
         workload = (f"2D plate with hole (hard BC: composite P + D*N, nested u_tt, plane stress), 8x{args.width} tanh MLP + frozen 4x20 distance / particular "
                     f"nets, {pts_per_rank} collocation pts per GPU + 9960 hole-traction pts, Adam step ({'BASELINE configs[2]' if args.width == 64 else 'the reference script net, not a BASELINE config'}; its L-BFGS stage runs "
-                    f"on the host over the same kernels); collocation set through the five-stream fused kernel, hole traction through the two-kernel path; {PRECISION_NOTE}")
+                    f"on the host over the same kernels); collocation set through the five-stream fused kernel, hole traction through the one-stream fused kernel; {PRECISION_NOTE}")
     else:
         from pinn_elastodynamics_amd.navier_cauchy_3d import NavierCauchy3D, halfspace_case
         c = halfspace_case(n_collo=n_global, n_ic=20000, n_top=20000, n_src=(200, 100), seed=1111, width=128, depth=10)
@@ -351,7 +351,11 @@ def main():
         "whole_path": {"achieved_tflops": flop_pt * value / 1e12, "frac_of_mfma_peak": flop_pt * value / 1e12 / (MFMA_PEAK_TFLOPS * world)},
     }
     if rank == 0:
-        issued = (8 * 3 + 4 * 2) / 12.0 if args.precision in ("f16x3", "bf16x3") else 1.0
+        # MFMAs issued per algorithmic product (forward and reverse chain: 8 of 12 contractions, 3 per product; weight gradient: 4 of 12): the
+        # narrow four-stream wave kernel multiplies high parts only there (1, round 4), the other narrow layouts state (hi) x adjoint (hi + lo) (2),
+        # the LDS-operand layouts (padded width > 64) both parts of both (3)
+        wg_mfma = 3 if (args.width > 64 or cfg == "nc3d") else (1 if cfg == "wave" else 2)
+        issued = (8 * 3 + 4 * wg_mfma) / 12.0 if args.precision in ("f16x3", "bf16x3") else 1.0
         if cfg == "wave":
             # ---- roofline of the dominant kernel: HIP events around its launches in the running step loop (the ring block above); on
             # the two-kernel path (no fused launch recorded) the synchronous per-kernel profile of one call
@@ -380,8 +384,8 @@ def main():
                                "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (one product per contraction) / mean HIP-event duration of the launches of one "
                                        "more block of steps behind the timed ones (events in stream order, nothing synchronises in between); the f16x3 mode issues 3 MFMAs per "
-                                       "product in the forward / reverse chain and 2 in the weight gradient, so a 100 %-busy matrix pipe is frac 0.375. "
-                                       "Measured limiter: the SIMD's instruction issue, not a pipe (DESIGN.md section 6). traffic is not measured in this "
+                                       f"product in the forward / reverse chain and {wg_mfma} in the weight gradient, so a 100 %-busy matrix pipe is frac {1.0 / issued:.3f}. "
+                                       "Measured limiter: one wave's in-order issue of vector instructions + MFMAs and its vector-memory instructions (DESIGN.md section 6, profiles/r04_opcode_issue_costs.md). traffic is not measured in this "
                                        "run (PMC counters need rocprofv3); see traffic_from_profiles"}
             out["kernel_ms_per_step"] = acc
         elif cfg == "plate" and eng.lib.supported_width(layers[1]) <= 96 and len(layers) - 2 in (4, 8):
@@ -395,8 +399,8 @@ def main():
                                "traffic": None, "launches_per_step": 1, "avg_launch_ms": acc["chain"], "algorithmic_flop_per_point": flop_pt,
                                "launches_timed": int(collo_ms.size), "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
-                                       "gradient) / HIP-event launch time of the collocation launch; the hole-traction set (9960 points) runs on the "
-                                       "two-kernel path.  traffic not measured in this run"}
+                                       "gradient) / HIP-event launch time of the collocation launch; the hole-traction set (9960 points) is a second, one-stream "
+                                       "launch of the fused kernel.  traffic not measured in this run"}
             out["kernel_ms_per_step"] = acc
         elif cfg == "nc3d" and args.precision == "f16x3" and layers[1:-1] == [128] * 10:
             # ---- the 3-D instantiation of the fused kernel (Fused<..., NL = 10, NS = 5, DIN = 4>): HIP events around the collocation launch
