@@ -37,6 +37,9 @@
 // weight-gradient waves read Z_L).
 #pragma once
 #include "pinn_device.hpp"
+#ifndef PINN_LO8_ENABLED
+#define PINN_LO8_ENABLED 1
+#endif
 
 namespace pinn {
 
@@ -205,6 +208,29 @@ struct Fused {
     // reference's trained weights is 5e-3 off in the first-layer blocks -- fp32: 2e-4 --, amplified by cancellation)
     static constexpr bool STATE_LO = !LDSOP && NP == 2 && !FASTSTATE;
     static constexpr unsigned SCRATCH_LO = (unsigned)((NL - 1) * IMG_B);          // byte offset of the low-part images
+    // LO8 (round 4, the narrow collocation kernels -- wave head and plate head -- of padded width 64): the parked LOW parts travel as ONE BYTE per value -- the top byte of the fp16 low
+    // part, which is an e5m2 number (sign, the fp16 exponent, two mantissa bits) -- packed four to a dword by one v_perm_b32 and expanded back by
+    // two.  What the activation reverse needs of the low parts was measured in round 2 (first-layer gradient blocks of the reference's inf10s net
+    // against float64: exact states 8.5e-7, fp16 high parts only 7.7e-5, + 3 significant bits of low part 3.1e-6, + 8 bits 9.2e-7): a few bits
+    // carry it.  Half the low-part bytes each way, one 16-byte store per stream and layer instead of two, four 16-byte loads per layer (requested
+    // with the layer's first fragments) instead of sixteen 8-byte ones.  The launch is sensitive to its bytes through the vector-memory path more
+    // than to the instructions that move them (DESIGN section 6 "Round 4"); the low image of a layer is then NS records: (stream) -> 16 bytes per
+    // lane = the four blocks' four values each.
+    static constexpr bool LO8 = PINN_LO8_ENABLED && !LDSOP && !SLDS && WB == 4 && NP == 2 && !FASTSTATE && KS == 2;      // (four- and five-stream narrow layouts)
+    static __device__ __forceinline__ uint32_t lo8_pack(uint32_t rows01, uint32_t rows23) {       // the high bytes of four fp16 values
+#if defined(__AMDGCN__)
+        return __builtin_amdgcn_perm(rows23, rows01, 0x07050301u);
+#else
+        return ((rows01 >> 8) & 0xffu) | (((rows01 >> 24) & 0xffu) << 8) | (((rows23 >> 8) & 0xffu) << 16) | (((rows23 >> 24) & 0xffu) << 24);
+#endif
+    }
+    static __device__ __forceinline__ u32x2 lo8_unpack(uint32_t p) {                              // back to two fp16 pairs, low bytes zero
+#if defined(__AMDGCN__)
+        return u32x2{__builtin_amdgcn_perm(p, p, 0x010c000cu), __builtin_amdgcn_perm(p, p, 0x030c020cu)};
+#else
+        return u32x2{((p & 0xffu) << 8) | (((p >> 8) & 0xffu) << 24), (((p >> 16) & 0xffu) << 8) | (((p >> 24) & 0xffu) << 24)};
+#endif
+    }
     // LSUM_MEM (the 3-D kernel): the per-lane loss sums live in a 4 KB tail of the tile's scratch image instead of 16 registers per lane.
     // As registers they are live through the whole step and touched once: the compiler spilled them, and reloaded them in the head ONE BY
     // ONE behind a full vmcnt(0) each -- 20 memory round trips, 21 k cycles of a 419 k step (tools/phase_trace_3d.py).  In memory: 12 loads
@@ -1349,7 +1375,15 @@ struct Fused {
                 for (int kk = 0; kk < KS; ++kk)
                     if (mine(s)) __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][0], x.scr, x.imgoff, (l - 1) * IMG_B + (s * KS + kk) * 1024, 0);
         }
-        if constexpr (STATE_LO) {
+        if constexpr (LO8) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+                if (mine(s)) {
+                    const u32x4 &k0 = Sf[s][0][0][NP - 1], &k1 = Sf[s][0][1][NP - 1];
+                    const u32x4 rec = {lo8_pack(k0[0], k0[1]), lo8_pack(k0[2], k0[3]), lo8_pack(k1[0], k1[1]), lo8_pack(k1[2], k1[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(rec, x.scr, x.imgoff, SCRATCH_LO + (l - 1) * IMG_B + s * 1024, 0);
+                }
+        } else if constexpr (STATE_LO) {
 #pragma unroll
             for (int s = 0; s < NS; ++s)
 #pragma unroll
@@ -1488,9 +1522,13 @@ struct Fused {
     //   ZOUT (ZDB): the high parts of Zn go to the adjoint image `zout` as soon as a fragment (two blocks) is complete
     static __device__ __forceinline__ void bwd_step(const Ctx& x, int frag0, int L, const char* img, const u32x4 (&Sreg)[NS][1][KS][NP], const u32x4 (&Zf)[NS][1][KSB][NP],
                                                     u32x4 (&Zn)[NS][1][KS][NP], u32x4 (&Aa)[KSB][RP], u32x4 (&Ab)[KSB][RP], f32x4 (&acca)[NS], f32x4 (&accb)[NS],
-                                                    u32x2 (&sla)[NS], u32x2 (&slb)[NS], char* zout = nullptr) {
+                                                    u32x2 (&sla)[NS], u32x2 (&slb)[NS], char* zout = nullptr, const u32x4 (*slq)[NS] = nullptr) {
         u32x2 (&slcur)[NS] = (MB & 1) ? slb : sla;
         u32x2 (&slnxt)[NS] = (MB & 1) ? sla : slb;
+        if constexpr (!TOP && LO8) {                           // this block's four bytes of every stream -> two fp16 pairs
+#pragma unroll
+            for (int s = 0; s < NS; ++s) slcur[s] = lo8_unpack((*slq)[s][MB]);
+        }
         u32x4 (&Acur)[KSB][RP] = (MB & 1) ? Ab : Aa;
         u32x4 (&Anxt)[KSB][RP] = (MB & 1) ? Aa : Ab;
         f32x4 (&acur)[NS] = (MB & 1) ? accb : acca;
@@ -1502,7 +1540,7 @@ struct Fused {
             if constexpr (STATE_LO) lo_from_frags<MB>(Sreg, slcur);
         } else {
             state_from_image<MB>(img, sp);
-            if constexpr (MB + 1 < WB) lo_from_scratch<MB + 1>(x, L, slnxt);
+            if constexpr (MB + 1 < WB && !LO8) lo_from_scratch<MB + 1>(x, L, slnxt);
         }
         if constexpr (MB + 1 < WB) {
             acc_zero(anxt);
@@ -1514,7 +1552,7 @@ struct Fused {
             for (int s = 0; s < NS; ++s) *reinterpret_cast<u32x4*>(zout + (s * KS + (MB >> 1)) * 1024) = Zn[s][0][MB >> 1][0];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MB + 1 < WB) bwd_step<MB + 1, KSB, TOP, ZOUT>(x, frag0, L, img, Sreg, Zf, Zn, Aa, Ab, acca, accb, sla, slb, zout);
+        if constexpr (MB + 1 < WB) bwd_step<MB + 1, KSB, TOP, ZOUT>(x, frag0, L, img, Sreg, Zf, Zn, Aa, Ab, acca, accb, sla, slb, zout, slq);
     }
 
     // Force the fragments to be fully computed at this point: without it the compiler sinks the reverse elementwise work past
@@ -1561,12 +1599,16 @@ struct Fused {
         static __device__ __forceinline__ void run(const FusedArgs& a, const Ctx& x, const float (&xin)[4], const u32x4 (&Zc)[NS][1][KS][NP]) {
             u32x4 Aa[KS][RP], Ab[KS][RP];
             u32x2 sla[NS], slb[NS];
+            u32x4 slq[NS];                                     // (LO8: the layer's low parts, one 16-byte record per stream)
             constexpr bool RECOMP = RECOMP1 && L == 1;
             u32x4 S1[NS][1][KS][NP];                           // (RECOMP only)
             if constexpr (L >= 1) {                            // this layer's first fragments travel during the hand-off
                 load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 0, 0), Aa);
                 load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 1, 0), Ab);
-                if constexpr (!RECOMP) lo_from_scratch<0>(x, L, sla);
+                if constexpr (!RECOMP && LO8) {
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) slq[s] = __builtin_amdgcn_raw_buffer_load_b128(x.scr, x.imgoff, SCRATCH_LO + (L - 1) * IMG_B + s * 1024, 0);
+                } else if constexpr (!RECOMP) lo_from_scratch<0>(x, L, sla);
             }
             constexpr bool ONE_BARRIER = ZDB && L <= NL - 2;   // Z_L is in its buffer already: written by the reverse step that produced it
             if constexpr (!ONE_BARRIER) {
@@ -1594,7 +1636,7 @@ struct Fused {
                 // (ZDB: Z_{L-1} goes to the other adjoint buffer while the weight-gradient waves read Z_L from this layer's)
                 char* zout = x.imgZ() + zbuf(L - 1);
                 if constexpr (RECOMP) bwd_step<0, KS, true, ZDB>(x, FI::bwd_mid(NL, L, 0, 0), L, nullptr, S1, Zc, Zn, Aa, Ab, acca, accb, sla, slb, zout);
-                else bwd_step<0, KS, false, ZDB>(x, FI::bwd_mid(NL, L, 0, 0), L, x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb, sla, slb, zout);
+                else bwd_step<0, KS, false, ZDB>(x, FI::bwd_mid(NL, L, 0, 0), L, x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb, sla, slb, zout, &slq);
                 pin<KS>(Zn);
                 fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
                 Down<L - 1>::run(a, x, xin, Zn);

@@ -31,7 +31,7 @@ def wg(S, Z, mode, zscale):
     if mode == 'cur':
         Zh = r16(Z); Zl = r16((Z - Zh) * f32(2048))
         return Sh.T @ Zh + (Sh.T @ Zl) / f32(2048)
-    if mode.startswith('zhi') and mode != 'zhi_ns':
+    if mode.startswith('zhi') and mode != 'zhi_ns':      # (also 'zhi+lo8' / 'zhi+hi': the state-precision rows)
         return (Sh.T @ r16(Z * f32(zscale))) / f32(zscale)
     if mode == 'zhi_ns':
         return Sh.T @ r16(Z)
@@ -44,6 +44,16 @@ def bsum(Z, mode, zscale):
         return Zh.sum(0) + Zl.sum(0) / f32(2048)
     if mode == 'zhi_ns': return r16(Z).sum(0)
     return r16(Z * f32(zscale)).sum(0) / f32(zscale)
+
+STATE_MODE = 'full'      # what the ACTIVATION REVERSE sees of the parked states: 'full' (hi + fp16 lo), 'lo8' (hi + the low part's top byte, truncated: e5m2), 'hi'
+def parked(v):
+    v = np.asarray(v, f32)
+    if STATE_MODE == 'full': return v
+    hi = r16(v)
+    if STATE_MODE == 'hi': return hi
+    lo = (v - hi).astype(np.float16)
+    lo8 = (lo.view(np.uint16) & np.uint16(0xff00)).view(np.float16).astype(f32)      # top byte of the fp16 low part
+    return hi + lo8
 
 def run(X, Ws, bs, lb, ub, normalize, tw, mode, zscale):
     X = np.asarray(X, f32); N = X.shape[0]
@@ -69,11 +79,12 @@ def run(X, Ws, bs, lb, ub, normalize, tw, mode, zscale):
     hb = mm_bwd(Yb, Ws[-1].T); dhb = [mm_bwd(dYb[k], Ws[-1].T) for k in range(3)]
     for l in range(L - 2, 0, -1):
         h, dh = cache[l]; hin, dhin = cache[l - 1]
+        if l < L - 2: h, dh = parked(h), [parked(d) for d in dh]       # (the top state comes from the forward's registers)
         s = 1 - h * h
         zb = s * hb - 2 * h * sum(dhb[k] * dh[k] for k in range(3)); dzb = [s * dhb[k] for k in range(3)]
         Wbar[l] = wg(hin, zb, mode, zscale) + sum(wg(dhin[k], dzb[k], mode, zscale) for k in range(3)); bbar[l] = bsum(zb, mode, zscale)
         hb = mm_bwd(zb, Ws[l].T); dhb = [mm_bwd(dzb[k], Ws[l].T) for k in range(3)]
-    h, dh = cache[0]; s = 1 - h * h
+    h, dh = cache[0]; s = 1 - h * h      # (S_1 is recomputed in full)
     zb = s * hb - 2 * h * sum(dhb[k] * dh[k] for k in range(3)); dzb = [s * dhb[k] for k in range(3)]
     Wbar[0] = h0.T @ zb + np.stack([sc[k] * dzb[k].sum(0) for k in range(3)]); bbar[0] = zb.sum(0)
     zmax = max(float(np.abs(zb).max()), 0.0)
@@ -101,7 +112,9 @@ for case in cases:
         zscale = 2.0 ** np.round(np.log2(m))          # host-side loss scale: the term weights carry 1/N
         print(f'{case} n={m}: host fp32 rel err per W layer ' + ' '.join(f'{e:.1e}' for e in e32))
         eb32 = layer_errs(g32, g64, layers, True)
-        for mode, sc in (('full', 1), ('cur', 1), ('zhi/64', 1 / 64.), ('zhi/8', 1 / 8.), ('zhi', 1), ('zhi*16', 16), ('zhi*256', 256), ('zhi_ns', 1)):
+        for mode, sc, stm in (('full', 1, 'full'), ('cur', 1, 'full'), ('zhi/64', 1 / 64., 'full'), ('zhi/8', 1 / 8., 'full'), ('zhi', 1, 'full'), ('zhi*16', 16, 'full'),
+                              ('zhi*256', 256, 'full'), ('zhi_ns', 1, 'full'), ('zhi+lo8', 16, 'lo8'), ('zhi+hi', 16, 'hi')):
+            globals()['STATE_MODE'] = stm
             gv = run(Xm, Ws, bs, lb, ub, norm, tw, mode, zscale * sc)
             e = layer_errs(gv, g64, layers); eb = layer_errs(gv, g64, layers, True)
             print(f'   {mode:8s} W x fp32: ' + ' '.join(f'{a / b:5.1f}' for a, b in zip(e, e32)) + ' | b x fp32: ' + ' '.join(f'{a / b:5.1f}' for a, b in zip(eb, eb32)) + f' | all {np.linalg.norm(gv - g64) / np.linalg.norm(g64):.1e}')
