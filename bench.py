@@ -33,8 +33,9 @@ sys.path.insert(0, ROOT)
 
 LB, UB = [0.0, 0.0, 0.0], [30.0, 30.0, 20.0]
 MFMA_PEAK_TFLOPS = 2500.0                                        # bf16/f16 dense, MI355X_MICROARCH.md
-PRECISION_NOTE = ("f16x3 = fp16 operands split hi+lo, 3 MFMAs per product, fp32 accumulate, per-layer states kept in full precision for "
-                  "the reverse pass: fp32-class results also at trained weights (fields 3e-6 vs the float64 oracle); the plain bf16 mode named in "
+PRECISION_NOTE = ("f16x3 = fp16 operands split hi+lo, 3 MFMAs per product in the forward / reverse chain, fp32 accumulate; per-layer states reach the "
+                  "reverse pass as fp16 high part + low part (padded width 64: the low part's top byte, 14 significant bits in all; wider nets: both parts "
+                  "in full): fp32-class results also at trained weights (fields 3e-6 vs the float64 oracle, gradient blocks within fp32's own error); the plain bf16 mode named in "
                   "BASELINE.json fails field parity by 5-10 %, and the fp16-state variant of f16x3 (PINN_FLAG_STATE_FP16, 17 % faster) loses gradient "
                   "accuracy at trained weights: both are reported beside the headline, not as it")
 

@@ -43,7 +43,11 @@ enum {
                              fused kernels' weight format (32 w must stay finite in fp16).  A larger weight is DETECTED when the weights
                              are packed: the call then returns NaN in every gradient entry and every loss sum (never a plausible wrong
                              number) -- pass PINN_FLAG_TWO_KERNEL to evaluate such weights (the two-kernel path holds |w| up to 65504);
-                             pinn_fused_weight_limit() returns the bound. */
+                             pinn_fused_weight_limit() returns the bound;  (4) the collocation kernels of padded width 64 (wave and plate
+                             heads, 8 or 4 hidden layers) hand the per-layer states to their activation reverse as fp16 high part + the TOP BYTE
+                             of the fp16 low part (14 significant bits; round 4): measured at the reference's trained nets the gradient blocks
+                             stay where full low parts put them (tools/studies/wgrad_operand_study.py, the per-layer fp32 bounds of the GPU
+                             tests); PINN_FLAG_STATE_FP16 drops the low parts altogether and is NOT parity-grade. */
     PINN_PREC_F16 = 2,    /* fp16 operands, one MFMA per product */
     PINN_PREC_BF16X3 = 3, /* bf16 hi/lo split, three MFMAs per product (16-bit significand) */
     PINN_PREC_FP32 = 4,   /* plain fp32 FMA arithmetic, no matrix pipe (the reference's own precision, INF:71-92): ~100x slower,
