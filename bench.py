@@ -157,7 +157,9 @@ def traffic_from_profiles(name):
             if pm.get("kernel_source_sha") != sha:
                 return {"bytes_per_launch": None, "stale": f"profiles/{rnd}_{name}_pmc_summary.json was collected on kernel sources "
                                                             f"{pm.get('kernel_source_sha')}, this tree is {sha}"}
-            return {"bytes_per_launch": pm.get("hbm_bytes_per_launch"), "source": f"profiles/{rnd}_{name}_pmc_summary.json", "kernel_source_sha": sha,
+            pts = pm.get("points_per_launch")
+            return {"bytes_per_launch": pm.get("hbm_bytes_per_launch"), "points_per_launch": pts,
+                    "bytes_per_point": (pm.get("hbm_bytes_per_launch") / pts) if pts else None, "source": f"profiles/{rnd}_{name}_pmc_summary.json", "kernel_source_sha": sha,
                     "ea_read_bytes": pm.get("ea_read_bytes_per_launch"), "ea_write_bytes": pm.get("ea_write_bytes_per_launch"),
                     "note": "L2<->fabric request bytes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE; ea_*: TCC_EA0 request counters of the same "
                             "passes at 64 B per request -- a read request fetches a 128-byte line); the kernel's own parked states and in-memory "
@@ -353,9 +355,9 @@ def main():
     }
     if rank == 0:
         # MFMAs issued per algorithmic product (forward and reverse chain: 8 of 12 contractions, 3 per product; weight gradient: 4 of 12): the
-        # narrow four-stream wave kernel multiplies high parts only there (1, round 4), the other narrow layouts state (hi) x adjoint (hi + lo) (2),
-        # the LDS-operand layouts (padded width > 64) both parts of both (3)
-        wg_mfma = 3 if (args.width > 64 or cfg == "nc3d") else (1 if cfg == "wave" else 2)
+        # narrow four- and five-stream collocation kernels multiply high parts only there (1, round 4), the LDS-operand layouts (padded width
+        # > 64) both parts of both (3)
+        wg_mfma = 3 if (args.width > 64 or cfg == "nc3d") else 1
         issued = (8 * 3 + 4 * wg_mfma) / 12.0 if args.precision in ("f16x3", "bf16x3") else 1.0
         if cfg == "wave":
             # ---- roofline of the dominant kernel: HIP events around its launches in the running step loop (the ring block above); on
@@ -378,7 +380,7 @@ def main():
             tflops = kflop * pts_per_rank / (acc["chain"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": "fused_wave_kernel (forward + reverse chain + weight gradient)" if fused else "chain_kernel (forward + reverse chain)",
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
-                               "traffic": None, "traffic_from_profiles": traffic_from_profiles("fused") if fused and args.precision == "f16x3" and args.width == 64 else None,
+                               "traffic": None, "traffic_from_profiles": traffic_from_profiles({64: "fused", 80: "wide80", 100: "wide100"}.get(args.width, "none")) if fused and args.precision == "f16x3" else None,
                                "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch, "algorithmic_flop_per_point": kflop,
                                "launches_timed": int(collo_ms.size), "launch_ms_min_max": [float(collo_ms.min()), float(collo_ms.max())] if collo_ms.size else None,
                                "side_sets_launch_ms": float(side_ms.mean()) if side_ms.size else None,
@@ -397,7 +399,8 @@ def main():
             tflops = flop_pt * pts_per_rank / (acc["chain"] * 1e-3) / 1e12 if fused else 0.0
             out["roofline"] = {"kernel": "fused_wave_kernel<..., NS = 5> (forward with the second time derivative + plate head + reverse chain + weight gradient)",
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
-                               "traffic": None, "launches_per_step": 1, "avg_launch_ms": acc["chain"], "algorithmic_flop_per_point": flop_pt,
+                               "traffic": None, "traffic_from_profiles": traffic_from_profiles("plate") if fused and args.precision == "f16x3" and args.width == 64 else None,
+                               "launches_per_step": 1, "avg_launch_ms": acc["chain"], "algorithmic_flop_per_point": flop_pt,
                                "launches_timed": int(collo_ms.size), "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; the hole-traction set (9960 points) is a second, one-stream "
@@ -426,7 +429,8 @@ def main():
             out["roofline"] = {"kernel": "fused_wave_kernel<OpF16, 3, 128, 10, 5, false, 4> (3-D: forward with four tangent streams + 12-residual head + reverse "
                                          "chain + weight gradient)" if fused else "chain_kernel + wgrad_kernel (two-kernel path)",
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
-                               "traffic": None, "launches_per_step": n_launch, "avg_launch_ms": t_ms / n_launch, "algorithmic_flop_per_point": flop_pt,
+                               "traffic": None, "traffic_from_profiles": traffic_from_profiles("nc3d") if fused else None,
+                               "launches_per_step": n_launch, "avg_launch_ms": t_ms / n_launch, "algorithmic_flop_per_point": flop_pt,
                                "launches_timed": int(collo_ms.size), "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; measured limiter of the LDS-operand layouts: the bytes "

@@ -35,7 +35,7 @@ enum {
                              rounding of the same weights and, like it, the same for every point: where a residual is a > 1000-fold
                              cancellation of O(1) outputs (the plate's hole traction at trained weights) the gradient error does
                              not fall with the number of points as host fp32's does; (2) the weight gradient of padded widths <= 64
-                             takes the layer states as fp16 high parts, and in the four-stream collocation kernel the adjoints too (round 4: one
+                             takes the layer states as fp16 high parts, and in the four- and five-stream collocation kernels the adjoints too (round 4: one
                              MFMA per product; forward and reverse chain keep hi + lo): a random rounding noise of 3.5e-4 / sqrt(points)
                              relative to the gradient (1e-5 at 4096 points, 2.5e-7 at 2 M) that stays inside host-fp32's own per-layer error at
                              the reference's trained weights -- the wider layouts use both parts of both;

@@ -46,6 +46,7 @@ struct OpF16 {
     typedef f16x2 V2;
     // low part of the hi/lo split is stored scaled by 2^11 so that it keeps fp16's normal range
     static constexpr float LO_SCALE = 2048.0f;
+    static constexpr bool TOP_BYTE_IS_FLOAT = true;      // the top byte of a value is itself a float (e5m2): the fused kernel's one-byte low parts (LO8)
     static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(V8, a), __builtin_bit_cast(V8, b), c, 0, 0, 0);
     }
@@ -55,6 +56,7 @@ struct OpBF16 {
     typedef bf16x8 V8;
     typedef bf16x2 V2;
     static constexpr float LO_SCALE = 256.0f;
+    static constexpr bool TOP_BYTE_IS_FLOAT = false;     // (sign + seven of eight exponent bits)
     static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(V8, a), __builtin_bit_cast(V8, b), c, 0, 0, 0);
     }

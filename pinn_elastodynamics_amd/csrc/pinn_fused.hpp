@@ -186,8 +186,10 @@ struct Fused {
     // What it buys: the Z area (NS * KS * NP records per tile) holds TWO high-part images instead of one two-part image, so the chain
     // wave writes Z_{L-1} into the other buffer WHILE the weight gradient of layer L reads Z_L -- fragment by fragment as the reverse step
     // produces them, not as a burst in a hand-off window -- and a reverse layer needs ONE workgroup barrier, not two.
-    static constexpr bool ZDB = !LDSOP && !SLDS && NS_ == 4 && KS == 2 && NP == 2;
-    static constexpr float ZDB_SEED_SCALE = 16.0f;                  // host side: adjoint seeds x 16, gradient / 16 at the reduction (fused_launch)
+    // (Also the plate's five-stream narrow layout, with seed scale 1: its residuals at fresh weights are thousands -- E = 20 -- and x 16 would put
+    // the normalised seeds beyond fp16; the normalised scale alone has 8x of margin in the study.)
+    static constexpr bool ZDB = !LDSOP && !SLDS && (NS_ == 4 || (NS_ == 5 && DIN_ == 3)) && KS == 2 && NP == 2;
+    static constexpr float ZDB_SEED_SCALE = NS_ == 4 ? 16.0f : 1.0f;      // host side: adjoint seeds x 16, gradient / 16 at the reduction (fused_launch)
     static constexpr int ZNP = ZDB ? 1 : NP;                         // parts of an adjoint image in LDS
     // WGLO: the weight gradient also multiplies LOW parts (the adjoints' scaled low part; LDS-operand layouts: the states' too).  Off for ZDB
     // only.  (Round 4, measured and NOT adopted: high parts only in the LDS-operand layouts as well -- 8 x 80 6.2 -> 5.5 ms per 1 M points, but
@@ -195,12 +197,26 @@ struct Fused {
     // tests/test_gpu_parity.py in its FIRST layer, whose gradient fp32 itself gets to 1e-6: these layouts keep three MFMAs per product.)
     static constexpr bool WG_HI = ZDB;
     static constexpr bool WGLO = NP == 2 && !WG_HI;
+    // (Round 4, also measured and NOT adopted: high parts only in the MID layers of the padded-width-96 four-stream layout, first and last
+    // layer as they are -- 8 x 80 6.24 -> 5.70 ms per 1 M points, and the reference's inf10s net then misses the same bound in a MID layer:
+    // 1.8e-5 against fp32's 2.2e-7 on a block of norm 0.18, 1024 points.  At those weights the sum over points cancels, and the operand
+    // rounding does not average out as 1 / sqrt(points) of the RESULT.)
     static constexpr int ZBUF_B = NS * KS * 1024;                    // ZDB: one high-part adjoint image
     static __device__ __forceinline__ constexpr int zbuf(int L) { return ZDB ? (L & 1) * ZBUF_B : 0; }      // Z_L lives in buffer L & 1
     static constexpr int S_SLOTS = SLDS ? NL + 1 : BASE_SLOTS;
     static constexpr int WAVE_B = TENSOR_Z_B + S_SLOTS * IMG_B;
     static constexpr int CONST_OFF = TILES * WAVE_B;
-    static constexpr int LDS_B = CONST_OFF + CONST_USED;
+    // S1_BY_WG (round 4; the four-stream narrow kernel that recomputes S_1 in the reverse, RECOMP1 below): the recomputation is the
+    // WEIGHT-GRADIENT wave's -- the wave that shares the tile's SIMD and has finished layer 2 long before the chain wave has.  It writes the high
+    // parts into the layer's state slot (where the LDS-DMA would have put them) and the low parts, as LO8 records, into S1LO: 4 KB per tile
+    // behind the constants.  The chain wave finds S_1 like any other kept state; 2.4 k cycles leave its critical path.  (Measured: 1.3 % of the
+    // launch, not the 3.3 % those cycles are -- at its lower priority the weight-gradient wave needs 2-2.5 k cycles per QUARTER of the layer, and
+    // the chain wave's own steps stretch by a few hundred cycles when its SIMD partner has vector work: the SIMD's vector issue is not idle
+    // while the chain wave runs, which is also what the shared forward of tools/experiments/ found.)
+    static constexpr int S1LO_OFF = (CONST_OFF + CONST_USED + 15) & ~15;
+    static constexpr bool S1_BY_WG = !LDSOP && !SLDS && NS_ == 4 && NL >= 4 && KS == 2 && NP == 2 && !FASTSTATE && WB == 4 && PINN_LO8_ENABLED && Op::TOP_BYTE_IS_FLOAT && CONST_LDS &&
+                                     S1LO_OFF + TILES * NS * 1024 <= 160 * 1024;
+    static constexpr int LDS_B = S1_BY_WG ? S1LO_OFF + TILES * NS * 1024 : CONST_OFF + CONST_USED;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
     // per tile: parked states S_1..S_{NL-1}.  Narrow layouts: [high-part images | low-part images]: the high parts return to LDS by
     // LDS-DMA (they are also the weight gradient's operand), the (unscaled) low parts are read back by the chain wave itself, block by
@@ -216,7 +232,7 @@ struct Fused {
     // with the layer's first fragments) instead of sixteen 8-byte ones.  The launch is sensitive to its bytes through the vector-memory path more
     // than to the instructions that move them (DESIGN section 6 "Round 4"); the low image of a layer is then NS records: (stream) -> 16 bytes per
     // lane = the four blocks' four values each.
-    static constexpr bool LO8 = PINN_LO8_ENABLED && !LDSOP && !SLDS && WB == 4 && NP == 2 && !FASTSTATE && KS == 2;      // (four- and five-stream narrow layouts)
+    static constexpr bool LO8 = PINN_LO8_ENABLED && Op::TOP_BYTE_IS_FLOAT && !LDSOP && !SLDS && WB == 4 && NP == 2 && !FASTSTATE && KS == 2;      // (four- and five-stream narrow layouts)
     static __device__ __forceinline__ uint32_t lo8_pack(uint32_t rows01, uint32_t rows23) {       // the high bytes of four fp16 values
 #if defined(__AMDGCN__)
         return __builtin_amdgcn_perm(rows23, rows01, 0x07050301u);
@@ -246,7 +262,7 @@ struct Fused {
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
     // (two-slot wide layout: layer 1's nine blocks stay in registers -- one layer less of the sums' round trip through L2: 6.39 -> 6.28 ms;
     // a second layer spills 82 registers)
-    static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? (ZDB ? 1 : 5) : (NL >= 4 ? 2 : 0));      // (NL = 8 before ZDB: NG = 2..7 within 1 %, 5 left the fewest spills; with ZDB the role has registers to spare -- no second accumulator set for the adjoints' low parts -- and every layer kept in registers is a round trip of sums less: NG = 5 / 4 / 3 / 2 / 1 / 0 -> 5.00 / 4.93 / 4.88 / 4.85 / 4.82 / 4.82 ms per 2 M points)
+    static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? (ZDB ? 1 : 5) : (NL >= 4 ? 2 : 0));      // (NL = 8 before ZDB: NG = 2..7 within 1 %, 5 left the fewest spills; with ZDB the role has registers to spare -- no second accumulator set for the adjoints' low parts -- and every layer kept in registers is a round trip of sums less: NG = 5 / 4 / 3 / 2 / 1 / 0 -> 5.00 / 4.93 / 4.88 / 4.85 / 4.82 / 4.82 ms per 2 M points; the plate's five streams: NG = 5 / 3 / 1 -> 3.50 / 3.44 / 3.38 ms per 1 M points)
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
     // Padded width 160: 5 x 5 blocks per wave do not fit the register file next to their running sums (100 + 100 registers), so the
     // weight gradient walks its out-blocks in three passes (2 + 2 + 1) and STREAMS the sums: a pass starts from its ten (five) records,
@@ -895,6 +911,12 @@ struct Fused {
 #endif
     }
 
+    struct Ctx;
+    struct S1Job {                    // S1_BY_WG: the chain tile this wave recomputes S_1 for, and the tile's inputs of this step
+        const Ctx* x;
+        float xin[4];
+        mutable u32x4 S1[NS][1][KS][NP];      // k-step 0 between the two halves of recompute_s1
+    };
     template <int L>
     struct WgDown {     // same barrier sequence as the chain role's Down<>
         // vector-memory operations this wave issues in the hand-off window of layer L (between the two barriers), in this order:
@@ -911,11 +933,20 @@ struct Fused {
         // layer L+1's sums back and to request layer L's; the counted wait covers what it issued before those -- the LDS-DMA of S_L.
         static constexpr bool ONE_BARRIER = ZDB && L <= NL - 2;
         static __device__ __forceinline__ void run(const FusedArgs& a, bool tracer, const WgCtx& w, const DmaSrc& scr, __amdgpu_buffer_rsrc_t accr,
-                                                   unsigned lane16, char* tile_lds, Acc& A, int quad, Sums& pend, Sums& ld) {
+                                                   unsigned lane16, char* tile_lds, Acc& A, int quad, Sums& pend, Sums& ld, const S1Job& sj) {
             if constexpr (ONE_BARRIER) {
                 static_assert(!EARLY_SUMS && !DMA_IN_WINDOW && !DMA_OWN, "narrow parked layout");
                 if constexpr (in_memory(L + 1)) store_sums(accr, lane16, L + 1, pend);
                 if constexpr (in_memory(L)) load_sums(accr, lane16, L, ld);
+                // S1_BY_WG: a piece of S_1 per idle window of this wave (a whole first layer in one window made the chain wave wait 1.9 k cycles
+                // at layer 1's barrier, halves 0.8 k, quarters none): feature block 4 - L behind the weight gradient of layer L + 1
+                if constexpr (S1_BY_WG && NL >= 6) {
+                    if constexpr (L >= 1 && L <= 4) recompute_s1<4 - L, 5 - L>(a, sj, sj.S1);
+                } else if constexpr (S1_BY_WG) {
+                    if constexpr (L == 2) recompute_s1<0, 2>(a, sj, sj.S1);
+                    if constexpr (L == 1) recompute_s1<2, 4>(a, sj, sj.S1);
+                }
+                // (the write in the last piece: slot 1 is free since the barrier of layer 2 -- S_3's readers were layer 3's)
                 __builtin_amdgcn_sched_barrier(0);
                 wait_vmcnt<N_STORE + N_LOAD>();
                 fused_stamp(a, tracer, 64 + 3 * (NL - L));
@@ -923,7 +954,7 @@ struct Fused {
                 fused_stamp(a, tracer, 65 + 3 * (NL - L));
                 wgrad<L>(w, A, quad, ld, pend, DmaJob{&scr, lane16, tile_lds, quad, accr});
                 fused_stamp(a, tracer, 66 + 3 * (NL - L));
-                if constexpr (L >= 1) WgDown<L - 1>::run(a, tracer, w, scr, accr, lane16, tile_lds, A, quad, pend, ld);
+                if constexpr (L >= 1) WgDown<L - 1>::run(a, tracer, w, scr, accr, lane16, tile_lds, A, quad, pend, ld, sj);
                 return;
             }
             // (chain waves now overwrite the tensors; this wave's reads of them are done)
@@ -953,7 +984,7 @@ struct Fused {
                 if constexpr (in_memory(L - 1)) load_sums(accr, lane16, L - 1, ld);
             }
             fused_stamp(a, tracer, 66 + 3 * (NL - L));
-            if constexpr (L >= 1) WgDown<L - 1>::run(a, tracer, w, scr, accr, lane16, tile_lds, A, quad, pend, ld);
+            if constexpr (L >= 1) WgDown<L - 1>::run(a, tracer, w, scr, accr, lane16, tile_lds, A, quad, pend, ld, sj);
         }
     };
 
@@ -998,7 +1029,23 @@ struct Fused {
             for (int r = 0; r < NG * NSUM; ++r) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, accr, lane16, r * 1024, 0);
         }
         Sums pend, ld;
+        Ctx xs1;                                          // S1_BY_WG: addressing of chain tile `quad` as far as the first layer needs it
+        S1Job sj;
+        sj.x = &xs1;
+        if constexpr (S1_BY_WG) {
+            xs1.tenZ = lds + quad * WAVE_B;
+            xs1.cw0 = lds + CONST_OFF + CONST_BIAS_F * 4 + q * 64;
+            xs1.imgoff = img_record(c, q);
+            xs1.s1lo = lds + S1LO_OFF + quad * NS * 1024 + lane * 16;
+            xs1.c = c;
+            xs1.q = q;
+        }
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
+            if constexpr (S1_BY_WG) {                     // the tile's inputs: requested here, used a forward and six reverse layers later
+                bool valid;
+                long pidx;
+                load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + quad, c, sj.xin, valid, pidx);
+            }
             if constexpr (KEEP2) lds_barrier();           // the forward's barrier in front of its first state-slot write (see KEEP2)
             if constexpr (LDSOP) {
                 __syncthreads();                          // step barrier (see the chain role): this wave's reads of the previous step are done
@@ -1009,7 +1056,7 @@ struct Fused {
                     if (l + 1 <= NL - 1 && !kept_in_lds(l + 1)) park_image(scr_st, lane16, tile_lds, l + 1, quad);
                 }
             }
-            WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend, ld);
+            WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend, ld, sj);
         }
         // ---- write this workgroup's partial gradient
         // (kept in the body of the role: as a separate function taking the accumulators by reference the same statements cost the
@@ -1117,6 +1164,7 @@ struct Fused {
         const char* cbias;                         // LDS constants: bias table + q * 16 (a lane holds accumulator rows 4q..4q+3)
         const char* cw0;                           // LDS constants: first-layer rows + q * 64
         const float* blast;                        // output-layer bias (constants not in LDS)
+        char* s1lo;                                // S1_BY_WG: this lane's record of the tile's low-part image of S_1 (stream s at + s * 1024)
         int c, q;
         bool tracer;                               // workgroup 0, chain wave 0, lane 0
         __device__ __forceinline__ void set_tile(const FusedArgs& a, long gtile) {
@@ -1134,6 +1182,7 @@ struct Fused {
             cbias = lds + CONST_OFF + q_ * 16;
             cw0 = lds + CONST_OFF + CONST_BIAS_F * 4 + q_ * 64;
             imgoff = img_record(c_, q_);
+            s1lo = lds + S1LO_OFF + slot * NS * 1024 + lane * 16;
             c = c_;
             q = q_;
             tracer = false;
@@ -1328,7 +1377,7 @@ struct Fused {
     }
 
     // forward first layer (K = 3, VALU): INF:191-195 with the tangent seeds e_k * sx_k
-    template <int MB>
+    template <int MB, int END = WB>
     static __device__ __forceinline__ void first_mb(const FusedArgs& a, const Ctx& x, const float (&xin)[4], u32x4 (&Bn)[NS][1][KS][NP]) {
         float vals[NS][4];
 #pragma unroll
@@ -1344,7 +1393,7 @@ struct Fused {
             if constexpr (SECOND) vals[4][r] = -2.0f * h * vals[3][r] * (a.sx[2] * w[2]);      // z_tt = 0 at the first layer
         }
         emit_state<MB>(Bn, vals);
-        if constexpr (MB + 1 < WB) first_mb<MB + 1>(a, x, xin, Bn);
+        if constexpr (MB + 1 < END) first_mb<MB + 1, END>(a, x, xin, Bn);
     }
 
     // forward: park the high parts of state S_l as the tile's register image (scratch), or straight into its LDS slot
@@ -1498,6 +1547,24 @@ struct Fused {
     }
 
     // the low parts of the same values: from the forward's registers (S_NL) or from the tile's parked low-part image (plain loads)
+    // S1_BY_WG: feature blocks MB0 .. MB1 - 1 of S_1 of the job's tile from its inputs (the forward's own function: the same bits); they
+    // wait in registers for the slot, which S_3 occupies until layer 2's barrier.  The last piece writes the high parts into the tile's
+    // slot of S_1 and the low parts, as LO8 records (the parked layers' format), into the tile's S1LO image.
+    template <int MB0, int MB1>
+    static __device__ __forceinline__ void recompute_s1(const FusedArgs& a, const S1Job& sj, u32x4 (&S1)[NS][1][KS][NP]) {
+        if constexpr (S1_BY_WG) {
+            const Ctx& x = *sj.x;
+            first_mb<MB0, MB1>(a, x, sj.xin, S1);
+            if constexpr (MB1 == WB) {
+                put_image<KS>(x.imgS(1), S1);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    const u32x4 &k0 = S1[s][0][0][NP - 1], &k1 = S1[s][0][1][NP - 1];
+                    *reinterpret_cast<u32x4*>(x.s1lo + s * 1024) = u32x4{lo8_pack(k0[0], k0[1]), lo8_pack(k0[2], k0[3]), lo8_pack(k1[0], k1[1]), lo8_pack(k1[2], k1[3])};
+                }
+            }
+        }
+    }
     template <int MB>
     static __device__ __forceinline__ void lo_from_frags(const u32x4 (&B)[NS][1][KS][NP], u32x2 (&sl)[NS]) {
 #pragma unroll
@@ -1600,12 +1667,15 @@ struct Fused {
             u32x4 Aa[KS][RP], Ab[KS][RP];
             u32x2 sla[NS], slb[NS];
             u32x4 slq[NS];                                     // (LO8: the layer's low parts, one 16-byte record per stream)
-            constexpr bool RECOMP = RECOMP1 && L == 1;
+            constexpr bool RECOMP = RECOMP1 && L == 1 && !S1_BY_WG;
+            constexpr bool S1_LDS = S1_BY_WG && L == 1;        // S_1: high parts in its slot, low parts in S1LO, both from the weight-gradient wave
             u32x4 S1[NS][1][KS][NP];                           // (RECOMP only)
             if constexpr (L >= 1) {                            // this layer's first fragments travel during the hand-off
                 load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 0, 0), Aa);
                 load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 1, 0), Ab);
-                if constexpr (!RECOMP && LO8) {
+                if constexpr (S1_LDS) {
+                    // (read behind the barrier below)
+                } else if constexpr (!RECOMP && LO8) {
 #pragma unroll
                     for (int s = 0; s < NS; ++s) slq[s] = __builtin_amdgcn_raw_buffer_load_b128(x.scr, x.imgoff, SCRATCH_LO + (L - 1) * IMG_B + s * 1024, 0);
                 } else if constexpr (!RECOMP) lo_from_scratch<0>(x, L, sla);
@@ -1627,6 +1697,10 @@ struct Fused {
             }
             hand_barrier();                                    // tensors visible to the weight-gradient waves; S_L has landed
             fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
+            if constexpr (S1_LDS) {
+#pragma unroll
+                for (int s = 0; s < NS; ++s) slq[s] = *reinterpret_cast<const u32x4*>(x.s1lo + s * 1024);
+            }
             if constexpr (L >= 1) {
                 // reverse through W_L and the activation that produced S_L -> Z_{L-1}
                 u32x4 Zn[NS][1][KS][NP];

@@ -23,7 +23,7 @@ for name in names:
     for _ in range(2):
         eng.wave_loss_grad(theta, *xs, [0, 0, 0], [30, 30, 20], True, tw)
     engs[name] = (eng, err, [])
-for rnd in range(4):                        # interleaved rounds: box-to-box and clock drift hit every variant alike
+for rnd in range(int(os.environ.get("EXP_ROUNDS", "4"))):                        # interleaved rounds: box-to-box and clock drift hit every variant alike
     for name in names:
         eng, err, ts = engs[name]
         for _ in range(6):

@@ -1,13 +1,15 @@
 #!/bin/bash
 # Dev tool (GPU box): per-kernel PMC counters of an experiment library's fused launch, several passes of <= 4 counters.
-#   tools/pmc_collect.sh NAME [WIDTH | nc3d]     (library build/exp/NAME/libpinn_hip.so; output gpurun_out/pmc_NAME[_WIDTH]/)
+#   tools/pmc_collect.sh NAME [WIDTH | nc3d | plate]     (library build/exp/NAME/libpinn_hip.so; output gpurun_out/pmc_NAME[_WIDTH]/)
 # WIDTH (80, 100): the launches of tools/wide_time.py WIDTH NAME (1,000,000 points of the 8 x WIDTH net) instead of tools/exp_run.py (8x64, 2 M).
 NAME=$1
 WIDTH=$2
 OUT=$PWD/gpurun_out/pmc_$NAME${WIDTH:+_$WIDTH}
 if [ "$WIDTH" = "nc3d" ]; then CMD="$GRAFT_REPO_ROOT/tools/nc3d_time.py $NAME 6"; WHAT="fused 3-D kernel Fused<OpF16,3,128,10,5,false,4>, 1,000,000 points per launch (tools/nc3d_time.py)"
+elif [ "$WIDTH" = "plate" ]; then CMD="$GRAFT_REPO_ROOT/tools/plate_time.py 64 $NAME"; WHAT="plate collocation kernel Fused<OpF16,3,64,8,5>, 1,000,000 points per launch (tools/plate_time.py)"
 elif [ -n "$WIDTH" ]; then CMD="$GRAFT_REPO_ROOT/tools/wide_time.py $WIDTH $NAME"; WHAT="8x$WIDTH net, 1,000,000 points per launch (tools/wide_time.py)"
 else CMD="$GRAFT_REPO_ROOT/tools/exp_run.py $NAME"; WHAT="fused_wave_kernel<OpF16,3,64,8,4>, 2,000,000 points per launch (tools/exp_run.py)"; fi
+PTS=1000000; [ -z "$WIDTH" ] && PTS=2000000
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 i=0
@@ -47,6 +49,7 @@ import hashlib
 h = hashlib.sha256()
 for f in ('pinn_fused.hpp', 'pinn_device.hpp', 'pinn_host.hpp'):
     h.update(open('$GRAFT_REPO_ROOT/pinn_elastodynamics_amd/csrc/' + f, 'rb').read())
+js['points_per_launch'] = $PTS
 js['kernel_source_sha'] = h.hexdigest()[:16]      # bench.py refuses to quote these bytes for other kernel sources
 js['note'] = ('$WHAT; tools/pmc_collect.sh: one rocprofv3 --pmc pass per '
               'group of <= 4 counters, --kernel-trace only. FETCH_SIZE/WRITE_SIZE are in KB; hbm_bytes = 2*FETCH (gfx950 correction) + WRITE. These '
