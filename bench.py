@@ -335,8 +335,11 @@ def main():
     # library's asynchronous event ring armed (HIP events around every fused launch on its own stream, in stream order, no
     # synchronisation between the steps: include/pinn_hip.h).  Every rank runs the block (the steps hold collectives).
     eng.lib.profile_ring_arm(4096)
+    barrier()
+    t0 = time.perf_counter()
     step(steps)
     barrier()
+    ring_block_ms_per_step = 1e3 * (time.perf_counter() - t0) / steps      # this block's own wall time: the launches below are a part of THESE steps
     ring_ms, ring_streams = eng.lib.profile_ring_read()
     collo_ms = ring_ms[ring_streams >= 4]
     side_ms = ring_ms[ring_streams == 1]
@@ -382,7 +385,7 @@ def main():
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
                                "traffic": None, "traffic_from_profiles": traffic_from_profiles({64: "fused", 80: "wide80", 100: "wide100"}.get(args.width, "none")) if fused and args.precision == "f16x3" else None,
                                "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch, "algorithmic_flop_per_point": kflop,
-                               "launches_timed": int(collo_ms.size), "launch_ms_min_max": [float(collo_ms.min()), float(collo_ms.max())] if collo_ms.size else None,
+                               "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "launch_ms_min_max": [float(collo_ms.min()), float(collo_ms.max())] if collo_ms.size else None,
                                "side_sets_launch_ms": float(side_ms.mean()) if side_ms.size else None,
                                "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (one product per contraction) / mean HIP-event duration of the launches of one "
@@ -401,10 +404,12 @@ def main():
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
                                "traffic": None, "traffic_from_profiles": traffic_from_profiles("plate") if fused and args.precision == "f16x3" and args.width == 64 else None,
                                "launches_per_step": 1, "avg_launch_ms": acc["chain"], "algorithmic_flop_per_point": flop_pt,
-                               "launches_timed": int(collo_ms.size), "issued_mfma_tflops": tflops * issued,
+                               "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; the hole-traction set (9960 points) is a second, one-stream "
-                                       "launch of the fused kernel.  traffic not measured in this run"}
+                                       "launch of the fused kernel.  The launches are timed in one more block of `steps` steps behind the timed ones "
+                                       "(timed_block_ms_per_step is that block's own wall time per step: avg_launch_ms is a part of IT; the collocation launch "
+                                       "is 98 % of a plate step, so a percent of drift between the blocks shows).  traffic not measured in this run"}
             out["kernel_ms_per_step"] = acc
         elif cfg == "nc3d" and args.precision == "f16x3" and layers[1:-1] == [128] * 10:
             # ---- the 3-D instantiation of the fused kernel (Fused<..., NL = 10, NS = 5, DIN = 4>): HIP events around the collocation launch
@@ -431,7 +436,7 @@ def main():
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
                                "traffic": None, "traffic_from_profiles": traffic_from_profiles("nc3d") if fused else None,
                                "launches_per_step": n_launch, "avg_launch_ms": t_ms / n_launch, "algorithmic_flop_per_point": flop_pt,
-                               "launches_timed": int(collo_ms.size), "issued_mfma_tflops": tflops * issued,
+                               "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; measured limiter of the LDS-operand layouts: the bytes "
                                        "of parked states and in-memory weight-gradient sums through L2 (DESIGN.md section 6).  traffic not measured in this run"}

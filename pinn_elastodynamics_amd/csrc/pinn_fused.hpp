@@ -217,6 +217,14 @@ struct Fused {
     static constexpr bool S1_BY_WG = !LDSOP && !SLDS && NS_ == 4 && NL >= 4 && KS == 2 && NP == 2 && !FASTSTATE && WB == 4 && PINN_LO8_ENABLED && Op::TOP_BYTE_IS_FLOAT && CONST_LDS &&
                                      S1LO_OFF + TILES * NS * 1024 <= 160 * 1024;
     static constexpr int LDS_B = S1_BY_WG ? S1LO_OFF + TILES * NS * 1024 : CONST_OFF + CONST_USED;
+    // S1_HI_BY_WG (the plate's five-stream narrow kernel, whose LDS is full and whose chain wave has no registers to recompute anything): the
+    // same wave recomputes the HIGH parts of S_1 into the slot; the low parts stay parked as LO8 records (the forward has them anyway).  The
+    // chain wave's code does not change -- S_1 is a kept state with parked low parts, like S_{NL-1} -- and 10 KB per tile and direction
+    // (of 86: high parts of six layers, low parts of seven) neither leave through L2 nor come back by LDS-DMA.
+    // (3.19 -> 3.08 ms per 1 M points, -3.4 %; in two pieces instead of four -2.8 %; the role spills 31 registers more either way)
+    static constexpr bool S1_HI_BY_WG = !LDSOP && !SLDS && NS_ == 5 && DIN_ == 3 && NL >= 6 && KS == 2 && NP == 2 && !FASTSTATE && WB == 4 && PINN_LO8_ENABLED &&
+                                        Op::TOP_BYTE_IS_FLOAT;
+    static constexpr bool S1_WG_ANY = S1_BY_WG || S1_HI_BY_WG;
     static_assert(LDS_B <= 160 * 1024, "LDS budget");
     // per tile: parked states S_1..S_{NL-1}.  Narrow layouts: [high-part images | low-part images]: the high parts return to LDS by
     // LDS-DMA (they are also the weight gradient's operand), the (unscaled) low parts are read back by the chain wave itself, block by
@@ -822,7 +830,7 @@ struct Fused {
     static constexpr bool KEEP_W = LDSOP && !ONE_SLOT && !WSLDS;
     static constexpr bool TOP_IN_Z = KEEP2 && KS == 2 && NP == 2;
     static constexpr int FIRST_KEPT = TOP_IN_Z ? NL - 2 : NL - 1;
-    static __device__ __forceinline__ constexpr bool kept_in_lds(int l) { return WSLDS || (KEEP2 && l >= FIRST_KEPT && l <= NL - 1) || (KEEP_W && l == NL - 1) || ((RECOMP1 || RECOMP_W) && l == 1); }
+    static __device__ __forceinline__ constexpr bool kept_in_lds(int l) { return WSLDS || (KEEP2 && l >= FIRST_KEPT && l <= NL - 1) || (KEEP_W && l == NL - 1) || ((RECOMP1 || RECOMP_W || S1_HI_BY_WG) && l == 1); }
     // S_NL inside the Z area: record (s * KS + 1) * NP + kk beside the two-part Z_NL; ZDB: the whole OTHER buffer as a plain high-part image
     static constexpr int TOPZ_OFF = ZDB ? zbuf(NL + 1) : NP * 1024, TOPZ_STRIDE = ZDB ? KS * 1024 : KS * NP * 1024;
     static constexpr int N_DMA_ALL = LDSOP ? IMG_B / 2048 : IMG_B / 1024;       // LDSOP: two waves share a tile's records
@@ -940,9 +948,9 @@ struct Fused {
                 if constexpr (in_memory(L)) load_sums(accr, lane16, L, ld);
                 // S1_BY_WG: a piece of S_1 per idle window of this wave (a whole first layer in one window made the chain wave wait 1.9 k cycles
                 // at layer 1's barrier, halves 0.8 k, quarters none): feature block 4 - L behind the weight gradient of layer L + 1
-                if constexpr (S1_BY_WG && NL >= 6) {
+                if constexpr (S1_WG_ANY && NL >= 6) {
                     if constexpr (L >= 1 && L <= 4) recompute_s1<4 - L, 5 - L>(a, sj, sj.S1);
-                } else if constexpr (S1_BY_WG) {
+                } else if constexpr (S1_WG_ANY) {
                     if constexpr (L == 2) recompute_s1<0, 2>(a, sj, sj.S1);
                     if constexpr (L == 1) recompute_s1<2, 4>(a, sj, sj.S1);
                 }
@@ -1032,7 +1040,8 @@ struct Fused {
         Ctx xs1;                                          // S1_BY_WG: addressing of chain tile `quad` as far as the first layer needs it
         S1Job sj;
         sj.x = &xs1;
-        if constexpr (S1_BY_WG) {
+        if constexpr (S1_WG_ANY) {
+            if constexpr (!CONST_LDS) xs1.w0p = __builtin_amdgcn_make_buffer_rsrc((void*)a.pw.w0p, 0, WIDTH * 16, 0x00020000);
             xs1.tenZ = lds + quad * WAVE_B;
             xs1.cw0 = lds + CONST_OFF + CONST_BIAS_F * 4 + q * 64;
             xs1.imgoff = img_record(c, q);
@@ -1041,7 +1050,7 @@ struct Fused {
             xs1.q = q;
         }
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
-            if constexpr (S1_BY_WG) {                     // the tile's inputs: requested here, used a forward and six reverse layers later
+            if constexpr (S1_WG_ANY) {                    // the tile's inputs: requested here, used a forward and six reverse layers later
                 bool valid;
                 long pidx;
                 load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + quad, c, sj.xin, valid, pidx);
@@ -1412,6 +1421,8 @@ struct Fused {
             if constexpr (FIRST) put_image<KS>(x.imgS(l), Sf);               // the tile's own records of slot l; nobody else touches them in the forward
         } else if (RECOMP1 && l == 1) {
             return;                                     // recomputed by the reverse (hi and lo)
+        } else if (S1_HI_BY_WG && l == 1) {
+            // (high parts recomputed by the weight-gradient wave; the low parts are parked below)
         } else if (kept_in_lds(l)) {
             if constexpr (FIRST) {
                 if (l == FIRST_KEPT) lds_barrier();     // (see KEEP2)
@@ -1549,20 +1560,27 @@ struct Fused {
     // the low parts of the same values: from the forward's registers (S_NL) or from the tile's parked low-part image (plain loads)
     // S1_BY_WG: feature blocks MB0 .. MB1 - 1 of S_1 of the job's tile from its inputs (the forward's own function: the same bits); they
     // wait in registers for the slot, which S_3 occupies until layer 2's barrier.  The last piece writes the high parts into the tile's
-    // slot of S_1 and the low parts, as LO8 records (the parked layers' format), into the tile's S1LO image.
+    // slot of S_1; the low parts go, as LO8 records (the parked layers' format), into the tile's S1LO image.
     template <int MB0, int MB1>
     static __device__ __forceinline__ void recompute_s1(const FusedArgs& a, const S1Job& sj, u32x4 (&S1)[NS][1][KS][NP]) {
+        if constexpr (S1_HI_BY_WG) {
+            const Ctx& x = *sj.x;
+            first_mb<MB0, MB1>(a, x, sj.xin, S1);
+            if constexpr (MB1 == WB) put_image<KS>(x.imgS(1), S1);
+        }
         if constexpr (S1_BY_WG) {
             const Ctx& x = *sj.x;
             first_mb<MB0, MB1>(a, x, sj.xin, S1);
-            if constexpr (MB1 == WB) {
-                put_image<KS>(x.imgS(1), S1);
+            // the low parts leave at once (dword MB of a stream's LO8 record is block MB's; S1LO was last read in the previous step's layer 1):
+            // only the high parts wait in registers
+#pragma unroll
+            for (int mb = MB0; mb < MB1; ++mb)
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
-                    const u32x4 &k0 = S1[s][0][0][NP - 1], &k1 = S1[s][0][1][NP - 1];
-                    *reinterpret_cast<u32x4*>(x.s1lo + s * 1024) = u32x4{lo8_pack(k0[0], k0[1]), lo8_pack(k0[2], k0[3]), lo8_pack(k1[0], k1[1]), lo8_pack(k1[2], k1[3])};
+                    const u32x4& lo = S1[s][0][mb >> 1][NP - 1];
+                    *reinterpret_cast<uint32_t*>(x.s1lo + s * 1024 + 4 * mb) = lo8_pack(lo[(mb & 1) * 2], lo[(mb & 1) * 2 + 1]);
                 }
-            }
+            if constexpr (MB1 == WB) put_image<KS>(x.imgS(1), S1);
         }
     }
     template <int MB>

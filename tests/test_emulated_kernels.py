@@ -243,6 +243,8 @@ def test_emulated_plate_entry_points(emu, lN, lD, n):
 @pytest.mark.parametrize("lN,n", [([3] + 4 * [24] + [5], 70),       # five streams, all layer states in LDS
                                   ([3] + 8 * [30] + [5], 130),      # parked states + LDS-DMA, several workgroup steps
                                   ([3] + 4 * [40] + [5], 40),       # padded width 64: constants from memory (LDS is full)
+                                  ([3] + 8 * [48] + [5], 140),      # BASELINE configs[2]'s layout (8 layers of padded width 64): double-buffered adjoints, S_1's
+                                                                    # high parts from the weight-gradient wave, several workgroup steps
                                   ([3] + 8 * [70] + [5], 75)])      # the reference's plate net (PLATE:885): padded width 96, LDS-operand layout
 def test_emulated_plate_fused(emu, lN, n):
     """The plate's loss + gradient through the five-stream instantiation of the fused kernel (second time derivative carried as a

@@ -34,7 +34,10 @@ def test_bench_line(cfg, extra):
     assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(r) and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     # the fused kernel's own launch time, measured with HIP events in this run (nc3d: the fused 3-D kernel since round 3)
     # (events around the launches of a running step loop, in stream order: a kernel time above the step time would be an inconsistency)
-    assert r["avg_launch_ms"] > 0 and r["avg_launch_ms"] <= d["ms_per_step"] and r["launches_timed"] >= 4
+    # (wave: the step holds a second launch of 3 % on top; plate / nc3d: the collocation launch IS 98-99 % of the step, and the block that carries
+    # the events runs after the timed ones -- the by-construction bound is the next line, this one allows that block 3 % of clock drift)
+    assert r["avg_launch_ms"] > 0 and r["avg_launch_ms"] <= (1.0 if cfg == "wave" else 1.03) * d["ms_per_step"] and r["launches_timed"] >= 4
+    assert r["avg_launch_ms"] <= r["timed_block_ms_per_step"]      # by construction: the launches are a part of that block's steps
     if cfg == "nc3d":
         assert "fused_wave_kernel" in r["kernel"] and r["launches_per_step"] == 1 and "fused" in d["config"]["workload"]
     # at least one second of timed work whatever --steps is: the K-step block is repeated, the median block is reported

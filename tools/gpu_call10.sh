@@ -1,3 +1,4 @@
-mkdir -p gpurun_out
-EXP_ROUNDS=10 timeout 600 python tools/exp_run.py base s1p2 s1p4 2>&1 | grep -v Warn > gpurun_out/s1wg.log
-cat gpurun_out/s1wg.log
+mkdir -p gpurun_out/r4c10
+python -m pytest tests -m gpu -q > gpurun_out/r4c10/pytest.log 2>&1; echo "pytest rc $?" >> gpurun_out/r4c10/pytest.log
+grep -E "^E  |FAILED|passed|failed|pytest rc" gpurun_out/r4c10/pytest.log | head -40
+bash tools/collect_round.sh r04 2>&1 | tail -5
