@@ -1,5 +1,5 @@
 # Dev tool (GPU box): the headline pair on one box -- rocprofv3 kernel-trace stats of the default bench command, then the default bench line
-OUT=$PWD/gpurun_out/pair_$1
+OUT=$PWD/gpurun_out/pair_${1:-x}
 mkdir -p $OUT
 ROOT=$PWD
 cd /tmp; export TMPDIR=/tmp
