@@ -270,12 +270,18 @@ struct Fused {
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
     // (two-slot wide layout: layer 1's nine blocks stay in registers -- one layer less of the sums' round trip through L2: 6.39 -> 6.28 ms;
     // a second layer spills 82 registers)
-    static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : NL - 1) : (NL >= 8 ? (ZDB ? 1 : 5) : (NL >= 4 ? 2 : 0));      // (NL = 8 before ZDB: NG = 2..7 within 1 %, 5 left the fewest spills; with ZDB the role has registers to spare -- no second accumulator set for the adjoints' low parts -- and every layer kept in registers is a round trip of sums less: NG = 5 / 4 / 3 / 2 / 1 / 0 -> 5.00 / 4.93 / 4.88 / 4.85 / 4.82 / 4.82 ms per 2 M points; the plate's five streams: NG = 5 / 3 / 1 -> 3.50 / 3.44 / 3.38 ms per 1 M points)
+    static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : (WB == 8 ? NL - 2 : NL - 1)) : (NL >= 8 ? (ZDB ? 1 : 5) : (NL >= 4 ? 2 : 0));      // (NL = 8 before ZDB: NG = 2..7 within 1 %, 5 left the fewest spills; with ZDB the role has registers to spare -- no second accumulator set for the adjoints' low parts -- and every layer kept in registers is a round trip of sums less: NG = 5 / 4 / 3 / 2 / 1 / 0 -> 5.00 / 4.93 / 4.88 / 4.85 / 4.82 / 4.82 ms per 2 M points; the plate's five streams: NG = 5 / 3 / 1 -> 3.50 / 3.44 / 3.38 ms per 1 M points)
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
     // Padded width 160: 5 x 5 blocks per wave do not fit the register file next to their running sums (100 + 100 registers), so the
     // weight gradient walks its out-blocks in three passes (2 + 2 + 1) and STREAMS the sums: a pass starts from its ten (five) records,
     // requested one pass ahead, and stores them behind its last MFMA.
-    static constexpr bool STREAM_SUMS = LDSOP && WB == 10;
+    // Padded width 128 (round 4; the reference's 8 x 100 net and the 3-D net): the same streaming in two passes of 4 x 2 blocks.  Their 16 blocks
+    // fit, but as one set they cost 2 x 68 registers (the sums requested for the next layer + the ones being accumulated) and 34 vector-memory
+    // operations in front of the layer's LDS-DMA; streamed, the role has room to keep the FIRST mid layer's 16 blocks in registers -- one
+    // layer's matrix less to read and write per 32-point step, 4.3 of 60 KB per point.  8 x 100: 11.70 -> 11.4 (streaming) -> 10.25 ms per
+    // 1 M points (+ the register layer, at 38 spilled registers; a second one: 298 spilled, 15 ms); the 3-D kernel: 23.3 -> 23.1-23.3 ms
+    // (its launch is bound by its 86 KB per point, of which this is 4).  Six blocks per side (8 x 80, plate 8 x 70) measured 1-3 % SLOWER streamed.
+    static constexpr bool STREAM_SUMS = LDSOP && (WB == 10 || WB == 8);
     static constexpr int NBIASREC = (OBW + 3) / 4;                            // lane records holding the bias blocks (one float per block, four per record)
     static constexpr int NSUM = IBW * OBW + (LDSOP ? NBIASREC : 0);            // in-memory records per layer: the blocks (+ LDSOP: the bias blocks' lane records)
     static constexpr unsigned WG_ACC_BYTES = (unsigned)((NG > 0 ? NG : 1) * NSUM * 1024);
@@ -294,7 +300,7 @@ struct Fused {
         f32x4 first2, last2;
         f32x4 first3, last3;           // (ten blocks per side: out- / in-block quad + 8 for quad < 2)
         float bias0b, bias0c;          // (LDSOP mid-layer bias blocks: one more in-memory record per layer, bias_record)
-        float biasr[NREG > 0 ? NREG : 1][3];      // ... of the in-register layers (LDSOP)
+        float biasr[NREG > 0 ? NREG : 1][4];      // ... of the in-register layers (LDSOP)
     };
 
     // ---------------------------------------------------------------------------------------------
@@ -608,7 +614,7 @@ struct Fused {
     // records), requested behind the previous layer's weight gradient (load_sums)
     template <int L>
     static __device__ __forceinline__ void wgrad_stream(const WgCtx& w, int quad, const Sums& lds_, const DmaJob& job) {
-        static_assert(IBW == 5 && OBW == 5, "ten blocks per side");
+        static_assert((IBW == 5 && OBW == 5) || (IBW == 4 && OBW == 4), "ten or eight blocks per side");
         const int wi = quad >> 1, wo = quad & 1;
         const char* s0 = w.s0 + slot_of(L) * IMG_B;
         const char* s1 = w.s1 + slot_of(L) * IMG_B;
@@ -620,6 +626,22 @@ struct Fused {
         }
         f32x4 n1[IBW][2], n2[IBW][2];
         float b01[2], b23[2], b4[2];
+        if constexpr (OBW == 4) {              // eight blocks per side: two passes, one bias record
+            stream_pass<L, 0, 2, 2>(s0, s1, w.z0, w.z1, ia, oz, lds_.blk, n1, b01, job);
+            stream_pass<L, 2, 2, 0>(s0, s1, w.z0, w.z1, ia, oz, n1, n2, b23, job);
+            if (wi == 0) {
+                f32x4 ba = lds_.bias;
+                ba[0] += b01[0];
+                ba[1] += b01[1];
+                ba[2] += b23[0];
+                ba[3] += b23[1];
+                f32x4 one[1][1] = {{ba}};
+                store_fence(one);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, one[0][0]), job.accr, job.lane16, bias_record(L), 0);
+                stores_issued();
+            }
+            return;
+        }
         stream_pass<L, 0, 2, 2>(s0, s1, w.z0, w.z1, ia, oz, lds_.blk, n1, b01, job);
         stream_pass<L, 2, 2, 1>(s0, s1, w.z0, w.z1, ia, oz, n1, n2, b23, job);
         stream_pass<L, 4, 1, 0>(s0, s1, w.z0, w.z1, ia, oz, n2, n1, b4, job);
@@ -664,10 +686,26 @@ struct Fused {
                     }
                 }
             }
-        } else if constexpr (STREAM_SUMS) {
+        } else if constexpr (STREAM_SUMS && in_memory(L)) {
             wgrad_stream<L>(w, quad, lds_, job);
         } else {
-            if constexpr (!in_memory(L)) {               // an in-register layer (two-slot layout): the nine blocks accumulate in place
+            if constexpr (!in_memory(L) && WB == 8) {    // an in-register layer of the eight-block layouts: four 2 x 2 passes in place
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip)
+#pragma unroll
+                    for (int op = 0; op < 2; ++op) {
+                        f32x4 t[2][2] = {{A.mid[L - 1][2 * ip][2 * op], A.mid[L - 1][2 * ip][2 * op + 1]}, {A.mid[L - 1][2 * ip + 1][2 * op], A.mid[L - 1][2 * ip + 1][2 * op + 1]}};
+                        float b2[2];
+                        wg_blocks<2, 2, true, 0>(s0 + img_block(IBW * wi + 2 * ip), s1 + img_block(IBW * wi + 2 * ip), w.z0 + zimg_block(OBW * wo + 2 * op),
+                                                 w.z1 + zimg_block(OBW * wo + 2 * op), t, b2, &job);
+                        A.mid[L - 1][2 * ip][2 * op] = t[0][0]; A.mid[L - 1][2 * ip][2 * op + 1] = t[0][1];
+                        A.mid[L - 1][2 * ip + 1][2 * op] = t[1][0]; A.mid[L - 1][2 * ip + 1][2 * op + 1] = t[1][1];
+                        if (ip == 0 && wi == 0) {
+                            A.biasr[L - 1][2 * op] += b2[0];
+                            A.biasr[L - 1][2 * op + 1] += b2[1];
+                        }
+                    }
+            } else if constexpr (!in_memory(L)) {        // an in-register layer (two-slot layout): the nine blocks accumulate in place
                 static_assert(WB == 6, "in-register layers of the LDS-operand layouts: width 96 only");
                 const char* sp0 = s0 + img_block(2 * wi);
                 const char* sp1 = s1 + img_block(2 * wi);
@@ -929,8 +967,10 @@ struct Fused {
     struct WgDown {     // same barrier sequence as the chain role's Down<>
         // vector-memory operations this wave issues in the hand-off window of layer L (between the two barriers), in this order:
         // the stores of layer L+1's in-memory sums, the loads of layer L's, the LDS-DMA of S_{L-1}
-        static constexpr int N_STORE = in_memory(L + 1) ? NSUM : 0;
-        static constexpr int N_LOAD = in_memory(L) ? NSUM : 0;
+        // (STREAM_SUMS: behind the last LDS-DMA slice of layer L+1's weight gradient stand the stores of its LAST pass -- the bias record, which
+        // only two of the four waves store, is not counted: a smaller count only waits longer -- and the first pass's records of layer L)
+        static constexpr int N_STORE = in_memory(L + 1) ? (STREAM_SUMS ? IBW * (OBW == 4 ? 2 : 1) : NSUM) : 0;
+        static constexpr int N_LOAD = in_memory(L) ? (STREAM_SUMS ? IBW * 2 + 1 : NSUM) : 0;
         // LDSOP mid layers: the DMA of S_{L-1} is issued inside the weight gradient of layer L (wg_blocks33), not in the window
         // ONE_SLOT: the DMA of S_L itself, in layer L's own window, and the window waits for all of it
         static constexpr bool DMA_IN_WINDOW = !SLDS && !WSLDS && !ONE_SLOT && L >= 2 && (!DMA_IN_WGRAD || L == NL) && !kept_in_lds(L - 1);
@@ -1010,7 +1050,7 @@ struct Fused {
 #pragma unroll
         for (int l = 0; l <= NL; ++l) A.bias[l] = 0.0f;
 #pragma unroll
-        for (int l = 0; l < (NREG > 0 ? NREG : 1); ++l) A.biasr[l][0] = A.biasr[l][1] = A.biasr[l][2] = 0.0f;
+        for (int l = 0; l < (NREG > 0 ? NREG : 1); ++l) A.biasr[l][0] = A.biasr[l][1] = A.biasr[l][2] = A.biasr[l][3] = 0.0f;
         WgCtx w;
         {
             const char* wave0 = lds + (q >> 1) * WAVE_B;
@@ -1127,7 +1167,7 @@ struct Fused {
                     bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l), 0));
                     if constexpr (NBIASREC > 1) bv2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l) + 1024, 0));
                 } else {
-                    bv = f32x4{A.biasr[l <= NREG ? l - 1 : 0][0], A.biasr[l <= NREG ? l - 1 : 0][1], A.biasr[l <= NREG ? l - 1 : 0][2], 0.0f};
+                    bv = f32x4{A.biasr[l <= NREG ? l - 1 : 0][0], A.biasr[l <= NREG ? l - 1 : 0][1], A.biasr[l <= NREG ? l - 1 : 0][2], A.biasr[l <= NREG ? l - 1 : 0][3]};
                 }
                 if (wi == 0 && q == 0) {
 #pragma unroll
