@@ -268,9 +268,9 @@ struct Fused {
     // (loaded in the layer's hand-off window, stored one layer later so that the write acknowledgement never sits in front of a
     // full drain): with all NL-1 layers in registers the compiler spilled several layers' worth anyway, reloaded and stored them
     // around the barriers, and the weight-gradient waves became the critical path of those layers (round-2 phase traces).
-    // (two-slot wide layout: layer 1's nine blocks stay in registers -- one layer less of the sums' round trip through L2: 6.39 -> 6.28 ms;
-    // a second layer spills 82 registers)
-    static constexpr int NG = LDSOP ? ((WB == 6 && NS_ == 4) ? NL - 2 : (WB == 8 ? NL - 2 : NL - 1)) : (NL >= 8 ? (ZDB ? 1 : 5) : (NL >= 4 ? 2 : 0));      // (NL = 8 before ZDB: NG = 2..7 within 1 %, 5 left the fewest spills; with ZDB the role has registers to spare -- no second accumulator set for the adjoints' low parts -- and every layer kept in registers is a round trip of sums less: NG = 5 / 4 / 3 / 2 / 1 / 0 -> 5.00 / 4.93 / 4.88 / 4.85 / 4.82 / 4.82 ms per 2 M points; the plate's five streams: NG = 5 / 3 / 1 -> 3.50 / 3.44 / 3.38 ms per 1 M points)
+    // (padded width 96: layer 1's nine blocks stay in registers -- one layer less of the sums' round trip through L2: 8 x 80 6.39 -> 6.28 ms,
+    // the plate's 8 x 70 8.07 -> 7.97 ms per 1 M points; a second layer spills 82 registers)
+        static constexpr int NG = LDSOP ? ((WB == 6 && NS_ >= 4) ? NL - 2 : (WB == 8 ? NL - 2 : NL - 1)) : (NL >= 8 ? (ZDB ? 1 : 5) : (NL >= 4 ? 2 : 0));      // (NL = 8 before ZDB: NG = 2..7 within 1 %, 5 left the fewest spills; with ZDB the role has registers to spare -- no second accumulator set for the adjoints' low parts -- and every layer kept in registers is a round trip of sums less: NG = 5 / 4 / 3 / 2 / 1 / 0 -> 5.00 / 4.93 / 4.88 / 4.85 / 4.82 / 4.82 ms per 2 M points; the plate's five streams: NG = 5 / 3 / 1 -> 3.50 / 3.44 / 3.38 ms per 1 M points)
     static constexpr int NREG = NL - 1 - NG;                                   // mid layers 1..NREG accumulate in registers
     // Padded width 160: 5 x 5 blocks per wave do not fit the register file next to their running sums (100 + 100 registers), so the
     // weight gradient walks its out-blocks in three passes (2 + 2 + 1) and STREAMS the sums: a pass starts from its ten (five) records,
