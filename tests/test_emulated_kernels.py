@@ -70,6 +70,7 @@ def test_wave_loss_grad_emulated(emu, layers, n, prec, tol):
     ([3] + 8 * [64] + [7], 200, "f16x3", 2e-6, 1e-4),   # loss exact, gradient ~5e-4/sqrt(n) (tools/precision_study2.py)
     ([3] + 8 * [64] + [7], 100, "bf16", 2e-2, 2e-2),
     ([3] + 4 * [64] + [7], 70, "bf16x3", 1e-4, 1e-3),
+    ([3] + 4 * [64] + [7], 200, "f16x3", 2e-6, 1e-4),   # four layers of padded width 64: S_1 from the weight-gradient wave in TWO pieces (S1_BY_WG, NL < 6)
 ])
 def test_fused_kernel_emulated(emu, layers, n, prec, tol_loss, tol_grad):
     """fused persistent kernel (role-specialised waves, LDS transpose hand-off, LDS-DMA state reload)"""
@@ -81,6 +82,14 @@ def test_fused_persistent_accumulation_emulated(emu):
     """minimum workspace => fewer workgroups than steps: accumulators persist across steps of a workgroup"""
     e_loss, e_grad = run_wave(emu, [3] + 4 * [32] + [7], 9000, "f16x3", min_ws=True, fused=True)
     assert e_loss < 2e-6 and e_grad < 2e-5
+
+
+def test_fused_narrow_several_steps_per_workgroup_emulated(emu):
+    """The 8 x 64 and 4 x 64 collocation kernels with the minimum workspace: several steps per workgroup, so that what the weight-gradient
+    wave carries from step to step (its tile's inputs for the recomputation of S_1, the in-register sums) is exercised."""
+    for layers, n in (([3] + 8 * [64] + [7], 520), ([3] + 4 * [64] + [7], 390)):
+        e_loss, e_grad = run_wave(emu, layers, n, "f16x3", min_ws=True, fused=True, seed=3)
+        assert e_loss < 2e-6 and e_grad < 6e-5, (layers, e_loss, e_grad)
 
 
 def test_fp16_state_flag_emulated(emu):
