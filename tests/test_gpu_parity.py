@@ -48,7 +48,7 @@ TOL = {"f16x3": 2e-5, "bf16x3": 2e-4, "f16": 5e-3, "bf16": 3e-2}
 
 
 @pytest.mark.parametrize("prec", ["f16x3", "bf16", "f16", "bf16x3"])
-@pytest.mark.parametrize("depth,width,n", [(4, 32, 5000), (8, 64, 20000)])
+@pytest.mark.parametrize("depth,width,n", [(4, 32, 5000), (8, 64, 20000), (4, 64, 20000)])
 def test_wave_loss_grad_xavier(dev, prec, depth, width, n):
     if prec in ("f16", "bf16x3") and width != 64:
         pytest.skip("variant compiled for width 64 only")
