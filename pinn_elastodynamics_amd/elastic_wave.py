@@ -371,6 +371,13 @@ class DeepHPM(NetApi):
             for k in stale:
                 sums[8 * k:8 * k + 8].zero_()
             self._slots_dirty = set(writes)
+            if self._reduce:
+                # the all-reduce below leaves the GLOBAL total in every slot ANY rank wrote -- also in a slot this rank did not write
+                # (a set or block with fewer rows than ranks: _shard gives e == s here).  Such a slot must be zeroed again before the next
+                # collective, or the old total is added into it.  Which slots are written somewhere is a global fact (a side set is
+                # registered on every rank with its global row count): mark them all.
+                self._slots_dirty |= ({0} if n_blk > 0 else set()) | {k for k, name in enumerate(_SLOTS[1:], start=1)
+                                                                       if name in self._sides and lay[name] != 0.0}
         else:
             sums = sums_out
         grad = buf[:P]

@@ -226,3 +226,28 @@ def test_shard_cache_is_bounded_and_keeps_two_batchings_resident():
         s, e = m._shard(lo, lo + 100)
         assert np.allclose(x.numpy(), Collo[s:e, 0].astype(np.float32))
         assert sum(v[0].numel() for v in m._collo_cache.values()) <= 2 * 200 + 64
+
+
+def test_reduced_slot_of_a_set_without_local_rows_is_not_accumulated(monkeypatch):
+    """Round-4 advisor finding: the all-reduce leaves the global total in EVERY slot, also in one this rank did not write (a side set
+    with fewer rows than ranks); the lazily zeroed slot must not carry it into the next collective.  Rank 0 of 2 with a one-row SRC set
+    (its row belongs to rank 1), the collective mocked as 'the other rank contributes 0.25 to the SRC slot'."""
+    import torch
+    Collo, SRC, IC, UP = small_sets(n=64)
+    m = DeepHPM(Collo, SRC[:1], IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), verbose=False, seed=3)
+    m.world, m.rank, m._collo_full, m._reduce = 2, 0, None, True
+    s, e = m._shard(0, 1)
+    assert (s, e) == (0, 0)                                            # the one SRC row is rank 1's
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    m._sides["SRC"] = (dev(SRC[0:0, 0]), dev(SRC[0:0, 1]), dev(SRC[0:0, 2]), None, (0, 1), 1)
+    P = m.n_params
+
+    def fake_all_reduce(buf, op=None, group=None):
+        buf[P + 8 * 2] += 0.25                                          # rank 1's share of the SRC sum (slot 2, column 0)
+
+    monkeypatch.setattr(torch.distributed, "all_reduce", fake_all_reduce)
+    seen = []
+    for _ in range(4):
+        m._loss_and_grad(0, 64)
+        seen.append(float(m._buf[P + 16]))
+    assert seen == [0.25, 0.25, 0.25, 0.25], seen
