@@ -151,7 +151,7 @@ def traffic_from_profiles(name):
     same launches, profiles/README.md) -- NOT measured in this run, hence its own key.  A summary collected on other kernel sources than
     the ones in this tree (kernel_source_sha) is refused: the key then says which file is stale instead of quoting its bytes."""
     sha = kernel_source_sha()
-    for rnd in ("r04",):
+    for rnd in ("r05", "r04"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_summary.json")))
             if pm.get("kernel_source_sha") != sha:
@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--min-timed-seconds", type=float, default=1.0, help="repeat the K-step timed block until this much timed work has run (0: one block)")
     ap.add_argument("--always-reduce", action="store_true", help="run the step's gradient all-reduce (and the buffer handling around it) also in a "
                     "process group of ONE rank: what one of N GPUs does per step, collective included, measured on a single GPU")
+    ap.add_argument("--rank-share", type=int, default=1, help="N > 1 (one GPU, wave config): run what ONE of N data-parallel ranks executes per step -- 1/N of the "
+                    "--global-points collocation rows AND 1/N of every side set, sharded as DeepHPM._shard does, sums weighted with the global 1/N -- "
+                    "with --always-reduce the collective branch included; `value` counts this rank's points")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-config", action="store_true")
     ap.add_argument("--extra-modes", default="bf16,f16x3_fp16state",
@@ -243,6 +246,11 @@ def main():
     ppg = args.points_per_gpu if args.points_per_gpu is not None else (4_000_000 if cfg == "nc3d" else 2_000_000)
     n_global = ppg * world if args.scaling == "weak" else args.global_points
     pts_per_rank = n_global // world
+    share = max(1, args.rank_share)
+    if share > 1:
+        assert world == 1 and cfg == "wave", "--rank-share emulates one rank of N on ONE GPU (wave config)"
+        n_global = args.global_points
+        pts_per_rank = n_global * 1 // share - n_global * 0 // share          # rank 0's rows, as DeepHPM._shard splits them
 
     # ------------------------------------------------------------------------------------------------------------------
     if cfg == "wave":
@@ -253,9 +261,11 @@ def main():
         SRC, IC = ricker_source(), ic_grid()
         eng = HipEngine(layers, precision=args.precision, device=dev, max_points=args.chunk_points)
         model = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, case="infinite", engine=eng, seed=1111, verbose=False,
-                        always_reduce=args.always_reduce)
+                        always_reduce=args.always_reduce, shard_as=(0, share) if share > 1 else None)
         step = lambda k: model.train(k, 1e-3, 1)
-        workload = (f"2D elastic wave (infinite), 8x{args.width} tanh MLP, {pts_per_rank} collocation pts per GPU + IC 10201 + SRC 70400, Adam (TF1 rule) step "
+        side_note = (f"IC {model._sides['IC'][0].numel()} + SRC {model._sides['SRC'][0].numel()} (rank 0's 1/{share} share of IC 10201 / SRC 70400, of {n_global} collocation pts)"
+                     if share > 1 else "IC 10201 + SRC 70400")
+        workload = (f"2D elastic wave (infinite), 8x{args.width} tanh MLP, {pts_per_rank} collocation pts per GPU + {side_note}, Adam (TF1 rule) step "
                     f"incl. gradient all-reduce ({'BASELINE configs[1]; x8 GPUs weak = configs[3]' if args.width == 64 else 'a net width of the reference scripts, not a BASELINE config'}); {PRECISION_NOTE}")
     elif cfg == "plate":
         from pinn_elastodynamics_amd import pointsets as ps
@@ -329,20 +339,39 @@ def main():
         d, losses = timed_block()
         dts.append(d)
     dt = float(np.median(dts))
-    value = n_global * steps / dt
+    value = (pts_per_rank if share > 1 else n_global) * steps / dt
 
     # ---- launch time of the dominant kernel under the SAME conditions as the timed steps: one more block of `steps` steps with the
     # library's asynchronous event ring armed (HIP events around every fused launch on its own stream, in stream order, no
     # synchronisation between the steps: include/pinn_hip.h).  Every rank runs the block (the steps hold collectives).
-    eng.lib.profile_ring_arm(4096)
+    # Every 8th step only: the events of a bracketed launch put barrier packets between back-to-back kernels (a fully bracketed block ran
+    # 3.8 % slower than the timed ones in round 4).  The same block carries (a) shader-clock stamps of workgroup 0 around the whole launch
+    # -> the clock the kernel ran at (it is power-limited: 1.9-2.0 GHz of a 2.4 GHz part, box to box), (b) with a collective, events around
+    # the all-reduce.
+    RING_EVERY = 8
+    stamps = torch.zeros(128, dtype=torch.int64, device=dev)
+    eng.lib.set_stamp_buffer(stamps.data_ptr())
+    if getattr(model, "_reduce", False):
+        model.collective_events = []
+    eng.lib.profile_ring_arm(4096, every=RING_EVERY)
     barrier()
     t0 = time.perf_counter()
-    step(steps)
+    step(max(steps, 4 * RING_EVERY))
     barrier()
-    ring_block_ms_per_step = 1e3 * (time.perf_counter() - t0) / steps      # this block's own wall time: the launches below are a part of THESE steps
+    ring_block_ms_per_step = 1e3 * (time.perf_counter() - t0) / max(steps, 4 * RING_EVERY)      # this block's own wall time: the launches below are a part of THESE steps
     ring_ms, ring_streams = eng.lib.profile_ring_read()
+    eng.lib.set_stamp_buffer(None)
     collo_ms = ring_ms[ring_streams >= 4]
     side_ms = ring_ms[ring_streams == 1]
+    st = stamps.cpu().numpy()
+    launch_cycles = int(st[125] - st[124])                 # the LAST collocation launch of the block (every launch overwrites the slots)
+    # its duration: the block's last recorded launch is not necessarily the last launch; the mean of the recorded ones is the estimate
+    shader_clock_ghz = (launch_cycles / (float(collo_ms.mean()) * 1e-3) / 1e9) if collo_ms.size and launch_cycles > 0 else None
+    allreduce_ms = None
+    if getattr(model, "collective_events", None):
+        evs = model.collective_events
+        allreduce_ms = float(np.mean([a.elapsed_time(b) for a, b in evs[len(evs) // 2:]]))      # (second half: warm)
+        model.collective_events = None
     final_loss = float(losses[-1][-1]) if isinstance(losses, (tuple, list)) and len(losses[-1]) else None
 
     out = {
@@ -355,7 +384,16 @@ def main():
         "config": {"workload": workload, "bench_config": cfg, "collocation_points_global": n_global, "precision_mode": args.precision,
                    "parallelism": f"dp{world}", "always_reduce": bool(args.always_reduce), "final_loss": final_loss, "algorithmic_flop_per_point": flop_pt},
         "whole_path": {"achieved_tflops": flop_pt * value / 1e12, "frac_of_mfma_peak": flop_pt * value / 1e12 / (MFMA_PEAK_TFLOPS * world)},
+        "shader_clock_ghz": shader_clock_ghz,
+        "shader_clock_note": "shader cycles of workgroup 0 over one collocation launch (in-kernel stamps) / the mean HIP-event duration of the launches "
+                             "recorded in the same block: the clock the dominant kernel ran at on THIS box -- it is power-limited, and box-to-box "
+                             "differences of ms_per_step (+-2.5 %) follow it",
+        "allreduce_ms": allreduce_ms,
+        "rank_share": share if share > 1 else None,
     }
+    if allreduce_ms is not None:
+        out["allreduce_note"] = ("mean of timing events recorded on the step's stream around torch.distributed.all_reduce of the fused buffer "
+                                 f"[gradient | loss sums] ({4 * model._buf.numel()} bytes), backend {backend}, world {world}")
     if rank == 0:
         # MFMAs issued per algorithmic product (forward and reverse chain: 8 of 12 contractions, 3 per product; weight gradient: 4 of 12): the
         # narrow four- and five-stream collocation kernels multiply high parts only there (1, round 4), the LDS-operand layouts (padded width
@@ -387,12 +425,18 @@ def main():
                                "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch, "algorithmic_flop_per_point": kflop,
                                "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "launch_ms_min_max": [float(collo_ms.min()), float(collo_ms.max())] if collo_ms.size else None,
                                "side_sets_launch_ms": float(side_ms.mean()) if side_ms.size else None,
+                               "ring_every": RING_EVERY,
+                               "step_decomposition_ms": None if not collo_ms.size else {
+                                   "collocation_launch": float(collo_ms.mean()), "side_sets_launch": float(side_ms.mean()) if side_ms.size else 0.0,
+                                   "rest_of_step": 1e3 * dt / steps - float(collo_ms.mean()) - (float(side_ms.mean()) if side_ms.size else 0.0),
+                                   "note": "rest_of_step = ms_per_step - the two fused launches = repack + reductions + Adam (+ collective) + launch gaps; "
+                                           "with events on every 8th step only the pieces add up to the TIMED blocks' step (contract: launches <= 1.01 x ms_per_step)"},
                                "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (one product per contraction) / mean HIP-event duration of the launches of one "
                                        "more block of steps behind the timed ones (events in stream order, nothing synchronises in between); the f16x3 mode issues 3 MFMAs per "
                                        f"product in the forward / reverse chain and {wg_mfma} in the weight gradient, so a 100 %-busy matrix pipe is frac {1.0 / issued:.3f}. "
-                                       "Measured limiter: one wave's in-order issue of vector instructions + MFMAs and its vector-memory instructions (DESIGN.md section 6, profiles/r04_opcode_issue_costs.md). traffic is not measured in this "
-                                       "run (PMC counters need rocprofv3); see traffic_from_profiles"}
+                                       "Measured limiter: one wave's in-order issue of vector instructions + MFMAs and its vector-memory instructions (DESIGN.md section 4, profiles/r04_opcode_issue_costs.md). traffic: NOT MEASURED IN THIS "
+                                       "RUN (PMC counters need rocprofv3); traffic_from_profiles quotes the committed PMC passes of the same kernel sources"}
             out["kernel_ms_per_step"] = acc
         elif cfg == "plate" and eng.lib.supported_width(layers[1]) <= 96 and len(layers) - 2 in (4, 8):
             # ---- the five-stream instantiation of the fused kernel: HIP events around the kernel on the launch stream (process-wide

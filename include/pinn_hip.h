@@ -82,6 +82,31 @@ int pinn_supported_width(int h);
 /* Largest |w| the fused kernels' weight format holds (2047); see PINN_PREC_F16X3 (3) and PINN_FLAG_TWO_KERNEL. */
 float pinn_fused_weight_limit(void);
 
+/* Which kernel path a loss + gradient call takes (round 5: no silent slow path).  `head` names the entry point family, `ws_bytes` is the
+ * workspace the calls will be given (0: assume pinn_workspace_bytes() of a large set).  The answer is the rule the calls themselves apply
+ * (same code), so a caller -- the model classes warn once -- can tell BEFORE training that a net lands on the two-kernel path, which is
+ * 2.3-5x slower than the fused persistent kernel (profiles/r04_conf_time.txt): the fused kernel is compiled for the depths the reference
+ * uses (padded width <= 64: 4 or 8 hidden layers; 96 / 128: 8; 160: 6; the 3-D net: 10 x 128). */
+enum {
+    PINN_HEAD_WAVE = 0,        /* pinn_wave2d_loss_grad: four streams */
+    PINN_HEAD_DATA = 1,        /* pinn_data_loss_grad(_multi), pinn_plate2d_traction_loss_grad: one stream */
+    PINN_HEAD_PLATE = 2,       /* pinn_plate2d_loss_grad: five streams (second time derivative) */
+    PINN_HEAD_NC3D = 3,        /* pinn_nc3d_loss_grad: four inputs, five first-order streams */
+    PINN_HEAD_NC3D_DATA = 4,   /* pinn_nc3d_data_loss_grad */
+    PINN_HEAD_STREAMS = 5      /* pinn_stream_loss_grad (the plate's pre-training losses) */
+};
+enum {
+    PINN_PATH_FUSED_REGISTERS = 1,   /* fused persistent kernel, tile state in registers (padded width <= 64) */
+    PINN_PATH_FUSED_LDS = 2,         /* fused persistent kernel, LDS-operand layout (padded widths 96 / 128 / 160) */
+    PINN_PATH_TWO_KERNEL = 3,        /* chain_kernel + wgrad_kernel with state / adjoint panels through the workspace */
+    PINN_PATH_FP32 = 4               /* PINN_PREC_FP32: the checker mode, no matrix pipe */
+};
+/* returns a PINN_PATH_* value, or a negative PINN_ERR_* code (unsupported layer list / precision mode) */
+int pinn_path_for(const int* layers, int n_layers, int precision_mode, int head, size_t ws_bytes);
+/* Process-wide counters of the paths the loss + gradient calls actually took since the last reset: counts[PINN_PATH_*] (index 0 unused).
+ * `reset` != 0 zeroes them after the read.  Tests assert with it that a case ran where it was meant to run. */
+void pinn_debug_path_counts(int64_t counts[5], int reset);
+
 /* Workspace sizing.  `recommended` holds all tiles of an n-point call in one pass; anything
  * >= `min` works (the call then walks the points in several chunks).  The fused persistent kernel (one launch per call, what the
  * published numbers are measured with) needs one scratch image per workgroup on top of the fixed part -- pinn_workspace_bytes() of a
@@ -258,6 +283,10 @@ void pinn_debug_set_profile_buffer(float* host_ms4);
  * recorded launches, writes their milliseconds and stream counts (4 / 5: a collocation set, 1: the value-only side sets) in launch
  * order and returns how many there were.  Either output may be NULL. */
 int pinn_debug_profile_ring_arm(int max_launches);
+/* ... of every `every`-th step only (a step = one collocation launch and the side-set launches behind it; default 1): the events of a
+ * bracketed launch put barrier packets between back-to-back kernels, which slowed a fully bracketed block by 3.8 % (round 4); at a stride
+ * of 8 the block is the timed loop again to 0.5 %.  Applies to the next _arm(). */
+void pinn_debug_profile_ring_stride(int every);
 int pinn_debug_profile_ring_read(float* ms_out, int* streams_out, int capacity);
 
 const char* pinn_error_string(int code);

@@ -9,6 +9,8 @@ import ctypes as C
 import os
 
 PREC = {"bf16": 0, "f16x3": 1, "f16": 2, "bf16x3": 3, "fp32": 4}
+HEADS = {"wave": 0, "data": 1, "plate": 2, "nc3d": 3, "nc3d_data": 4, "streams": 5}      # PINN_HEAD_*
+PATHS = {1: "fused-registers", 2: "fused-lds", 3: "two-kernel", 4: "fp32"}                  # PINN_PATH_*
 FLAG_WEIGHTS_PACKED = 0x100
 FLAG_TWO_KERNEL = 0x400            # PINN_FLAG_TWO_KERNEL: keep the call off the fused kernel (weights beyond its |w| <= 2047 format)
 FLAG_STATE_FP16 = 0x200            # PINN_FLAG_STATE_FP16: fused 8-layer collocation kernel parks fp16 states only (faster, not parity-grade)
@@ -100,6 +102,14 @@ class PinnLib:
         L.pinn_debug_set_fused.restype = i32
         L.pinn_fused_weight_limit.argtypes = []
         L.pinn_fused_weight_limit.restype = C.c_float
+        L.pinn_path_for.argtypes = [pi32, i32, i32, i32, sz]
+        L.pinn_path_for.restype = i32
+        L.pinn_debug_path_counts.argtypes = [vp, i32]
+        L.pinn_debug_path_counts.restype = None
+        L.pinn_debug_profile_ring_stride.argtypes = [i32]
+        L.pinn_debug_profile_ring_stride.restype = None
+        L.pinn_debug_set_stamp_buffer.argtypes = [vp]
+        L.pinn_debug_set_stamp_buffer.restype = None
         L.pinn_debug_profile_ring_arm.argtypes = [i32]
         L.pinn_debug_profile_ring_arm.restype = i32
         L.pinn_debug_profile_ring_read.argtypes = [vp, vp, i32]
@@ -144,9 +154,30 @@ class PinnLib:
         self.lib.pinn_debug_set_profile_buffer(None)      # (the module-level buffer stays allocated: a launch in flight may still write to it)
         return None
 
-    def profile_ring_arm(self, max_launches: int) -> int:
-        """Start recording the next launches of the fused kernel with HIP events in stream order, nothing synchronises (include/pinn_hip.h)"""
+    def profile_ring_arm(self, max_launches: int, every: int = 1) -> int:
+        """Start recording the next launches of the fused kernel with HIP events in stream order, nothing synchronises (include/pinn_hip.h);
+        ``every`` > 1: the launches of every ``every``-th step only"""
+        self.lib.pinn_debug_profile_ring_stride(int(every))
         return int(self.lib.pinn_debug_profile_ring_arm(int(max_launches)))
+
+    def set_stamp_buffer(self, device_ptr) -> None:
+        """128 x uint64 device buffer for the fused kernel's shader-clock stamps of workgroup 0 (None: off)"""
+        self.lib.pinn_debug_set_stamp_buffer(None if device_ptr is None else C.c_void_p(int(device_ptr)))
+
+    def path_for(self, layers, precision, head: str = "wave", ws_bytes: int = 0) -> str:
+        """pinn_path_for: 'fused-registers' | 'fused-lds' | 'two-kernel' | 'fp32' for a loss + gradient call of family ``head``
+        ('wave', 'data', 'plate', 'nc3d', 'nc3d_data', 'streams'); ``precision`` is a mode name or the full precision_mode word"""
+        mode = PREC[precision] if isinstance(precision, str) else int(precision)
+        rc = int(self.lib.pinn_path_for(self._ints(layers), len(layers), mode, HEADS[head], int(ws_bytes)))
+        if rc <= 0:
+            raise PinnLibError(f"pinn_path_for failed: {self.lib.pinn_error_string(rc).decode()} (code {rc})")
+        return PATHS[rc]
+
+    def path_counts(self, reset: bool = False) -> dict:
+        """calls per path since the last reset (pinn_debug_path_counts)"""
+        buf = (C.c_int64 * 5)()
+        self.lib.pinn_debug_path_counts(C.cast(buf, C.c_void_p), int(bool(reset)))
+        return {PATHS[i]: int(buf[i]) for i in range(1, 5)}
 
     def profile_ring_read(self):
         """Stop the recording and return (milliseconds, streams) of the recorded launches, in launch order"""

@@ -78,6 +78,8 @@ static int g_use_fused = 1;
 static unsigned long long* g_dbg_stamps = nullptr;
 static float* g_prof_ms = nullptr;
 static ProfRing g_ring;
+static int g_ring_every = 1;
+namespace pinn { long g_path_counts[5] = {0, 0, 0, 0, 0}; }
 
 extern "C" {
 
@@ -92,8 +94,20 @@ int pinn_debug_profile_ring_arm(int max_launches) {
     if (max_launches < 0) max_launches = 0;
     g_ring.limit = max_launches > ProfRing::CAP ? ProfRing::CAP : max_launches;
     g_ring.n = 0;
+    g_ring.every = g_ring_every;
+    g_ring.steps_seen = 0;
+    g_ring.step_on = true;
     g_ring.armed = g_ring.limit > 0;
     return g_ring.limit;
+}
+
+void pinn_debug_profile_ring_stride(int every) { g_ring_every = every < 1 ? 1 : every; }
+
+void pinn_debug_path_counts(int64_t counts[5], int reset) {
+    for (int i = 0; i < 5; ++i) {
+        if (counts) counts[i] = (int64_t)g_path_counts[i];
+        if (reset) g_path_counts[i] = 0;
+    }
 }
 
 int pinn_debug_profile_ring_read(float* ms_out, int* streams_out, int capacity) {
@@ -206,6 +220,24 @@ size_t pinn_workspace_bytes(const int* layers, int n_layers, int64_t n, int prec
     return impl ? impl->ws_bytes(net, (long)n, 0) : 0;
 }
 
+int pinn_path_for(const int* layers, int n_layers, int precision_mode, int head, size_t ws_bytes) {
+    if (!layers) return PINN_ERR_NULL;
+    if (head < PINN_HEAD_WAVE || head > PINN_HEAD_STREAMS) return PINN_ERR_LAYERS;
+    const int din = (head == PINN_HEAD_NC3D || head == PINN_HEAD_NC3D_DATA) ? 4 : 3;
+    NetDesc net;
+    int width = 0;
+    const int rc = decode_net(layers, n_layers, net, width, din);
+    if (rc) return rc;
+    const int mode = mode_only(precision_mode);
+    if (mode < 0 || mode > PINN_PREC_FP32) return PINN_ERR_PRECISION;
+    if (mode == PINN_PREC_FP32) return PINN_PATH_FP32;
+    const Impl* impl = find_impl(mode, width);
+    if (!impl) return PINN_ERR_LAYERS;
+    const int path = impl->path_for(net, head, ws_bytes);
+    if (path > 0 && ((precision_mode & PINN_FLAG_TWO_KERNEL) || !g_use_fused)) return PINN_PATH_TWO_KERNEL;
+    return path;
+}
+
 size_t pinn_min_workspace_bytes(const int* layers, int n_layers, int precision_mode) {
     NetDesc net;
     int width = 0;
@@ -221,6 +253,7 @@ static int fp32_call(const Call& c, int head, int nterms, int ns, int din = 3) {
     hipStream_t st = c.stream;
     const size_t per_point = fp32_bytes_per_point(c.net, ns);
     if (((uintptr_t)c.ws & 255) != 0 || c.ws_bytes < per_point * 256) return PINN_ERR_WORKSPACE;
+    ++g_path_counts[PINN_PATH_FP32];
     long mmax = (long)(c.ws_bytes / per_point);
     if (mmax > (1L << 20)) mmax = 1L << 20;
     Fp32Args a;

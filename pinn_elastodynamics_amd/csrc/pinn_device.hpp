@@ -47,6 +47,7 @@ struct OpF16 {
     // low part of the hi/lo split is stored scaled by 2^11 so that it keeps fp16's normal range
     static constexpr float LO_SCALE = 2048.0f;
     static constexpr bool TOP_BYTE_IS_FLOAT = true;      // the top byte of a value is itself a float (e5m2): the fused kernel's one-byte low parts (LO8)
+    static constexpr float OPERAND_MAX = 65504.0f;       // largest finite fp16: |w| <= 2047 in the fused weight format (FUSED_OPERAND_MAX)
     static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(V8, a), __builtin_bit_cast(V8, b), c, 0, 0, 0);
     }
@@ -57,6 +58,7 @@ struct OpBF16 {
     typedef bf16x2 V2;
     static constexpr float LO_SCALE = 256.0f;
     static constexpr bool TOP_BYTE_IS_FLOAT = false;     // (sign + seven of eight exponent bits)
+    static constexpr float OPERAND_MAX = 3.3895314e38f;  // largest finite bf16: the fused weight format of bf16x3 has fp32's range
     static __device__ __forceinline__ f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(V8, a), __builtin_bit_cast(V8, b), c, 0, 0, 0);
     }
@@ -378,7 +380,7 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackArgs a) {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     const float v0 = wv[2 * d] * FUSED_WEIGHT_SCALE, v1 = wv[2 * d + 1] * FUSED_WEIGHT_SCALE;
-                    out_of_range |= !(__builtin_fabsf(v0) <= FUSED_OPERAND_MAX) || !(__builtin_fabsf(v1) <= FUSED_OPERAND_MAX);      // (also true for NaN)
+                    out_of_range |= !(__builtin_fabsf(v0) <= Op::OPERAND_MAX) || !(__builtin_fabsf(v1) <= Op::OPERAND_MAX);      // (also true for NaN; per operand type: bf16x3 holds fp32's range)
                     p0[d] = pack2<Op>(v0, v1);
                     p1[d] = pack2<Op>(v0 - round16<Op>(v0), v1 - round16<Op>(v1));
                     p2[d] = pack2<Op>(round16<Op>(v0) * (1.0f / Op::LO_SCALE), round16<Op>(v1) * (1.0f / Op::LO_SCALE));
@@ -1278,7 +1280,15 @@ __global__ __launch_bounds__(256) void reduce_grad_loss_kernel(const float* part
 // slots per wave: 8, or LOSS_SLOTS_3D for the 3-D heads; nterms <= slots)
 template <int UNUSED = 0>
 __global__ __launch_bounds__(256) void reduce_loss_kernel(const float* loss_part, long nwaves, int nterms, float* loss_terms,
-                                                          int accumulate, int slots) {
+                                                          int accumulate, int slots, const int* wflags = nullptr, int nflags = 0) {
+    // (fused 3-D path: the same NaN poisoning as reduce_grad_loss_kernel when a weight left the fused format)
+    __shared__ int bad_weights;
+    if (threadIdx.x == 0) bad_weights = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nflags; i += 256)
+        if (wflags[i]) bad_weights = 1;
+    __syncthreads();
+    const float poison = bad_weights ? __builtin_nanf("") : 0.0f;
     const int sub = threadIdx.x & 31;
     for (int term = threadIdx.x >> 5; term < slots; term += 8) {
         double s = 0.0;
@@ -1290,7 +1300,7 @@ __global__ __launch_bounds__(256) void reduce_loss_kernel(const float* loss_part
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 8);
         v += __shfl_xor(v, 16);
-        if (sub == 0 && term < nterms) loss_terms[term] = (accumulate ? loss_terms[term] : 0.0f) + v;
+        if (sub == 0 && term < nterms) loss_terms[term] = (accumulate ? loss_terms[term] : 0.0f) + v + poison;
     }
 }
 

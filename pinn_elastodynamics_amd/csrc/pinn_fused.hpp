@@ -241,6 +241,14 @@ struct Fused {
     // than to the instructions that move them (DESIGN section 6 "Round 4"); the low image of a layer is then NS records: (stream) -> 16 bytes per
     // lane = the four blocks' four values each.
     static constexpr bool LO8 = PINN_LO8_ENABLED && Op::TOP_BYTE_IS_FLOAT && !LDSOP && !SLDS && WB == 4 && NP == 2 && !FASTSTATE && KS == 2;      // (four- and five-stream narrow layouts)
+    // LO_FROM (round 5, the per-layer low-part policy): parked states S_2 .. S_{LO_FROM-1} travel WITHOUT a low-part record -- the activation reverse
+    // of those layers sees fp16 states.  tools/studies/lo_policy_study.py (the kernel's arithmetic in numpy at the reference's trained nets and the
+    // 8 x 64 fixture, per weight layer and bias against the fp32 bound of the GPU tests) prices every subset; see DESIGN section 4.
+#ifndef PINN_LO_FROM
+#define PINN_LO_FROM 2
+#endif
+    static constexpr int LO_FROM = PINN_LO_FROM;
+    static __device__ __forceinline__ constexpr bool lo_layer(int l) { return l <= 1 || l >= LO_FROM; }
     static __device__ __forceinline__ uint32_t lo8_pack(uint32_t rows01, uint32_t rows23) {       // the high bytes of four fp16 values
 #if defined(__AMDGCN__)
         return __builtin_amdgcn_perm(rows23, rows01, 0x07050301u);
@@ -1476,6 +1484,7 @@ struct Fused {
                     if (mine(s)) __builtin_amdgcn_raw_buffer_store_b128(Sf[s][0][kk][0], x.scr, x.imgoff, (l - 1) * IMG_B + (s * KS + kk) * 1024, 0);
         }
         if constexpr (LO8) {
+            if (lo_layer(l))
 #pragma unroll
             for (int s = 0; s < NS; ++s)
                 if (mine(s)) {
@@ -1652,7 +1661,7 @@ struct Fused {
         u32x2 (&slnxt)[NS] = (MB & 1) ? sla : slb;
         if constexpr (!TOP && LO8) {                           // this block's four bytes of every stream -> two fp16 pairs
 #pragma unroll
-            for (int s = 0; s < NS; ++s) slcur[s] = lo8_unpack((*slq)[s][MB]);
+            for (int s = 0; s < NS; ++s) slcur[s] = slq != nullptr ? lo8_unpack((*slq)[s][MB]) : u32x2{0u, 0u};      // (nullptr: a layer without low-part record, LO_FROM)
         }
         u32x4 (&Acur)[KSB][RP] = (MB & 1) ? Ab : Aa;
         u32x4 (&Anxt)[KSB][RP] = (MB & 1) ? Aa : Ab;
@@ -1733,6 +1742,8 @@ struct Fused {
                 load_afrags<KS, RP>(x, FI::bwd_mid(NL, L, 1, 0), Ab);
                 if constexpr (S1_LDS) {
                     // (read behind the barrier below)
+                } else if constexpr (!RECOMP && LO8 && !lo_layer(L)) {
+                    // (no low-part record for this layer: LO_FROM)
                 } else if constexpr (!RECOMP && LO8) {
 #pragma unroll
                     for (int s = 0; s < NS; ++s) slq[s] = __builtin_amdgcn_raw_buffer_load_b128(x.scr, x.imgoff, SCRATCH_LO + (L - 1) * IMG_B + s * 1024, 0);
@@ -1768,7 +1779,7 @@ struct Fused {
                 // (ZDB: Z_{L-1} goes to the other adjoint buffer while the weight-gradient waves read Z_L from this layer's)
                 char* zout = x.imgZ() + zbuf(L - 1);
                 if constexpr (RECOMP) bwd_step<0, KS, true, ZDB>(x, FI::bwd_mid(NL, L, 0, 0), L, nullptr, S1, Zc, Zn, Aa, Ab, acca, accb, sla, slb, zout);
-                else bwd_step<0, KS, false, ZDB>(x, FI::bwd_mid(NL, L, 0, 0), L, x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb, sla, slb, zout, &slq);
+                else bwd_step<0, KS, false, ZDB>(x, FI::bwd_mid(NL, L, 0, 0), L, x.imgS(L), Zc /*unused*/, Zc, Zn, Aa, Ab, acca, accb, sla, slb, zout, (LO8 && !lo_layer(L)) ? nullptr : &slq);
                 pin<KS>(Zn);
                 fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
                 Down<L - 1>::run(a, x, xin, Zn);
@@ -2435,6 +2446,11 @@ struct Fused {
                 for (int i = 0; i < LT; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, x.scr, x.lane16 >> 2, LSUM_OFF + i * 256, 0);
             }
         }
+        // launch-long stamps of workgroup 0 (slots 124 / 125; the one-stream launches 122 / 123): shader cycles of the whole launch, which over its
+        // HIP-event duration are the clock the launch ran at (bench.py: shader_clock_ghz -- the kernel is power-limited, and a bench line without
+        // its clock cannot tell a code change from a box)
+        const bool launch_tracer = x.tracer;
+        fused_stamp(a, launch_tracer, NS == 1 ? 122 : 124);
         for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
             float xin[4];
             bool valid;
@@ -2492,6 +2508,7 @@ struct Fused {
                 reverse_tile(a, x, xin, B, ZL);
             }
         }
+        fused_stamp(a, launch_tracer, NS == 1 ? 123 : 125);
         if constexpr (LSUM_MEM) {
             if (half == 0) {
 #pragma unroll

@@ -29,10 +29,13 @@ struct ProfRing {
     hipEvent_t ev[CAP][2];
     int tag[CAP];              // streams of the recorded launch (4 / 5: a collocation set, 1: the value-only side sets)
     int created = 0, n = 0, limit = 0;
-    bool armed = false;
-    // slot for the next launch, or -1 (not armed / full)
+    int every = 1, steps_seen = 0;      // record every `every`-th step only (a collocation launch opens a step)
+    bool armed = false, step_on = true;
+    // slot for the next launch, or -1 (not armed / full / a step that is not recorded)
     int begin(hipStream_t st, int tag_) {
         if (!armed || n >= limit) return -1;
+        if (tag_ >= 4) step_on = (steps_seen++ % every) == 0;
+        if (!step_on) return -1;
         if (n >= created) {
             if (hipEventCreate(&ev[n][0]) != hipSuccess || hipEventCreate(&ev[n][1]) != hipSuccess) return -1;
             created = n + 1;
@@ -82,7 +85,11 @@ struct Call {
     int fast_state;            // PINN_FLAG_STATE_FP16: fused kernel parks its states as fp16 high parts only (faster, less accurate at trained weights)
 };
 
+// paths taken by the loss + gradient calls of this process (pinn_debug_path_counts); defined in pinn_capi.hip
+extern long g_path_counts[5];
+
 struct Impl {
+    int (*path_for)(const NetDesc&, int head, size_t ws_bytes);
     int (*wave_loss_grad)(const Call&);
     int (*data_loss_grad)(const Call&);
     int (*fields)(const Call&);
@@ -278,6 +285,7 @@ struct Host {
         Plan p;
         int rc = make_plan<NS>(c, p, true);
         if (rc) return rc;
+        ++g_path_counts[PINN_PATH_TWO_KERNEL];
         // optional HIP-event timing of each kernel class (bench.py's roofline leg)
         float acc_ms[4] = {0.f, 0.f, 0.f, 0.f};
         const bool prof = c.prof_ms != nullptr;
@@ -331,7 +339,7 @@ struct Host {
             toc(1);
             tic();
             hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)blocks * 4, nterms,
-                               c.loss_out, pass > 0 ? 1 : 0, head_is_3d(HEAD) ? LOSS_SLOTS_3D : 8);
+                               c.loss_out, pass > 0 ? 1 : 0, head_is_3d(HEAD) ? LOSS_SLOTS_3D : 8, (const int*)nullptr, 0);
             if ((rc = (int)hipGetLastError())) return rc;
             toc(3);
             w.ntiles = nt;
@@ -461,7 +469,7 @@ struct Host {
                                    grid, c.net.nparams, twmax, c.grad_out, c.accumulate, (const float*)a.loss_part, (long)grid * F::TILES, 0, 0, SLOTS, lo,
                                    (const int*)(b + p.wflags), SPLIT == 3 ? repack_blocks(c.net) : 0);
                 hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * F::TILES, nterms,
-                                   c.loss_out, 0, LOSS_SLOTS_3D);
+                                   c.loss_out, 0, LOSS_SLOTS_3D, (const int*)(b + p.wflags), SPLIT == 3 ? repack_blocks(c.net) : 0);
                 return (int)hipGetLastError();
             }
             hipLaunchKernelGGL((reduce_grad_loss_kernel<0>), dim3((c.net.nparams + 63) / 64 + nsets), dim3(256), 0, c.stream, (const float*)a.partial,
@@ -473,25 +481,73 @@ struct Host {
         }
     }
 
+    // The depths the fused kernel is compiled for (the ones the reference's scripts use): the rule of try_fused AND of pinn_path_for.
+    template <int NS>
+    static bool fused_depth(const NetDesc& net) {
+        if constexpr (!fused_has<NS>()) return false;
+        if constexpr (WIDTH == 160) return net.nl == 6;          // padded width 160: the reference's confined-domain net, 6 x 140 (CONF:891)
+        if (net.nl != 4 && net.nl != 8) return false;
+        if (WIDTH > 64 && net.nl != 8) return false;            // padded widths 96 / 128: the 8-layer instantiations only (INF:645 8 x 80, SEMI:679 8 x 100)
+        return true;
+    }
+    // scratch images (= persistent workgroups) a workspace of ws_bytes holds for the NS-stream fused kernel of this net
+    template <int NS>
+    static long fused_images(const NetDesc& net, size_t ws_bytes) {
+        if constexpr (fused_has<NS>()) {
+            Plan p;
+            plan_fixed<4>(net, 1, p);
+            constexpr int TILES = Fused<Op, SPLIT, WIDTH, 4, NS>::TILES;
+            // (sized for the default layout, which parks more than the fp16-state one)
+            const size_t per_wg = (size_t)TILES * (WIDTH == 160 ? Fused<Op, SPLIT, WIDTH, 6, NS>::SCRATCH_BYTES
+                                                                : (net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NS>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NS>::SCRATCH_BYTES));
+            if (ws_bytes < p.fixed_end + per_wg) return 0;
+            return (long)((ws_bytes - p.fixed_end) / per_wg);
+        } else {
+            return 0;
+        }
+    }
+    static long fused_images_3d(const NetDesc& net, size_t ws_bytes) {
+        if constexpr (fused_has_3d()) {
+            typedef Fused<Op, SPLIT, WIDTH, 10, 5, false, 4> F;
+            Plan p;
+            plan_fixed<4>(net, 1, p);
+            const size_t per_wg = (size_t)F::TILES * F::SCRATCH_BYTES;
+            if (ws_bytes < p.fixed_end + per_wg) return 0;
+            return (long)((ws_bytes - p.fixed_end) / per_wg);
+        } else {
+            return 0;
+        }
+    }
+    // pinn_path_for: the path a call of this family takes for this net (ws_bytes == 0: a workspace that holds every scratch image)
+    static int path_for(const NetDesc& net, int head, size_t ws_bytes) {
+        const int fused_kind = WIDTH <= 64 ? PINN_PATH_FUSED_REGISTERS : PINN_PATH_FUSED_LDS;
+        auto enough = [&](long images) { return ws_bytes == 0 || images >= FUSED_MIN_GRID; };
+        switch (head) {
+            case PINN_HEAD_WAVE: return fused_depth<4>(net) && enough(fused_images<4>(net, ws_bytes)) ? fused_kind : PINN_PATH_TWO_KERNEL;
+            case PINN_HEAD_DATA: return fused_depth<1>(net) && enough(fused_images<1>(net, ws_bytes)) ? fused_kind : PINN_PATH_TWO_KERNEL;
+            case PINN_HEAD_PLATE:
+                if (SPLIT != 3) return PINN_ERR_PRECISION;
+                return fused_depth<5>(net) && enough(fused_images<5>(net, ws_bytes)) ? fused_kind : PINN_PATH_TWO_KERNEL;
+            case PINN_HEAD_NC3D:
+                if (SPLIT != 3) return PINN_ERR_PRECISION;
+                return fused_has_3d() && net.nl == 10 && net.din == 4 && net.nout == 12 && enough(fused_images_3d(net, ws_bytes)) ? PINN_PATH_FUSED_LDS : PINN_PATH_TWO_KERNEL;
+            case PINN_HEAD_NC3D_DATA:
+            case PINN_HEAD_STREAMS: return SPLIT == 3 ? PINN_PATH_TWO_KERNEL : PINN_ERR_PRECISION;
+            default: return PINN_ERR_LAYERS;
+        }
+    }
+
     // returns 1 if the fused path ran (rc in *out), 0 if it does not apply
     template <int NS>
     static int try_fused(const Call& c, int* out, int nterms) {
         if constexpr (fused_has<NS>()) {
-            if constexpr (WIDTH == 160) {
-                if (c.net.nl != 6) return 0;                    // padded width 160: the reference's confined-domain net, 6 x 140 (CONF:891)
-            } else {
-                if (c.net.nl != 4 && c.net.nl != 8) return 0;
-                if (WIDTH > 64 && c.net.nl != 8) return 0;      // padded widths 96 / 128: the 8-layer instantiations only (INF:645 8 x 80, SEMI:679 8 x 100)
-            }
+            if (!fused_depth<NS>(c.net)) return 0;
             Plan p;
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
             constexpr int TILES = Fused<Op, SPLIT, WIDTH, 4, NS>::TILES;
-            // (sized for the default layout, which parks more than the fp16-state one)
-            const size_t per_wg = (size_t)TILES * (WIDTH == 160 ? Fused<Op, SPLIT, WIDTH, 6, NS>::SCRATCH_BYTES
-                                                                : (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NS>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NS>::SCRATCH_BYTES));
-            if (c.ws_bytes < p.fixed_end + per_wg) return 0;
-            long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
+            long grid = fused_images<NS>(c.net, c.ws_bytes);
+            if (grid == 0) return 0;
             if (grid > FUSED_GRID) grid = FUSED_GRID;
             long nsteps = 0;
             if (NS == 1) {
@@ -508,6 +564,7 @@ struct Host {
             else if constexpr (WIDTH > 64) *out = fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
             else if (c.fast_state && SPLIT == 3 && NS == 4 && c.net.nl == 8) *out = fused_launch<8, NS, true>(c, p, (int)grid, nterms, nsteps);   // the collocation kernel of the 8-layer nets
             else *out = c.net.nl == 4 ? fused_launch<4, NS>(c, p, (int)grid, nterms, nsteps) : fused_launch<8, NS>(c, p, (int)grid, nterms, nsteps);
+            ++g_path_counts[WIDTH <= 64 ? PINN_PATH_FUSED_REGISTERS : PINN_PATH_FUSED_LDS];
             return 1;
         } else {
             return 0;
@@ -531,6 +588,7 @@ struct Host {
             if (grid > nsteps) grid = nsteps;
             if (grid < FUSED_MIN_GRID && grid < nsteps) return 0;      // (see FUSED_MIN_GRID)
             *out = fused_launch<10, 5, false, 4>(c, p, (int)grid, 12, nsteps);
+            ++g_path_counts[PINN_PATH_FUSED_LDS];
             return 1;
         } else {
             return 0;
@@ -632,7 +690,7 @@ struct Host {
     }
 
     static const Impl* impl() {
-        static const Impl I = {&wave_loss_grad, &data_loss_grad, &fields, &ws_bytes,
+        static const Impl I = {&path_for, &wave_loss_grad, &data_loss_grad, &fields, &ws_bytes,
                                &plate_loss_grad, &traction_loss_grad, &stream_loss_grad, &streams,
                                &nc3d_loss_grad, &nc3d_data_loss_grad, &nc3d_fields};
         return &I;

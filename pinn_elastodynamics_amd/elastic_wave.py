@@ -114,6 +114,20 @@ def relax_adjoint_shift(engine, loss, state):
         state["raised_at"] = loss
 
 
+def all_reduce_sum(buf, group, events=None):
+    """The step's one collective: all-reduce(sum) of the fused buffer [gradient | loss sums] (RCCL under the "nccl" backend), enqueued in stream
+    order behind the kernels that filled it.  ``events``: a list that receives one (start, end) pair of timing events per call, recorded on the
+    current stream around the collective (the stream waits for the communicator's own stream, so the pair brackets it) -- bench.py's
+    ``allreduce_ms``; None (default): nothing is recorded."""
+    if events is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+    torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=group)
+    if events is not None:
+        ev[1].record()
+        events.append(ev)
+
+
 def lbfgs_on_device(theta, loss_and_grad, options, callback=None):
     """The L-BFGS stage without the host in the loop: ``torch.optim.LBFGS`` (two-loop recursion with ``maxcor`` correction pairs and a
     strong-Wolfe line search, all vector work on the GPU in fp32) drives the same kernels.  ``loss_and_grad()`` evaluates at the current
@@ -150,7 +164,7 @@ class DeepHPM(NetApi):
 
     def __init__(self, Collo, SRC, IC, UP, uv_layers, lb, ub, ExistModel=0, modelDir='', *, case="infinite",
                  FIX=None, precision="f16x3", engine=None, seed=1111, process_group=None, verbose=True,
-                 E=2.5, mu=0.25, rho=1.0, always_reduce=False):
+                 E=2.5, mu=0.25, rho=1.0, always_reduce=False, shard_as=None):
         self.count = 0                      # callback counter (INF:26)
         self._shift_state = {}              # adjoint-shift bookkeeping of evaluate_with_finite_gradient
         self.loss_rec = []                  # SEMI:39
@@ -170,9 +184,13 @@ class DeepHPM(NetApi):
             self.world = torch.distributed.get_world_size(self.pg)
         else:
             self.rank, self.world = 0, 1
+        if shard_as is not None:
+            # ``shard_as=(r, w)``: hold and evaluate rank r's share of a w-rank job WITHOUT the other ranks -- every set sharded by _shard, sums
+            # weighted with the global 1/N, exactly what that rank executes per step (bench.py --rank-share; the collective is a separate switch)
+            self.rank, self.world = int(shard_as[0]), int(shard_as[1])
         # ``always_reduce``: run the step's all-reduce even in a process group of one rank -- the collective branch (RCCL under the
         # "nccl" backend) then executes on a single GPU exactly as it does on eight, which is how the tests prove that path here
-        self._reduce = self.world > 1 or (bool(always_reduce) and torch.distributed.is_available() and torch.distributed.is_initialized())
+        self._reduce = (self.world > 1 and shard_as is None) or (bool(always_reduce) and torch.distributed.is_available() and torch.distributed.is_initialized())
 
         # ---- engine (GPU kernels); tests may inject a stand-in with the same methods
         if engine is None:
@@ -181,6 +199,8 @@ class DeepHPM(NetApi):
             engine = HipEngine(self.uv_layers, precision=precision, max_points=n_max)
         self.engine = engine
         self.device = engine.device
+        if hasattr(engine, "warn_if_slow_path"):
+            engine.warn_if_slow_path("wave")      # no silent slow path: a depth the fused kernel is not compiled for says so once
 
         # ---- weights (INF:64-68)
         self._init_rng = np.random.default_rng(seed)
@@ -407,7 +427,7 @@ class DeepHPM(NetApi):
         if self._reduce:
             # one fused buffer [gradient | loss sums] (latency-bound message); enqueued behind the kernels in stream order, and Adam is
             # enqueued behind it: the host never waits
-            torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None))
 
     def _terms_from_sums(self, sums, n_blk):
         """sums: [len(_SLOTS), 8] numpy array of sums of squares -> the reference's loss terms."""

@@ -72,12 +72,31 @@ class HipEngine:
         """The fused kernels' weight format holds |w| <= 2047 (include/pinn_hip.h); beyond it a call returns NaN throughout.  Called by the
         model classes when a result comes back non-finite: if a weight is out of range, this engine's calls switch to the two-kernel path
         (PINN_FLAG_TWO_KERNEL) for good and True is returned -- the caller repeats its evaluation.  Synchronises (one reduction)."""
-        if self.two_kernel or self.precision not in ("f16x3", "bf16x3"):
+        if self.two_kernel or self.precision != "f16x3":      # (bf16x3: the fused format has fp32's range, nothing to leave for)
             return False
         if float(params.detach().abs().max()) <= self.lib.fused_weight_limit():
             return False
         self.two_kernel = True
         return True
+
+    def path(self, head: str = "wave") -> str:
+        """Which kernel path this engine's loss + gradient calls of family ``head`` take ('fused-registers', 'fused-lds', 'two-kernel',
+        'fp32'): pinn_path_for with this engine's layer list, precision mode word and workspace size (include/pinn_hip.h)."""
+        return self.lib.path_for(self.layers, self._mode(False), head, self.ws_bytes)
+
+    def warn_if_slow_path(self, head: str = "wave") -> None:
+        """One warning per engine and family when the calls land on the two-kernel path (2.3-5x slower than the fused kernel): the fused
+        kernel is compiled for the depths the reference's scripts use, any other layer list still WORKS, just not at the published speed."""
+        seen = self.__dict__.setdefault("_slow_path_warned", set())
+        if head in seen:
+            return
+        if self.path(head) == "two-kernel" and not self.two_kernel:
+            import warnings
+            seen.add(head)
+            warnings.warn(f"layers {self.layers} ({self.precision}, '{head}' calls) run on the two-kernel path (chain_kernel + wgrad_kernel): "
+                          f"2.3-5x slower than the fused persistent kernel, which is compiled for 4 or 8 hidden layers of width <= 64, 8 of width "
+                          f"<= 128, 6 of width <= 160 and the 10 x 128 3-D net -- or the workspace is too small for its scratch images "
+                          f"(pinn_path_for, include/pinn_hip.h)", RuntimeWarning, stacklevel=3)
 
     def _stream(self) -> int:
         return torch.cuda.current_stream(self.device).cuda_stream

@@ -17,7 +17,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .elastic_wave import _col, evaluate_with_finite_gradient, pack_params, unpack_params, xavier_init  # noqa: F401
+from .elastic_wave import _col, all_reduce_sum, evaluate_with_finite_gradient, pack_params, unpack_params, xavier_init  # noqa: F401
 from .net_api import NetApi, read_checkpoint, write_checkpoint
 
 OUT = ("u", "v", "w", "ut", "vt", "wt", "s11", "s22", "s33", "s12", "s13", "s23")
@@ -61,6 +61,8 @@ class NavierCauchy3D(NetApi):
             engine = HipEngine(self.uv_layers, precision=precision, max_points=n_max)
         self.engine = engine
         self.device = engine.device
+        if hasattr(engine, "warn_if_slow_path"):
+            engine.warn_if_slow_path("nc3d")
         self._init_rng = np.random.default_rng(seed)
         if ExistModel == 0:
             W, b = self.initialize_NN(self.uv_layers)
@@ -224,7 +226,7 @@ class NavierCauchy3D(NetApi):
         if not wrote:
             grad.zero_()
         if self._reduce:
-            torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None))
 
     def _terms_from_sums(self, sums, n_blk):
         lay = self.layout

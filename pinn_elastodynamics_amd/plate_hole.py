@@ -16,7 +16,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from .elastic_wave import _col, evaluate_with_finite_gradient, lbfgs_on_device, pack_params, relax_adjoint_shift, unpack_params, xavier_init  # noqa: F401
+from .elastic_wave import _col, all_reduce_sum, evaluate_with_finite_gradient, lbfgs_on_device, pack_params, relax_adjoint_shift, unpack_params, xavier_init  # noqa: F401
 from .net_api import NetApi, read_checkpoint, write_checkpoint
 
 _EPS = float(np.finfo(float).eps)
@@ -57,6 +57,8 @@ class PINN(NetApi):
         self.device = engines["uv"].device
 
         self.engine = engines["uv"]            # (net_api.NetApi's default engine; nets of other sizes find theirs in _engine_for)
+        if hasattr(self.engine, "warn_if_slow_path"):
+            self.engine.warn_if_slow_path("plate")      # (the frozen 4 x 20 nets are evaluated once: their path does not matter)
         self._init_rng = np.random.default_rng(seed)
         self.theta, self.adam_m, self.adam_v = {}, {}, {}
         for key, layers, d in (("dist", self.dist_layers, distDir), ("part", self.part_layers, partDir), ("uv", self.uv_layers, uvDir)):
@@ -250,7 +252,7 @@ class PINN(NetApi):
         if not wrote:
             grad.zero_()
         if self._reduce:
-            torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=self.pg)
+            all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None))
 
     def _terms(self, sums):
         out = {"loss_f_uv": float(sums[0:2].sum() / self.n_collo), "loss_f_s": float(sums[2:5].sum() / self.n_collo),

@@ -77,3 +77,35 @@ def test_product_has_no_oracle_or_cpu_fallback():
         from pinn_elastodynamics_amd.hip_engine import HipEngine
         with pytest.raises(PinnLibError):
             HipEngine([3, 32, 32, 7])
+
+
+def test_path_for_names_the_path_of_every_layer_list(lib):
+    """pinn_path_for (round 5: no silent slow path): the fused kernel is compiled for the depths the reference uses; any other depth, a
+    workspace too small for its scratch images, PINN_FLAG_TWO_KERNEL and the fp32 checker mode are reported as what they are."""
+    from pinn_elastodynamics_amd.capi import FLAG_TWO_KERNEL, PREC, PinnLibError
+    w = lambda depth, width, nout=7, din=3: [din] + depth * [width] + [nout]
+    assert lib.path_for(w(8, 64), "f16x3", "wave") == "fused-registers"          # BASELINE configs[1]
+    assert lib.path_for(w(4, 32), "f16x3", "wave") == "fused-registers"          # configs[0]
+    assert lib.path_for(w(4, 32), "bf16", "wave") == "fused-registers"
+    assert lib.path_for(w(8, 64), "f16x3", "data") == "fused-registers"
+    assert lib.path_for(w(8, 64, 5), "f16x3", "plate") == "fused-registers"      # configs[2]
+    assert lib.path_for(w(8, 70, 5), "f16x3", "plate") == "fused-lds"            # PLATE:885
+    assert lib.path_for(w(8, 80), "f16x3", "wave") == "fused-lds"                # INF:645
+    assert lib.path_for(w(8, 100), "f16x3", "wave") == "fused-lds"               # SEMI:679
+    assert lib.path_for(w(6, 140), "f16x3", "wave") == "fused-lds"               # CONF:891
+    assert lib.path_for(w(10, 128, 12, 4), "f16x3", "nc3d") == "fused-lds"       # configs[4]
+    # depths / widths the fused kernel is not compiled for: they run, on the two-kernel path
+    for layers, head in ((w(5, 64), "wave"), (w(6, 64), "data"), (w(4, 80), "wave"), (w(8, 140), "wave"), (w(6, 140), "data"), (w(8, 100, 5), "plate"),
+                         (w(8, 128, 12, 4), "nc3d"), (w(10, 128, 12, 4), "nc3d_data"), (w(8, 64, 5), "streams"), (w(8, 80), "wave")):
+        mode = "bf16" if layers == w(8, 80) else "f16x3"       # (the LDS-operand layouts exist for the split modes only)
+        assert lib.path_for(layers, mode, head) == "two-kernel", (layers, head)
+    assert lib.path_for(w(8, 64), "fp32", "wave") == "fp32"
+    assert lib.path_for(w(8, 64), PREC["f16x3"] | FLAG_TWO_KERNEL, "wave") == "two-kernel"
+    # workspace: one that holds fewer than 64 scratch images -> two-kernel; the recommended size of a large set holds all 256
+    assert lib.path_for(w(8, 64), "f16x3", "wave", lib.min_workspace_bytes(w(8, 64), "f16x3") // 2) == "two-kernel"
+    assert lib.path_for(w(8, 64), "f16x3", "wave", lib.workspace_bytes(w(8, 64), 1 << 18, "f16x3")) == "fused-registers"
+    with pytest.raises(PinnLibError):
+        lib.path_for(w(8, 200), "f16x3", "wave")
+    with pytest.raises(PinnLibError):
+        lib.path_for(w(8, 64), "bf16", "plate")
+    assert lib.path_counts(reset=True).keys() == {"fused-registers", "fused-lds", "two-kernel", "fp32"}

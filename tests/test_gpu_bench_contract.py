@@ -38,6 +38,14 @@ def test_bench_line(cfg, extra):
     # the events runs after the timed ones -- the by-construction bound is the next line, this one allows that block 3 % of clock drift)
     assert r["avg_launch_ms"] > 0 and r["avg_launch_ms"] <= (1.0 if cfg == "wave" else 1.03) * d["ms_per_step"] and r["launches_timed"] >= 4
     assert r["avg_launch_ms"] <= r["timed_block_ms_per_step"]      # by construction: the launches are a part of that block's steps
+    # round 5: the line carries the clock the dominant kernel ran at (power-limited part: a line without it cannot tell a code change from a
+    # box), and for the wave step a decomposition that adds up -- events on every 8th step only, so the bracketed block is the timed loop
+    assert d["shader_clock_ghz"] is not None and 0.8 < d["shader_clock_ghz"] < 2.6, d["shader_clock_ghz"]
+    if cfg == "wave":
+        sd = r["step_decomposition_ms"]
+        assert sd["collocation_launch"] + sd["side_sets_launch"] <= 1.01 * d["ms_per_step"], (sd, d["ms_per_step"])
+        assert abs(sd["collocation_launch"] + sd["side_sets_launch"] + sd["rest_of_step"] - d["ms_per_step"]) < 1e-9
+        assert r["ring_every"] == 8 and d["allreduce_ms"] is None and d["rank_share"] is None
     if cfg == "nc3d":
         assert "fused_wave_kernel" in r["kernel"] and r["launches_per_step"] == 1 and "fused" in d["config"]["workload"]
     # at least one second of timed work whatever --steps is: the K-step block is repeated, the median block is reported
@@ -73,3 +81,13 @@ def test_bench_always_reduce_runs_the_collective_branch_on_one_gpu():
     d = run_bench(base + ["--always-reduce"], env={"HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_PORT": "29671"})
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["parallelism"] == "dp1"
     assert "always_reduce" in d["config"] and d["config"]["always_reduce"] is True
+    assert d["allreduce_ms"] is not None and 0.0 < d["allreduce_ms"] < 5.0 and "nccl" in d["allreduce_note"]      # events around the collective
+
+
+def test_bench_rank_share_runs_one_ranks_share_of_every_set():
+    """--rank-share 8: 1/8 of the collocation rows AND of the side sets (round 4 fed the whole side sets to the "one of 8 GPUs" figure)"""
+    d = run_bench(["--steps", "4", "--warmup", "1", "--ramp-steps", "2", "--global-points", "400000", "--rank-share", "8", "--always-reduce", "--no-cpu-baseline",
+                   "--extra-modes", "none", "--no-small-config"], env={"HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_PORT": "29673"})
+    assert d["rank_share"] == 8 and d["n_gpus"] == 1 and d["config"]["collocation_points_global"] == 400000
+    assert "50000 collocation pts per GPU" in d["config"]["workload"] and "IC 1275 + SRC 8800" in d["config"]["workload"]
+    assert abs(d["value"] - 50000 / (1e-3 * d["ms_per_step"])) < 1e-3 * d["value"] and d["allreduce_ms"] > 0
