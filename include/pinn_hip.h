@@ -231,6 +231,34 @@ int pinn_data_loss_grad_multi(const float* params_flat, const int* layers, int n
                               float* grad_flat_out, int accumulate,
                               int precision_mode, void* workspace, size_t ws_bytes, void* stream);
 
+/* One call per rank per training step (round 5): what the step of INF:282-319 evaluates -- net_f_sig on the collocation
+ * batch (pinn_wave2d_loss_grad's arguments), the value-only side sets (pinn_data_loss_grad_multi's), the gradient of their weighted sum
+ * and, with `adam`, the optimizer update of INF:131-133 -- as
+ *     weight repack | ONE persistent launch for all point sets | ONE reduction (+ Adam)
+ * for the nets whose calls take the register-state fused kernel (padded width <= 64, 4 or 8 hidden layers: pinn_path_for).  The side sets'
+ * workgroups are dispatched behind the collocation set's and start on the compute units that run out of collocation steps first, so a set of
+ * N points no longer leaves most of the chip idle during its last of ceil(N / 64 / 256) steps (the 250,000-point share of one of 8 GPUs: 67
+ * workgroups have a 16th step, 189 do not).  Every other case -- other widths / depths, PINN_PREC_FP32, no side points, an empty batch, a
+ * workspace without room for both parts' scratch images -- makes the three calls one after the other inside: the RESULTS are the same bits
+ * either way (same partial sums, same order of the final additions, same Adam expression).
+ *   adam == NULL: the gradient is left in grad_flat_out (data-parallel ranks all-reduce it, then call pinn_adam_step);
+ *   adam != NULL: params_flat, adam->m, adam->v are updated in place behind the reduction (and grad_flat_out still holds the gradient).
+ * n_sets may be 0.  Loss sums as in the two calls it replaces. */
+typedef struct {
+    float* m;                  /* first / second moment, length n_params, updated in place */
+    float* v;
+    double lr, beta1, beta2, eps;
+    int64_t step;              /* 1-based */
+} pinn_adam_state;
+int pinn_wave2d_step(float* params_flat, const int* layers, int n_layers,
+                     const float* x, const float* y, const float* t, int64_t n,
+                     const double lb[3], const double ub[3], int normalize,
+                     double E, double mu, double rho, int plane_strain,
+                     const float term_weights[7], float* loss_terms_out,
+                     const pinn_point_set* sets, int n_sets,
+                     float* grad_flat_out, int accumulate, const pinn_adam_state* adam,
+                     int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- 3-D Navier-Cauchy extension (BASELINE.json configs[4]).  NOT in the reference: all four reference scripts are 2-D + time
  * (SURVEY.md section 0), so these entry points have no reference lines to replace; they state the 3-D form of net_f_sig
  * (INF:221-265) the way oracle/nc3d_oracle.py spells it out, and parity for them is unpinned by definition.

@@ -38,6 +38,12 @@ class PointSet(C.Structure):
                 ("out_weights", C.c_float * 8), ("loss_terms_out", C.c_void_p)]
 
 
+class AdamState(C.Structure):
+    """pinn_adam_state of include/pinn_hip.h"""
+    _fields_ = [("m", C.c_void_p), ("v", C.c_void_p), ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("eps", C.c_double),
+                ("step", C.c_int64)]
+
+
 class PinnLibError(RuntimeError):
     pass
 
@@ -78,6 +84,9 @@ class PinnLib:
         L.pinn_data_loss_grad.restype = i32
         L.pinn_data_loss_grad_multi.argtypes = [vp, pi32, i32, C.POINTER(PointSet), i32, pf64, pf64, i32, vp, i32, i32, vp, sz, vp]
         L.pinn_data_loss_grad_multi.restype = i32
+        L.pinn_wave2d_step.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, f64, f64, f64, i32, pf32, vp, C.POINTER(PointSet), i32, vp, i32,
+                                       C.POINTER(AdamState), i32, vp, sz, vp]
+        L.pinn_wave2d_step.restype = i32
         L.pinn_wave2d_fields.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, i32, vp, sz, vp]
         L.pinn_wave2d_fields.restype = i32
         L.pinn_net_streams.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, i32, vp, sz, vp]
@@ -253,6 +262,22 @@ class PinnLib:
         rc = self.lib.pinn_data_loss_grad_multi(params, self._ints(layers), len(layers), arr, len(sets), self._d3(lb), self._d3(ub),
                                                 int(bool(normalize)), grad_out, int(bool(accumulate)), mode_bits(prec), ws, int(ws_bytes), stream)
         self.check(rc, "pinn_data_loss_grad_multi")
+
+    def wave2d_step(self, params, layers, x, y, t, n, lb, ub, normalize, E, mu, rho, plane_strain, term_weights, loss_out, sets, grad_out,
+                    accumulate, adam, prec, ws, ws_bytes, stream=0):
+        """pinn_wave2d_step.  sets: as data_loss_grad_multi; adam: None or (m, v, lr, beta1, beta2, eps, step)."""
+        arr = (PointSet * max(1, len(sets)))()
+        for k, (sx, sy, st, sn, tg, ow, lo) in enumerate(sets):
+            arr[k].x, arr[k].y, arr[k].t, arr[k].n, arr[k].targets, arr[k].loss_terms_out = sx or None, sy or None, st or None, int(sn), tg or None, lo
+            for i in range(8):
+                arr[k].out_weights[i] = float(ow[i]) if i < len(ow) else 0.0
+        ad = None
+        if adam is not None:
+            ad = AdamState(adam[0], adam[1], float(adam[2]), float(adam[3]), float(adam[4]), float(adam[5]), int(adam[6]))
+        rc = self.lib.pinn_wave2d_step(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub), int(bool(normalize)),
+                                       float(E), float(mu), float(rho), int(bool(plane_strain)), self._floats(term_weights, 7), loss_out, arr, len(sets),
+                                       grad_out, int(bool(accumulate)), C.byref(ad) if ad is not None else None, mode_bits(prec), ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_wave2d_step")
 
     def wave2d_fields(self, params, layers, x, y, t, n, lb, ub, normalize, fields_out, prec, ws, ws_bytes, stream=0):
         rc = self.lib.pinn_wave2d_fields(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),

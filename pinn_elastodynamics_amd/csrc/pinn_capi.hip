@@ -306,17 +306,8 @@ static int fp32_call(const Call& c, int head, int nterms, int ns, int din = 3) {
     return PINN_OK;
 }
 
-static int wave2d_loss_grad_impl(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
-                          int64_t n, const double lb[3], const double ub[3], int normalize, double E, double mu, double rho,
-                          int plane_strain, const float term_weights[7], float* loss_terms_out, float* grad_flat_out, int accumulate,
-                          int precision_mode, void* workspace, size_t ws_bytes, void* stream, float* prof_ms) {
-    Call c;
-    const Impl* impl = nullptr;
-    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
-    if (rc) return rc;
-    if (!term_weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
-    if (c.net.nout != 7) return PINN_ERR_LAYERS;
-    // Hooke coefficients: plane strain INF:238-241, plane stress PLATE:416-418
+// Hooke coefficients: plane strain INF:238-241, plane stress PLATE:416-418
+static void set_hooke(Call& c, double E, double mu, double rho, int plane_strain) {
     double c1, c2;
     if (plane_strain) {
         const double coef = E / ((1.0 + mu) * (1.0 - 2.0 * mu));
@@ -330,6 +321,19 @@ static int wave2d_loss_grad_impl(const float* params_flat, const int* layers, in
     c.c2 = (float)c2;
     c.G = (float)(E / (2.0 * (1.0 + mu)));
     c.rho = (float)rho;
+}
+
+static int wave2d_loss_grad_impl(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
+                          int64_t n, const double lb[3], const double ub[3], int normalize, double E, double mu, double rho,
+                          int plane_strain, const float term_weights[7], float* loss_terms_out, float* grad_flat_out, int accumulate,
+                          int precision_mode, void* workspace, size_t ws_bytes, void* stream, float* prof_ms) {
+    Call c;
+    const Impl* impl = nullptr;
+    int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+    if (rc) return rc;
+    if (!term_weights || !loss_terms_out || !grad_flat_out) return PINN_ERR_NULL;
+    if (c.net.nout != 7) return PINN_ERR_LAYERS;
+    set_hooke(c, E, mu, rho, plane_strain);
     for (int i = 0; i < 7; ++i) c.tw[i] = term_weights[i];
     c.loss_out = loss_terms_out;
     c.grad_out = grad_flat_out;
@@ -433,6 +437,82 @@ int pinn_data_loss_grad_multi(const float* params_flat, const int* layers, int n
         return PINN_OK;
     }
     return impl->data_loss_grad(c);
+}
+
+// lr_t of the TF1 rule (bias correction folded into the step size, computed in double)
+static float adam_lr_t(double lr, double beta1, double beta2, int64_t step) {
+    const double b1t = __builtin_pow(beta1, (double)step), b2t = __builtin_pow(beta2, (double)step);      // (pinn_adam_step's own expression: the same bits)
+    const double lr_t = lr * __builtin_sqrt(1.0 - b2t) / (1.0 - b1t);
+    return (float)lr_t;
+}
+
+int pinn_wave2d_step(float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t, int64_t n,
+                     const double lb[3], const double ub[3], int normalize, double E, double mu, double rho, int plane_strain,
+                     const float term_weights[7], float* loss_terms_out, const pinn_point_set* sets, int n_sets, float* grad_flat_out,
+                     int accumulate, const pinn_adam_state* adam, int precision_mode, void* workspace, size_t ws_bytes, void* stream) {
+    if (n_sets < 0 || n_sets > PINN_MAX_SETS) return PINN_ERR_SIZE;
+    if (n_sets > 0 && !sets) return PINN_ERR_NULL;
+    if (adam && (!adam->m || !adam->v || adam->step < 1)) return adam->step < 1 ? PINN_ERR_SIZE : PINN_ERR_NULL;
+    int64_t side_total = 0;
+    for (int k = 0; k < n_sets; ++k) {
+        if (sets[k].n < 0) return PINN_ERR_SIZE;
+        if (!sets[k].loss_terms_out || (sets[k].n > 0 && (!sets[k].x || !sets[k].y || !sets[k].t))) return PINN_ERR_NULL;
+        side_total += sets[k].n;
+    }
+    // ---- the one-launch form: collocation set and side sets through fused_step_kernel, one reduction (+ Adam) behind it
+    if (n > 0 && side_total > 0 && term_weights && loss_terms_out && grad_flat_out) {
+        Call c;
+        const Impl* impl = nullptr;
+        int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+        if (rc) return rc;
+        if (c.net.nout != 7) return PINN_ERR_LAYERS;
+        if (impl) {
+            set_hooke(c, E, mu, rho, plane_strain);
+            for (int i = 0; i < 7; ++i) c.tw[i] = term_weights[i];
+            c.loss_out = loss_terms_out;
+            c.grad_out = grad_flat_out;
+            c.accumulate = accumulate;
+            Call d = c;
+            for (int i = 0; i < 16; ++i) d.tw[i] = 0.0f;
+            d.loss_out = nullptr;
+            d.nsets = n_sets;
+            hipStream_t st = static_cast<hipStream_t>(stream);
+            for (int k = 0; k < n_sets; ++k) {
+                d.sets[k].x = sets[k].x;
+                d.sets[k].y = sets[k].y;
+                d.sets[k].t = sets[k].t;
+                d.sets[k].targets = sets[k].targets;
+                d.sets[k].n = (long)sets[k].n;
+                for (int i = 0; i < 8; ++i) d.sets[k].tw[i] = i < c.net.nout ? sets[k].out_weights[i] : 0.0f;
+                d.sets[k].loss_out = sets[k].loss_terms_out;
+            }
+            AdamEpilogue ep = {nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+            if (adam) ep = AdamEpilogue{params_flat, adam->m, adam->v, adam_lr_t(adam->lr, adam->beta1, adam->beta2, adam->step), (float)adam->beta1, (float)adam->beta2, (float)adam->eps};
+            if (impl->wave_step(c, d, ep, &rc)) {
+                if (rc) return rc;
+                for (int k = 0; k < n_sets; ++k)      // (empty sets report zeros, as in pinn_data_loss_grad_multi)
+                    if (sets[k].n == 0 && (rc = (int)hipMemsetAsync(sets[k].loss_terms_out, 0, (size_t)c.net.nout * sizeof(float), st))) return rc;
+                return PINN_OK;
+            }
+        }
+    }
+    // ---- every other case (other widths / depths, PINN_PREC_FP32, an empty set, a small workspace): the same results from the calls one by one
+    int rc = pinn_wave2d_loss_grad(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, E, mu, rho, plane_strain, term_weights, loss_terms_out,
+                                   grad_flat_out, accumulate, precision_mode, workspace, ws_bytes, stream);
+    if (rc) return rc;
+    if (n_sets > 0) {
+        const int packed = n > 0 ? PINN_FLAG_WEIGHTS_PACKED : 0;      // (an empty collocation batch packed nothing)
+        rc = pinn_data_loss_grad_multi(params_flat, layers, n_layers, sets, n_sets, lb, ub, normalize, grad_flat_out, 1, precision_mode | packed, workspace,
+                                       ws_bytes, stream);
+        if (rc) return rc;
+    }
+    if (adam) {
+        NetDesc net;
+        int width = 0;
+        if ((rc = decode_net(layers, n_layers, net, width, 3))) return rc;
+        return pinn_adam_step(params_flat, adam->m, adam->v, grad_flat_out, net.nparams, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step, stream);
+    }
+    return PINN_OK;
 }
 
 int pinn_wave2d_fields(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,

@@ -1276,6 +1276,91 @@ __global__ __launch_bounds__(256) void reduce_grad_loss_kernel(const float* part
     }
 }
 
+// Epilogue of fused_step_kernel (round 5): ONE launch reduces the per-workgroup partials of BOTH parts of the step launch -- A: the collocation
+// set (slot layout [wave][8]), B: the value-only side sets ([wave][FUSED_MAX_SETS][8]) -- in the order the two separate calls used to
+// (grad = scaleA * sumA, then += scaleB * sumB: the same bits), writes the 1 + nsets loss sums, and, if `adam.theta` is set, applies the TF1 Adam
+// rule of adam_tf1_kernel to the parameters in the same thread (pinn_wave2d_step with an optimizer state: a training step at world size 1 is
+// repack + step launch + this; with a collective in between the gradient is left in `grad` and pinn_adam_step follows the all-reduce).
+struct AdamEpilogue {
+    float* theta;              // nullptr: no optimizer step
+    float* m;
+    float* v;
+    float lr_t, beta1, beta2, eps;
+};
+struct StepPart {
+    const float* partial;      // [nchunks][nparams]
+    int nchunks;
+    float scale;
+    const float* loss_part;
+    long nwaves;
+};
+template <int UNUSED = 0>
+__global__ __launch_bounds__(256) void reduce_step_kernel(StepPart A, StepPart B, int nparams, float* grad, int accumulate, int nterms_a, float* loss_a,
+                                                          int nterms_b, int nsets, int slots_b, LossOuts loss_b, AdamEpilogue adam, const int* wflags,
+                                                          int nflags) {
+    __shared__ int bad_weights;
+    if (threadIdx.x == 0) bad_weights = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nflags; i += 256)
+        if (wflags[i]) bad_weights = 1;
+    __syncthreads();
+    const float poison = bad_weights ? __builtin_nanf("") : 0.0f;
+    const int grad_blocks = (int)gridDim.x - nsets - 1;
+    if ((int)blockIdx.x >= grad_blocks) {
+        const int k = (int)blockIdx.x - grad_blocks - 1;          // -1: the collocation set, 0..nsets-1: the side sets
+        const float* lp = k < 0 ? A.loss_part : B.loss_part;
+        const long nw = k < 0 ? A.nwaves : B.nwaves;
+        const int slots = k < 0 ? 1 : slots_b, slot = k < 0 ? 0 : k, nterms = k < 0 ? nterms_a : nterms_b;
+        float* out = k < 0 ? loss_a : loss_b.p[k];
+        const int term = threadIdx.x >> 5, sub = threadIdx.x & 31;
+        double s = 0.0;
+        if (term < nterms)
+            for (long w = sub; w < nw; w += 32) s += (double)lp[(w * slots + slot) * 8 + term];
+        float v = (float)s;
+        v += __shfl_xor(v, 1);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 8);
+        v += __shfl_xor(v, 16);
+        if (sub == 0 && term < nterms && out != nullptr) out[term] = v + poison;
+        return;
+    }
+    __shared__ float sub[2][4][64];
+    const int pl = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const long p = (long)blockIdx.x * 64 + pl;
+#pragma unroll
+    for (int part = 0; part < 2; ++part) {
+        const StepPart& P = part ? B : A;
+        float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+        if (p < nparams) {
+            int cidx = sl;
+            for (; cidx + 12 < P.nchunks; cidx += 16) {
+                s0 += P.partial[(long)cidx * nparams + p];
+                s1 += P.partial[(long)(cidx + 4) * nparams + p];
+                s2 += P.partial[(long)(cidx + 8) * nparams + p];
+                s3 += P.partial[(long)(cidx + 12) * nparams + p];
+            }
+            for (; cidx < P.nchunks; cidx += 4) s0 += P.partial[(long)cidx * nparams + p];
+        }
+        sub[part][sl][pl] = (s0 + s1) + (s2 + s3);
+    }
+    __syncthreads();
+    if (sl == 0 && p < nparams) {
+        const float sa = (sub[0][0][pl] + sub[0][1][pl]) + (sub[0][2][pl] + sub[0][3][pl]);
+        const float sb = (sub[1][0][pl] + sub[1][1][pl]) + (sub[1][2][pl] + sub[1][3][pl]);
+        float g = (accumulate ? grad[p] : 0.0f) + A.scale * sa + poison;      // what the collocation call's reduction wrote ...
+        g = g + B.scale * sb + poison;                                         // ... and the side-set call's added
+        grad[p] = g;
+        if (adam.theta != nullptr) {
+            const float mi = adam.beta1 * adam.m[p] + (1.0f - adam.beta1) * g;
+            const float vi = adam.beta2 * adam.v[p] + (1.0f - adam.beta2) * g * g;
+            adam.m[p] = mi;
+            adam.v[p] = vi;
+            adam.theta[p] -= adam.lr_t * mi / (__builtin_amdgcn_sqrtf(vi) + adam.eps);
+        }
+    }
+}
+
 // loss_terms[i] (+)= sum over waves of loss_part[w][i]   (one block of 256 threads: 32 lanes per term and pass, `slots` partial
 // slots per wave: 8, or LOSS_SLOTS_3D for the 3-D heads; nterms <= slots)
 template <int UNUSED = 0>

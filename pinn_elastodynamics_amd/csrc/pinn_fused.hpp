@@ -78,7 +78,12 @@ struct FusedArgs {
     float* partial;            // [gridDim.x][nparams]
     u32x4* wg_acc;             // [gridDim.x * 4 waves][WG_ACC_BYTES]: weight-gradient accumulators kept in memory (see Fused::NG)
     unsigned long long* dbg;   // optional phase timestamps (s_memtime) of workgroup 0, chain wave 0 / weight-gradient wave 0; nullptr = off
+    // The persistent grid this launch part runs on: workgroups block0 .. block0 + grid - 1 of the launch (a plain launch: 0 and the launch's
+    // grid).  fused_step_kernel (round 5) runs the collocation set AND the value-only side sets of a training step in ONE launch -- the side
+    // sets' workgroups are the blocks behind the collocation set's and start on the compute units that run out of collocation steps first.
+    int block0, grid;
 };
+__device__ __forceinline__ int fused_bid(const FusedArgs& a) { return (int)blockIdx.x - a.block0; }
 
 // A launch constant, made opaque at its point of use inside the step loop.  Otherwise the compiler hoists whatever is computed from
 // such constants alone (2 * term weight, the packed tangent seeds of the input state ...) out of the loop into registers it then has
@@ -1070,7 +1075,7 @@ struct Fused {
         }
         // this wave feeds chain tile `quad` (if there is one: LDSOP has two tiles): descriptor of that tile's scratch image
         const int ftile = LDSOP ? (quad & 1) : quad;
-        const long gtile = (long)blockIdx.x * TILES + ftile;
+        const long gtile = (long)fused_bid(a) * TILES + ftile;
         DmaSrc scr;
         scr.init(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES, SCRATCH_BYTES);
         const unsigned lane16 = (unsigned)lane * 16u;
@@ -1079,7 +1084,7 @@ struct Fused {
             __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gtile * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES, 0x00020000);
         // this wave's in-memory accumulator records, zeroed here (same-wave program order makes the first loads see the zeros)
         const __amdgpu_buffer_rsrc_t accr = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(reinterpret_cast<char*>(a.wg_acc) + ((long)blockIdx.x * 4 + quad) * (long)WG_ACC_BYTES), 0, (int)WG_ACC_BYTES, 0x00020000);
+            (void*)(reinterpret_cast<char*>(a.wg_acc) + ((long)fused_bid(a) * 4 + quad) * (long)WG_ACC_BYTES), 0, (int)WG_ACC_BYTES, 0x00020000);
         if constexpr (NG > 0) {
 #pragma unroll
             for (int r = 0; r < NG * NSUM; ++r) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, accr, lane16, r * 1024, 0);
@@ -1097,7 +1102,7 @@ struct Fused {
             xs1.c = c;
             xs1.q = q;
         }
-        for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
+        for (long step = fused_bid(a); step < a.nsteps; step += a.grid) {
             if constexpr (S1_WG_ANY) {                    // the tile's inputs: requested here, used a forward and six reverse layers later
                 bool valid;
                 long pidx;
@@ -1113,12 +1118,12 @@ struct Fused {
                     if (l + 1 <= NL - 1 && !kept_in_lds(l + 1)) park_image(scr_st, lane16, tile_lds, l + 1, quad);
                 }
             }
-            WgDown<NL>::run(a, blockIdx.x == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)gridDim.x, w, scr, accr, lane16, tile_lds, A, quad, pend, ld, sj);
+            WgDown<NL>::run(a, fused_bid(a) == 0 && quad == 0 && c == 0 && q == 0 && step == 2 * (long)a.grid, w, scr, accr, lane16, tile_lds, A, quad, pend, ld, sj);
         }
         // ---- write this workgroup's partial gradient
         // (kept in the body of the role: as a separate function taking the accumulators by reference the same statements cost the
         // default kernel 17 more spilled registers and 6 % of its time)
-        float* part = a.partial + (long)blockIdx.x * a.net.nparams;
+        float* part = a.partial + (long)fused_bid(a) * a.net.nparams;
         const int H = a.net.h, NO = a.net.nout, wi = quad >> 1, wo = quad & 1;
         auto put_block = [&](const f32x4& v, int l, int ib, int ob, int n_in, int n_out) {
 #pragma unroll
@@ -2428,11 +2433,11 @@ struct Fused {
     static __device__ __forceinline__ void chain_role(const FusedArgs& a, char* lds, int wave4, int lane, int c, int q) {
         // LDSOP: two waves per tile (tile = wave & 1, half = wave >> 1); otherwise one wave per tile
         const int wave = LDSOP ? (wave4 & 1) : wave4, half = LDSOP ? (wave4 >> 1) : 0;
-        const long gwave = (long)blockIdx.x * TILES + wave;
+        const long gwave = (long)fused_bid(a) * TILES + wave;
         Ctx x;
         x.init(a, lds, wave, lane, c, q);
         x.set_tile(a, gwave);
-        x.tracer = blockIdx.x == 0 && wave4 == 0 && lane == 0;
+        x.tracer = fused_bid(a) == 0 && wave4 == 0 && lane == 0;
         constexpr int NSETS = NS == 1 ? FUSED_MAX_SETS : 1;
         float lsum[NSETS][LT];
 #pragma unroll
@@ -2451,7 +2456,7 @@ struct Fused {
         // its clock cannot tell a code change from a box)
         const bool launch_tracer = x.tracer;
         fused_stamp(a, launch_tracer, NS == 1 ? 122 : 124);
-        for (long step = blockIdx.x; step < a.nsteps; step += gridDim.x) {
+        for (long step = fused_bid(a); step < a.nsteps; step += a.grid) {
             float xin[4];
             bool valid;
             long pidx;
@@ -2464,7 +2469,7 @@ struct Fused {
             } else {
                 load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + wave, c, xin, valid, pidx);
             }
-            x.tracer = blockIdx.x == 0 && wave4 == 0 && lane == 0 && step == 2 * (long)gridDim.x;      // a steady-state step
+            x.tracer = fused_bid(a) == 0 && wave4 == 0 && lane == 0 && step == 2 * (long)a.grid;      // a steady-state step
             if constexpr (LDSOP) {                 // lane addresses derived from these are then formed where they are used, not hoisted and spilled
                 x.imgoff = in_loop(x.imgoff);
                 x.lane16 = in_loop(x.lane16);
@@ -2528,8 +2533,7 @@ struct Fused {
             }
     }
 
-    static __device__ __forceinline__ void run(const FusedArgs& a) {
-        __shared__ __attribute__((aligned(16))) char lds[LDS_B];
+    static __device__ __forceinline__ void run(const FusedArgs& a, char* lds /* LDS_B bytes, 16-byte aligned: declared by the kernel */) {
         const int lane = threadIdx.x & 63, c = lane & 15, q = lane >> 4;
         const int wave8 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // provably wave-uniform
         if constexpr (CONST_LDS) {
@@ -2554,7 +2558,24 @@ struct Fused {
 
 template <class Op, int SPLIT, int WIDTH, int NL, int NS, bool FASTSTATE, int DIN = 3>
 __global__ __launch_bounds__(512) void fused_wave_kernel(const FusedArgs a) {
-    Fused<Op, SPLIT, WIDTH, NL, NS, FASTSTATE, DIN>::run(a);
+    typedef Fused<Op, SPLIT, WIDTH, NL, NS, FASTSTATE, DIN> F;
+    __shared__ __attribute__((aligned(16))) char lds[F::LDS_B];
+    F::run(a, lds);
+}
+
+// One training step's point sets in ONE persistent launch (round 5): workgroups [0, a4.grid) run the collocation set (four streams, the
+// residual head), workgroups [a4.grid, a4.grid + a1.grid) the value-only side sets (one stream: loss_IC / loss_SRC / loss_NB / loss_FIX,
+// INF:111-118).  Both parts are the roles of fused_wave_kernel, unchanged; they share nothing but the launch.  What it buys: the side sets'
+// workgroups are dispatched as compute units run out of collocation steps -- a collocation set of N points is ceil(N / 64) steps over 256
+// workgroups, so in its last step most compute units idle (250,000 points, one of 8 GPUs' share of BASELINE's 2 M: 67 workgroups have a
+// 16th step, 189 do not) -- instead of waiting, as a second launch, for the whole first one; and a step is one launch less.
+template <class Op, int SPLIT, int WIDTH, int NL, bool FASTSTATE>
+__global__ __launch_bounds__(512) void fused_step_kernel(const FusedArgs a4, const FusedArgs a1) {
+    typedef Fused<Op, SPLIT, WIDTH, NL, 4, FASTSTATE, 3> F4;
+    typedef Fused<Op, SPLIT, WIDTH, NL, 1, false, 3> F1;
+    __shared__ __attribute__((aligned(16))) char lds[F4::LDS_B > F1::LDS_B ? F4::LDS_B : F1::LDS_B];
+    if ((int)blockIdx.x < a4.grid) F4::run(a4, lds);
+    else F1::run(a1, lds);
 }
 
 }  // namespace pinn

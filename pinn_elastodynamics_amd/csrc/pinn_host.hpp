@@ -90,6 +90,7 @@ extern long g_path_counts[5];
 
 struct Impl {
     int (*path_for)(const NetDesc&, int head, size_t ws_bytes);
+    int (*wave_step)(const Call&, const Call&, const AdamEpilogue&, int* rc);      // 1: ran (narrow fused layouts), 0: make the calls one by one
     int (*wave_loss_grad)(const Call&);
     int (*data_loss_grad)(const Call&);
     int (*fields)(const Call&);
@@ -139,6 +140,8 @@ struct Host {
     static constexpr int FUSED_MAX_WIDTH = 160;     // widest padded net the fused kernel takes (160: 4 streams, 6 layers = CONF:891; 128: 4 and 1 streams (+ the 3-D head); 96 also 5 streams)
     static constexpr size_t FUSED_ACC_W64 = 32 * 1024;
     static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? FUSED_ACC_W64 : (WIDTH <= 96 ? 72 * 1024 : 160 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
+    // fused_step_kernel (collocation set + side sets of a training step in one launch): the narrow layouts
+    static constexpr bool step_has() { return WIDTH <= 64; }
     template <int NS>
     static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5 || NS == 1)) || (WIDTH <= 128 && (NS == 4 || NS == 1)) || (WIDTH == 160 && NS == 4))); }
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
@@ -148,6 +151,7 @@ struct Host {
 
     struct Plan {
         size_t w0p, bias_mid, bias_last, wflags, frags, frags_fused, loss_part, partial, wg_acc, panels, fixed_end;
+        size_t loss_part_b, partial_b, wg_acc_b;      // fused_step_kernel: the side-set part's own partial sums (narrow nets only)
         long s_tile, z_tile;     // 16-bit elements per tile
         long ntiles;             // total tiles of the call (even)
         long chunk_tiles;        // tiles per workspace pass (even)
@@ -176,6 +180,15 @@ struct Host {
         o = align_up(o + (size_t)(NCHUNK > FUSED_GRID ? NCHUNK : FUSED_GRID) * net.nparams * sizeof(float), 256);
         p.wg_acc = o;           // fused kernel: weight-gradient accumulator blocks kept in memory (<= 2 layers x 4 blocks x 1 KB per wave)
         if (WIDTH <= FUSED_MAX_WIDTH) o = align_up(o + (size_t)FUSED_GRID * 4 * FUSED_ACC_BYTES, 256);
+        p.loss_part_b = p.partial_b = p.wg_acc_b = o;
+        if (step_has()) {
+            p.loss_part_b = o;
+            o = align_up(o + (size_t)FUSED_GRID * 4 * FUSED_MAX_SETS * 8 * sizeof(float), 256);
+            p.partial_b = o;
+            o = align_up(o + (size_t)FUSED_GRID * net.nparams * sizeof(float), 256);
+            p.wg_acc_b = o;
+            o = align_up(o + (size_t)FUSED_GRID * 4 * FUSED_ACC_BYTES, 256);
+        }
         p.panels = o;
         p.fixed_end = o;
         p.s_tile = PG::s_tile(net.nl);
@@ -382,6 +395,84 @@ struct Host {
 
     // the 3-D instantiation (4 inputs, five first-order streams, 10 x 128: BASELINE configs[4]) exists for the split-precision width-128 family
     static constexpr bool fused_has_3d() { return SPLIT == 3 && WIDTH == 128; }
+    // Arguments of one part of a fused launch: `area` 0 = the call's own per-workgroup areas, 1 = the second set (the side-set part of
+    // fused_step_kernel); `scratch_off` = byte offset of this part's scratch images behind p.panels; `block0` = its first workgroup.
+    struct FusedSetup {
+        FusedArgs a;
+        float twmax;
+        LossOuts lo;
+        int nsets;
+    };
+    template <int NL, int NS, bool FS = false, int DIN = 3>
+    static void fused_setup(const Call& c, const Plan& p, int grid, long nsteps, int area, size_t scratch_off, int block0, FusedSetup& su) {
+        typedef Fused<Op, SPLIT, WIDTH, NL, NS, FS, DIN> F;
+        char* b = static_cast<char*>(c.ws);
+        FusedArgs& a = su.a;
+        a.net = c.net;
+        a.pw = packed(c, p);
+        a.pw.frags = reinterpret_cast<const u32x4*>(b + p.frags_fused);
+        a.frags_bytes = (unsigned)((size_t)FI::total(c.net.nl) * FUSED_PARTS * 64 * sizeof(u32x4));
+        a.x = c.x;
+        a.y = c.y;
+        a.t = c.t;
+        a.z = c.z;
+        a.n = c.n;
+        a.nsteps = nsteps;
+        for (int k = 0; k < 4; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
+        a.c1 = c.c1;
+        a.c2 = c.c2;
+        a.G = c.G;
+        a.rho = c.rho;
+        a.targets = nullptr;
+        a.aux = c.aux;
+        float twmax = 0.0f;
+        LossOuts lo = {{nullptr, nullptr, nullptr, nullptr}};
+        int nsets = 1;
+        if constexpr (NS == 1) {
+            DataSet sets[4];
+            nsets = data_sets(c, sets);
+            for (int k = 0; k < nsets; ++k)
+                for (int i = 0; i < 8; ++i) { const float v = sets[k].tw[i] < 0 ? -sets[k].tw[i] : sets[k].tw[i]; if (v > twmax) twmax = v; }
+            twmax *= (float)(1u << c.adj_shift);
+            if constexpr (F::WG_HI) twmax *= 1.0f / F::ZDB_SEED_SCALE;
+            long s0 = 0;
+            for (int k = 0; k < 4; ++k) {
+                const bool on = k < nsets;
+                a.set_step0[k] = s0;
+                a.set_x[k] = on ? sets[k].x : nullptr;
+                a.set_y[k] = on ? sets[k].y : nullptr;
+                a.set_t[k] = on ? sets[k].t : nullptr;
+                a.set_targets[k] = on ? sets[k].targets : nullptr;
+                a.set_n[k] = on ? sets[k].n : 0;
+                a.set_head[k] = on ? sets[k].head : 0;
+                a.set_aux[k] = on ? sets[k].aux : nullptr;
+                for (int i = 0; i < 8; ++i) a.set_tw[k][i] = on && twmax > 0.0f ? sets[k].tw[i] / twmax : 0.0f;
+                if (on) { s0 += (sets[k].n + 16 * F::TILES - 1) / (16 * F::TILES); lo.p[k] = sets[k].loss_out; }
+            }
+            a.set_step0[4] = s0;
+            a.nsets = nsets;
+            for (int i = 0; i < 16; ++i) a.tw[i] = 0.0f;
+        } else {
+            for (int i = 0; i < 16; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
+            twmax *= (float)(1u << c.adj_shift);
+            if constexpr (F::WG_HI) twmax *= 1.0f / F::ZDB_SEED_SCALE;      // adjoint seeds x 16: the weight gradient's fp16 adjoints in the normal range (Fused::ZDB)
+            for (int i = 0; i < 16; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
+            a.nsets = 1;
+            lo.p[0] = c.loss_out;
+        }
+        a.scratch = reinterpret_cast<u32x4*>(b + p.panels + scratch_off);
+        a.loss_part = reinterpret_cast<float*>(b + (area ? p.loss_part_b : p.loss_part));
+        a.partial = reinterpret_cast<float*>(b + (area ? p.partial_b : p.partial));
+        a.wg_acc = reinterpret_cast<u32x4*>(b + (area ? p.wg_acc_b : p.wg_acc));
+        static_assert(F::WG_ACC_BYTES <= FUSED_ACC_BYTES, "accumulator area of the plan");
+        a.dbg = c.dbg_stamps;
+        a.block0 = block0;
+        a.grid = grid;
+        su.twmax = twmax;
+        su.lo = lo;
+        su.nsets = nsets;
+    }
+
     template <int NL, int NS, bool FS = false, int DIN = 3>
     static int fused_launch(const Call& c, const Plan& p, int grid, int nterms, long nsteps) {
         if constexpr (DIN == 4 ? fused_has_3d() : fused_has<NS>()) {
@@ -389,65 +480,12 @@ struct Host {
             int rc = repack(c, p);
             if (rc) return rc;
             char* b = static_cast<char*>(c.ws);
-            FusedArgs a;
-            a.net = c.net;
-            a.pw = packed(c, p);
-            a.pw.frags = reinterpret_cast<const u32x4*>(b + p.frags_fused);
-            a.frags_bytes = (unsigned)((size_t)FI::total(c.net.nl) * FUSED_PARTS * 64 * sizeof(u32x4));
-            a.x = c.x;
-            a.y = c.y;
-            a.t = c.t;
-            a.z = c.z;
-            a.n = c.n;
-            a.nsteps = nsteps;
-            for (int k = 0; k < 4; ++k) { a.sx[k] = c.sx[k]; a.ox[k] = c.ox[k]; }
-            a.c1 = c.c1;
-            a.c2 = c.c2;
-            a.G = c.G;
-            a.rho = c.rho;
-            a.targets = nullptr;
-            a.aux = c.aux;
-            float twmax = 0.0f;
-            LossOuts lo = {{nullptr, nullptr, nullptr, nullptr}};
-            int nsets = 1;
-            if constexpr (NS == 1) {
-                DataSet sets[4];
-                nsets = data_sets(c, sets);
-                for (int k = 0; k < nsets; ++k)
-                    for (int i = 0; i < 8; ++i) { const float v = sets[k].tw[i] < 0 ? -sets[k].tw[i] : sets[k].tw[i]; if (v > twmax) twmax = v; }
-                twmax *= (float)(1u << c.adj_shift);
-                if constexpr (F::WG_HI) twmax *= 1.0f / F::ZDB_SEED_SCALE;
-                long s0 = 0;
-                for (int k = 0; k < 4; ++k) {
-                    const bool on = k < nsets;
-                    a.set_step0[k] = s0;
-                    a.set_x[k] = on ? sets[k].x : nullptr;
-                    a.set_y[k] = on ? sets[k].y : nullptr;
-                    a.set_t[k] = on ? sets[k].t : nullptr;
-                    a.set_targets[k] = on ? sets[k].targets : nullptr;
-                    a.set_n[k] = on ? sets[k].n : 0;
-                    a.set_head[k] = on ? sets[k].head : 0;
-                    a.set_aux[k] = on ? sets[k].aux : nullptr;
-                    for (int i = 0; i < 8; ++i) a.set_tw[k][i] = on && twmax > 0.0f ? sets[k].tw[i] / twmax : 0.0f;
-                    if (on) { s0 += (sets[k].n + 16 * F::TILES - 1) / (16 * F::TILES); lo.p[k] = sets[k].loss_out; }
-                }
-                a.set_step0[4] = s0;
-                a.nsets = nsets;
-                for (int i = 0; i < 16; ++i) a.tw[i] = 0.0f;
-            } else {
-                for (int i = 0; i < 16; ++i) { const float v = c.tw[i] < 0 ? -c.tw[i] : c.tw[i]; if (v > twmax) twmax = v; }
-                twmax *= (float)(1u << c.adj_shift);
-                if constexpr (F::WG_HI) twmax *= 1.0f / F::ZDB_SEED_SCALE;      // adjoint seeds x 16: the weight gradient's fp16 adjoints in the normal range (Fused::ZDB)
-                for (int i = 0; i < 16; ++i) a.tw[i] = twmax > 0.0f ? c.tw[i] / twmax : 0.0f;
-                a.nsets = 1;
-                lo.p[0] = c.loss_out;
-            }
-            a.scratch = reinterpret_cast<u32x4*>(b + p.panels);
-            a.loss_part = reinterpret_cast<float*>(b + p.loss_part);
-            a.partial = reinterpret_cast<float*>(b + p.partial);
-            a.wg_acc = reinterpret_cast<u32x4*>(b + p.wg_acc);
-            static_assert(F::WG_ACC_BYTES <= FUSED_ACC_BYTES, "accumulator area of the plan");
-            a.dbg = c.dbg_stamps;
+            FusedSetup su;
+            fused_setup<NL, NS, FS, DIN>(c, p, grid, nsteps, 0, 0, 0, su);
+            const FusedArgs& a = su.a;
+            const float twmax = su.twmax;
+            const LossOuts lo = su.lo;
+            const int nsets = su.nsets;
             EventPair evp(c.prof_ms != nullptr);
             hipEvent_t (&ev)[2] = evp.ev;
             if (c.prof_ms) hipEventRecord(ev[0], c.stream);
@@ -478,6 +516,58 @@ struct Host {
             return (int)hipGetLastError();
         } else {
             return PINN_ERR_LAYERS;
+        }
+    }
+
+    // One training step's sets in one launch + one reduction (+ Adam): fused_step_kernel, reduce_step_kernel.  c = the collocation call
+    // (pinn_wave2d_loss_grad's arguments), d = the side sets (pinn_data_loss_grad_multi's; d.nsets > 0).  Returns 1 if it ran (rc in *out), 0 if
+    // this net / workspace / set sizes do not take it -- the caller then makes the two calls (+ pinn_adam_step) one after the other: same bits.
+    template <int NL, bool FS>
+    static int step_launch(const Call& c, const Call& d, const AdamEpilogue& adam, const Plan& p, int grid4, long nsteps4, int grid1, long nsteps1, size_t off1) {
+        typedef Fused<Op, SPLIT, WIDTH, NL, 4, FS, 3> F4;
+        typedef Fused<Op, SPLIT, WIDTH, NL, 1, false, 3> F1;
+        int rc = repack(c, p);
+        if (rc) return rc;
+        char* b = static_cast<char*>(c.ws);
+        FusedSetup s4, s1;
+        fused_setup<NL, 4, FS, 3>(c, p, grid4, nsteps4, 0, 0, 0, s4);
+        fused_setup<NL, 1, false, 3>(d, p, grid1, nsteps1, 1, off1, grid4, s1);
+        const int ring_slot = c.ring ? c.ring->begin(c.stream, 4) : -1;
+        hipLaunchKernelGGL((fused_step_kernel<Op, SPLIT, WIDTH, NL, FS>), dim3(grid4 + grid1), dim3(512), 0, c.stream, s4.a, s1.a);
+        if (c.ring) c.ring->end(ring_slot, c.stream);
+        if ((rc = (int)hipGetLastError())) return rc;
+        StepPart A = {(const float*)s4.a.partial, grid4, s4.twmax, (const float*)s4.a.loss_part, (long)grid4 * F4::TILES};
+        StepPart B = {(const float*)s1.a.partial, grid1, s1.twmax, (const float*)s1.a.loss_part, (long)grid1 * F1::TILES};
+        hipLaunchKernelGGL((reduce_step_kernel<0>), dim3((c.net.nparams + 63) / 64 + s1.nsets + 1), dim3(256), 0, c.stream, A, B, c.net.nparams, c.grad_out,
+                           c.accumulate, 7, c.loss_out, c.net.nout, s1.nsets, (int)FUSED_MAX_SETS, s1.lo, adam, (const int*)(b + p.wflags),
+                           SPLIT == 3 ? repack_blocks(c.net) : 0);
+        return (int)hipGetLastError();
+    }
+    static int wave_step(const Call& c, const Call& d, const AdamEpilogue& adam, int* out) {
+        if constexpr (step_has()) {
+            if (!c.use_fused || c.prof_ms != nullptr || !fused_depth<4>(c.net) || !fused_depth<1>(c.net)) return 0;
+            if (((uintptr_t)c.ws & 255) != 0 || c.n <= 0) return 0;
+            Plan p;
+            plan_fixed<4>(c.net, c.n, p);
+            constexpr int T4 = Fused<Op, SPLIT, WIDTH, 4, 4>::TILES, T1 = Fused<Op, SPLIT, WIDTH, 4, 1>::TILES;
+            const size_t per4 = (size_t)T4 * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, 4>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, 4>::SCRATCH_BYTES);
+            const size_t per1 = (size_t)T1 * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, 1>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, 1>::SCRATCH_BYTES);
+            const long nsteps4 = (c.n + 16 * T4 - 1) / (16 * T4);
+            long nsteps1 = 0;
+            DataSet sets[4];
+            const int m = data_sets(d, sets);
+            for (int k = 0; k < m; ++k) nsteps1 += (sets[k].n + 16 * T1 - 1) / (16 * T1);
+            if (nsteps1 == 0) return 0;
+            const long grid4 = nsteps4 < FUSED_GRID ? nsteps4 : FUSED_GRID, grid1 = nsteps1 < FUSED_GRID ? nsteps1 : FUSED_GRID;
+            const size_t off1 = align_up((size_t)grid4 * per4, 256);
+            if (c.ws_bytes < p.fixed_end + off1 + (size_t)grid1 * per1) return 0;      // (the two calls then size their grids to the workspace one by one)
+            if (c.fast_state && SPLIT == 3 && c.net.nl == 8) *out = step_launch<8, true>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1);
+            else *out = c.net.nl == 4 ? step_launch<4, false>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1)
+                                      : step_launch<8, false>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1);
+            g_path_counts[PINN_PATH_FUSED_REGISTERS] += 2;      // (both families of the step)
+            return 1;
+        } else {
+            return 0;
         }
     }
 
@@ -690,7 +780,7 @@ struct Host {
     }
 
     static const Impl* impl() {
-        static const Impl I = {&path_for, &wave_loss_grad, &data_loss_grad, &fields, &ws_bytes,
+        static const Impl I = {&path_for, &wave_step, &wave_loss_grad, &data_loss_grad, &fields, &ws_bytes,
                                &plate_loss_grad, &traction_loss_grad, &stream_loss_grad, &streams,
                                &nc3d_loss_grad, &nc3d_data_loss_grad, &nc3d_fields};
         return &I;

@@ -370,10 +370,13 @@ class DeepHPM(NetApi):
         """this rank's rows of the whole collocation set"""
         return self._rows(0, self._n_collo)
 
-    def _loss_and_grad(self, idx_start, idx_end, sums_out=None):
+    def _loss_and_grad(self, idx_start, idx_end, sums_out=None, adam=None):
         """Fills self._buf = [grad (P) | 8 floats per slot] with this rank's partial sums, then
-        all-reduces.  Returns nothing; everything stays on the device.  Single process only: ``sums_out`` (a view of
-        8*len(_SLOTS) floats, zero where no set exists) receives the sums directly instead of the tail of the buffer."""
+        all-reduces.  Everything stays on the device.  Single process only: ``sums_out`` (a view of
+        8*len(_SLOTS) floats, zero where no set exists) receives the sums directly instead of the tail of the buffer.
+        ``adam = (learning_rate, step)``: the caller wants the Adam update behind this gradient; where the whole evaluation is ONE library call
+        (engine.wave_step: collocation set + side sets in one launch, one reduction) and no collective stands in between, the update rides in
+        that reduction -- returns True then (the caller skips its own adam_step), False otherwise."""
         P, lay, eng, buf = self.n_params, self.layout, self.engine, self._buf
         n_blk = idx_end - idx_start
         s, e = self._shard(idx_start, idx_end)
@@ -402,12 +405,6 @@ class DeepHPM(NetApi):
             sums = sums_out
         grad = buf[:P]
         tw = [lay["f_uv"] / n_blk] * 4 + [lay["f_s"] / n_blk] * 3
-        wrote = False
-        if e > s:
-            x, y, t = self._rows(idx_start, idx_end)
-            eng.wave_loss_grad(self.theta, x, y, t, self.lb, self.ub, self.normalize, tw, self.E, self.mu, self.rho, True,
-                               grad_out=grad, accumulate=False, loss_out=sums[0:8])
-            wrote = True
         side = []
         for k, name in enumerate(_SLOTS[1:], start=1):
             if name not in self._sides or lay[name] == 0.0:
@@ -419,15 +416,31 @@ class DeepHPM(NetApi):
             for o in cols:
                 ow[o] = lay[name] / n
             side.append((x, y, t, tg, ow, sums[8 * k:8 * k + 8]))
-        for i in range(0, len(side), 4):           # all value-only sets of the step in one call (up to PINN_MAX_SETS per call)
-            eng.data_loss_grad_multi(self.theta, side[i:i + 4], self.lb, self.ub, self.normalize, grad_out=grad, accumulate=wrote, packed=wrote)
-            wrote = True
-        if not wrote:
-            grad.zero_()
+        stepped = False
+        if e > s and 1 <= len(side) <= 4 and hasattr(eng, "wave_step"):
+            # the whole evaluation as ONE library call: repack | one persistent launch for all sets | one reduction (+ Adam)
+            x, y, t = self._rows(idx_start, idx_end)
+            fold = adam is not None and not self._reduce
+            eng.wave_step(self.theta, x, y, t, self.lb, self.ub, self.normalize, tw, side, grad, sums[0:8], self.E, self.mu, self.rho, True,
+                          adam=(self.adam_m, self.adam_v, adam[0], adam[1]) if fold else None)
+            stepped = fold
+        else:
+            wrote = False
+            if e > s:
+                x, y, t = self._rows(idx_start, idx_end)
+                eng.wave_loss_grad(self.theta, x, y, t, self.lb, self.ub, self.normalize, tw, self.E, self.mu, self.rho, True,
+                                   grad_out=grad, accumulate=False, loss_out=sums[0:8])
+                wrote = True
+            for i in range(0, len(side), 4):           # all value-only sets of the step in one call (up to PINN_MAX_SETS per call)
+                eng.data_loss_grad_multi(self.theta, side[i:i + 4], self.lb, self.ub, self.normalize, grad_out=grad, accumulate=wrote, packed=wrote)
+                wrote = True
+            if not wrote:
+                grad.zero_()
         if self._reduce:
             # one fused buffer [gradient | loss sums] (latency-bound message); enqueued behind the kernels in stream order, and Adam is
             # enqueued behind it: the host never waits
             all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None))
+        return stepped
 
     def _terms_from_sums(self, sums, n_blk):
         """sums: [len(_SLOTS), 8] numpy array of sums of squares -> the reference's loss terms."""
@@ -472,11 +485,12 @@ class DeepHPM(NetApi):
                 evaluate_with_finite_gradient(self.engine, probe, P, self._shift_state)
                 self._shift_state["probed"] = True
             for it in range(iter):
-                self._loss_and_grad(idx_start, idx_end, sums_out=rec[it])     # one launch less per step than copying afterwards
+                self.adam_t += 1
+                updated = self._loss_and_grad(idx_start, idx_end, sums_out=rec[it], adam=(learning_rate, self.adam_t))     # (sums_out: one launch less per step than copying afterwards)
                 if self._reduce:
                     rec[it].copy_(self._buf[P:])
-                self.adam_t += 1
-                self.engine.adam_step(self.theta, self.adam_m, self.adam_v, self._buf[:P], learning_rate, self.adam_t)
+                if not updated:
+                    self.engine.adam_step(self.theta, self.adam_m, self.adam_v, self._buf[:P], learning_rate, self.adam_t)
                 if record == "post":                 # INF:308-317: the terms at the updated weights
                     self._loss_and_grad(idx_start, idx_end)
                     rec[it].copy_(self._buf[P:])

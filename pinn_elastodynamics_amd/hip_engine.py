@@ -172,6 +172,38 @@ class HipEngine:
                                       self._ws_ptr, self.ws_bytes, self._stream())
         return grad_out
 
+    def wave_step(self, params, x, y, t, lb, ub, normalize, term_weights, sets, grad_out, loss_out, E=2.5, mu=0.25, rho=1.0, plane_strain=True,
+                  accumulate: bool = False, adam=None):
+        """One training step's evaluation in one library call (pinn_wave2d_step): the collocation batch (x, y, t) with its seven term weights, the
+        value-only ``sets`` (as data_loss_grad_multi: (x, y, t, targets_or_None, out_weights, loss_out)), the gradient of everything into
+        ``grad_out`` and -- with ``adam = (m, v, lr, step[, beta1, beta2, eps])`` -- the TF1 Adam update of ``params`` behind it.  For the nets of
+        the register-state fused kernel that is repack | one persistent launch | one reduction (+ Adam); for every other net the library makes
+        the separate calls inside: the same bits either way."""
+        n = x.numel()
+        for v in (x, y, t):
+            self._chk(v, n)
+        self._chk(params, self.n_params)
+        self._chk(grad_out, self.n_params)
+        rows = []
+        for sx, sy, st, tg, ow, lo in sets:
+            m_ = sx.numel()
+            for v in (sx, sy, st):
+                self._chk(v, m_)
+            if tg is not None:
+                self._chk(tg, self.layers[-1] * m_)
+            rows.append((sx.data_ptr(), sy.data_ptr(), st.data_ptr(), m_, 0 if tg is None else tg.data_ptr(), ow, lo.data_ptr()))
+        ad = None
+        if adam is not None:
+            m, v, lr, step = adam[:4]
+            b1, b2, eps = (list(adam[4:]) + [0.9, 0.999, 1e-8][len(adam) - 4:])[:3]
+            for a_ in (m, v):
+                self._chk(a_, self.n_params)
+            ad = (m.data_ptr(), v.data_ptr(), lr, b1, b2, eps, step)
+        self.lib.wave2d_step(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize, E, mu, rho, plane_strain,
+                             term_weights, loss_out.data_ptr(), rows, grad_out.data_ptr(), accumulate, ad, self._mode(False), self._ws_ptr, self.ws_bytes,
+                             self._stream())
+        return grad_out
+
     def fields(self, params, x, y, t, lb, ub, normalize):
         """Returns [4, n_out, n]: Y and its derivatives w.r.t. x, y, t."""
         n = x.numel()

@@ -698,3 +698,92 @@ def test_hole_traction_through_the_fused_one_stream_kernel_emulated(emu, lN, n):
     finally:
         emu.set_fused(1)
     assert not np.array_equal(res[1][1], res[0][1])          # two different code paths ran
+
+
+def _step_case(emu, layers, n, n_side, prec, seed, with_adam):
+    """pinn_wave2d_step against pinn_wave2d_loss_grad + pinn_data_loss_grad_multi (+ pinn_adam_step) on the same inputs"""
+    emu.set_fused(True)
+    rng = np.random.default_rng(seed)
+    Ws, bs = po.xavier_init(layers, rng)
+    bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
+    flat = po.pack_params(Ws, bs).astype(np.float32)
+    X = po.collocation_points(n, LB, UB, rng)
+    x, y, t = (X[:, k].astype(np.float32).copy() for k in range(3))
+    tw = np.array([1, 2, 3, 1, 0.5, 1, 2.0]) / n
+    sets_np = []
+    for k, m in enumerate(n_side):
+        S = po.collocation_points(m, LB, UB, rng).astype(np.float32)
+        tg = (0.1 * rng.standard_normal((7, m))).astype(np.float32) if k % 2 == 0 else None
+        ow = [(1.0 + i) / max(m, 1) if i in ((0, 1), (0, 1, 2, 3), (5, 6))[k % 3] else 0.0 for i in range(7)]
+        sets_np.append([np.ascontiguousarray(S[:, j]) for j in range(3)] + [tg, ow, np.full(8, np.nan, np.float32)])
+    wsb = emu.workspace_bytes(layers, max(n, 1 << 12), prec)
+    out = {}
+    for mode in ("step", "calls"):
+        ws = aligned(wsb)
+        theta = flat.copy()
+        m1, v1 = np.full(theta.size, 0.01, np.float32), np.full(theta.size, 0.02, np.float32)
+        loss = np.full(8, np.nan, np.float32)
+        grad = np.full(theta.size, np.nan, np.float32)
+        rows = []
+        for sx, sy, st, tg, ow, lo in sets_np:
+            lo[:] = np.nan
+            rows.append((sx.ctypes.data, sy.ctypes.data, st.ctypes.data, sx.size, 0 if tg is None else tg.ctypes.data, ow, lo.ctypes.data))
+        emu.path_counts(reset=True)
+        if mode == "step":
+            emu.wave2d_step(theta.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, True, 2.5, 0.25, 1.0, True, tw, loss.ctypes.data,
+                            rows, grad.ctypes.data, False, (m1.ctypes.data, v1.ctypes.data, 1e-3, 0.9, 0.999, 1e-8, 3) if with_adam else None, prec,
+                            ws.ctypes.data, wsb)
+        else:
+            emu.wave2d_loss_grad(theta.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, True, 2.5, 0.25, 1.0, True, tw,
+                                 loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+            emu.data_loss_grad_multi(theta.ctypes.data, layers, rows, LB, UB, True, grad.ctypes.data, True, prec, ws.ctypes.data, wsb)
+            if with_adam:
+                emu.adam_step(theta.ctypes.data, m1.ctypes.data, v1.ctypes.data, grad.ctypes.data, theta.size, 1e-3, 3)
+        out[mode] = dict(theta=theta, m=m1, v=v1, loss=loss[:7].copy(), grad=grad, side=[r[5][:7].copy() for r in sets_np], counts=emu.path_counts(reset=True))
+    return out, (flat, X, tw, sets_np)
+
+
+@pytest.mark.parametrize("layers,n,n_side,prec,with_adam", [
+    ([3] + 4 * [32] + [7], 300, (70, 50), "f16x3", True),           # BASELINE configs[0] net: four-stream part with all states in LDS
+    ([3] + 8 * [64] + [7], 200, (70, 0, 130), "f16x3", True),       # configs[1] net: parked states, S_1 from the weight-gradient wave; an empty set
+    ([3] + 8 * [64] + [7], 130, (40,), "bf16", False),              # one MFMA per product, no optimizer step (the data-parallel form)
+])
+def test_step_call_is_the_separate_calls_bit_for_bit_emulated(emu, layers, n, n_side, prec, with_adam):
+    """pinn_wave2d_step (round 5): collocation set + side sets in ONE persistent launch (fused_step_kernel: the side sets' workgroups behind the
+    collocation set's), one reduction with the Adam update in it.  Same partial sums, same order of the final additions, same Adam expression
+    as the three calls it replaces: identical bits in loss sums, gradient, parameters and both moments -- and the oracle's numbers."""
+    out, (flat, X, tw, sets_np) = _step_case(emu, layers, n, n_side, prec, 5, with_adam)
+    a, b = out["step"], out["calls"]
+    assert a["counts"]["fused-registers"] == 2 and b["counts"]["fused-registers"] == 2, (a["counts"], b["counts"])
+    for key in ("loss", "grad", "theta", "m", "v"):
+        assert np.array_equal(a[key], b[key]), key
+    for sa, sb in zip(a["side"], b["side"]):
+        assert np.array_equal(sa, sb)
+    assert np.isfinite(a["grad"]).all() and (not with_adam or not np.array_equal(a["theta"], flat))
+    # against the float64 oracle: collocation terms + data terms
+    ss, g, _ = po.wave2d_loss_grad(flat.astype(np.float64), layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, True, term_weights=tw)
+    gsum = g.copy()
+    for (sx, sy, st, tg, ow, lo), got in zip(sets_np, a["side"]):
+        if sx.size == 0:
+            assert np.all(got == 0.0)
+            continue
+        s2, g2, _ = po.data_loss_grad(flat.astype(np.float64), layers, sx, sy, st, LB, UB, True, None if tg is None else tg.T.astype(np.float64), np.asarray(ow))
+        gsum += g2
+        assert rel(got, s2) < (2e-2 if prec == "bf16" else 2e-6)
+    assert rel(a["loss"], ss) < (2e-2 if prec == "bf16" else 2e-6) and rel(a["grad"], gsum) < (3e-2 if prec == "bf16" else 1e-4)
+
+
+def test_step_call_several_steps_per_workgroup_and_fallbacks_emulated(emu):
+    """more steps than workgroups in both parts (the persistent accumulators of both roles carry over), and the cases the one-launch form
+    declines -- a depth without fused kernel, PINN_PREC_FP32 -- which make the separate calls inside: same bits as making them outside."""
+    out, _ = _step_case(emu, [3] + 4 * [32] + [7], 17000, (16500,), "f16x3", 9, True)
+    a, b = out["step"], out["calls"]
+    assert a["counts"]["fused-registers"] == 2
+    for key in ("loss", "grad", "theta", "m", "v"):
+        assert np.array_equal(a[key], b[key]), key
+    for layers, prec, path in (([3] + 3 * [32] + [7], "f16x3", "two-kernel"), ([3] + 4 * [32] + [7], "fp32", "fp32")):
+        out, _ = _step_case(emu, layers, 150, (40, 30), prec, 2, True)
+        a, b = out["step"], out["calls"]
+        assert a["counts"][path] >= 2 and a["counts"]["fused-registers"] == 0, a["counts"]
+        for key in ("loss", "grad", "theta", "m", "v"):
+            assert np.array_equal(a[key], b[key]), (layers, prec, key)
