@@ -74,7 +74,8 @@ enum {
     PINN_ERR_LAYERS = -2,      /* unsupported layer list (see pinn_supported_width) */
     PINN_ERR_PRECISION = -3,   /* unknown precision_mode */
     PINN_ERR_WORKSPACE = -4,   /* workspace smaller than pinn_min_workspace_bytes() or misaligned */
-    PINN_ERR_SIZE = -5         /* n < 0 (n == 0 is a valid empty batch: zero sums, zero / untouched gradient) */
+    PINN_ERR_SIZE = -5,        /* n < 0 (n == 0 is a valid empty batch: zero sums, zero / untouched gradient) */
+    PINN_ERR_COLLECTIVE = -6   /* pinn_p2p_*: not connected, or a rank did not arrive within the bounded wait (~2 s) */
 };
 
 /* Padded hidden width the kernels use for a real hidden width h (0 if unsupported). */
@@ -292,6 +293,26 @@ int pinn_nc3d_fields(const float* params_flat, const int* layers, int n_layers,
  * correction).  step is 1-based.  All arrays are length n_params, updated in place. */
 int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_flat, int64_t n_params,
                    double lr, double beta1, double beta2, double eps, int64_t step, void* stream);
+
+/* ---- Latency-floor all-reduce of the step's buffer [gradient | loss sums] (round 5; SURVEY sections 5 and 8e).  The message is ~119 KB:
+ * latency-bound, so a ring or tree buys nothing.  One-shot: every rank WRITES its buffer into a slot of every peer's IPC-mapped receive buffer
+ * over its point-to-point xGMI link, flags it, and every rank sums the world's slots locally in rank order (the same bits on every rank) --
+ * with the TF1 Adam update of INF:131-133 in the same kernel.  One launch replaces all-reduce + pinn_adam_step and does not depend on RCCL's
+ * small-message protocol (RCCL stays the default collective of the model classes; this is `collective="p2p"`).
+ *   pinn_p2p_create   allocates this rank's receive buffer (2 parities x world slots x max_floats, fine-grained device memory -- the ONE
+ *                     allocation this library makes, owned by the comm object) and returns its IPC handle;
+ *   the caller exchanges the world's handles (any out-of-band channel: the model classes use torch.distributed.all_gather_object);
+ *   pinn_p2p_connect  opens the peers' buffers;   pinn_p2p_allreduce  buf[0..n) <- sum over ranks, enqueued on `stream`; with `adam` the
+ *                     first n_params entries of the sum also update params_flat / adam->m / adam->v;   every rank must make the same calls.
+ *   pinn_p2p_status   synchronises and returns 0, or PINN_ERR_COLLECTIVE if a rank did not arrive within the bounded wait of some call
+ *                     (the kernel then returns without hanging the GPU; its results are void). */
+#define PINN_IPC_HANDLE_BYTES 64
+typedef struct pinn_p2p_comm pinn_p2p_comm;
+int pinn_p2p_create(int rank, int world, int64_t max_floats, pinn_p2p_comm** comm_out, unsigned char handle_out[PINN_IPC_HANDLE_BYTES]);
+int pinn_p2p_connect(pinn_p2p_comm* comm, const unsigned char* all_handles /* world x PINN_IPC_HANDLE_BYTES, rank order */);
+int pinn_p2p_allreduce(pinn_p2p_comm* comm, float* buf, int64_t n, float* params_flat, const pinn_adam_state* adam, int64_t n_params, void* stream);
+int pinn_p2p_status(pinn_p2p_comm* comm, int* fine_grained_out);
+int pinn_p2p_destroy(pinn_p2p_comm* comm);
 
 /* Testing hook (process-wide): 0 forces the two-kernel path (chain + wgrad kernels) even where the
  * fused kernel applies; 1 (default) prefers the fused kernel.  Returns the previous setting.  Both paths

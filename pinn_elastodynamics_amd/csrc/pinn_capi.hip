@@ -146,6 +146,7 @@ const char* pinn_error_string(int code) {
         case PINN_ERR_PRECISION: return "unknown precision_mode";
         case PINN_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
         case PINN_ERR_SIZE: return "n must not be negative";
+        case PINN_ERR_COLLECTIVE: return "p2p collective: not connected, or a rank did not arrive within the bounded wait";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }

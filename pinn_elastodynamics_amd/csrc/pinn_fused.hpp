@@ -248,11 +248,17 @@ struct Fused {
     static constexpr bool LO8 = PINN_LO8_ENABLED && Op::TOP_BYTE_IS_FLOAT && !LDSOP && !SLDS && WB == 4 && NP == 2 && !FASTSTATE && KS == 2;      // (four- and five-stream narrow layouts)
     // LO_FROM (round 5, the per-layer low-part policy): parked states S_2 .. S_{LO_FROM-1} travel WITHOUT a low-part record -- the activation reverse
     // of those layers sees fp16 states.  tools/studies/lo_policy_study.py (the kernel's arithmetic in numpy at the reference's trained nets and the
-    // 8 x 64 fixture, per weight layer and bias against the fp32 bound of the GPU tests) prices every subset; see DESIGN section 4.
-#ifndef PINN_LO_FROM
-#define PINN_LO_FROM 2
-#endif
+    // 8 x 64 fixture, per weight layer and bias, error against float64 as a multiple of host-fp32's: the GPU tests' bound is 6) prices every subset.
+    // Which layers the reverse needs: the UPPER ones (at inf20s, the most sensitive net: without S_6's low part 3.9 -> 18, S_7 14, S_5 11.5, S_4 7.3,
+    // S_3 5.4, S_2 4.6 on 4096 points; semi16s / conf14s / the 8 x 64 fixture do not move for any single layer).  Shipped: S_2 alone goes without
+    // (four-stream kernel): worst multiple 3.9 -> 4.6 (4096 points) and 7.5 -> 7.4 (32 k points) at inf20s, unchanged elsewhere; dropping S_3 as well
+    // reaches 6.3 and was not taken.  Measured (60 interleaved launches each, order shuffled per round): 4.531 -> 4.439 ms per 2 M points (-2.0 %; with
+    // S_3 as well -2.5 %, all low parts gone -12 %).  The plate's five-stream kernel keeps every record: it has no trained-weight fixture of its own.
+#ifdef PINN_LO_FROM
     static constexpr int LO_FROM = PINN_LO_FROM;
+#else
+    static constexpr int LO_FROM = NS_ == 4 ? 3 : 2;
+#endif
     static __device__ __forceinline__ constexpr bool lo_layer(int l) { return l <= 1 || l >= LO_FROM; }
     static __device__ __forceinline__ uint32_t lo8_pack(uint32_t rows01, uint32_t rows23) {       // the high bytes of four fp16 values
 #if defined(__AMDGCN__)

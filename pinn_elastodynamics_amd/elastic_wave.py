@@ -114,18 +114,26 @@ def relax_adjoint_shift(engine, loss, state):
         state["raised_at"] = loss
 
 
-def all_reduce_sum(buf, group, events=None):
-    """The step's one collective: all-reduce(sum) of the fused buffer [gradient | loss sums] (RCCL under the "nccl" backend), enqueued in stream
-    order behind the kernels that filled it.  ``events``: a list that receives one (start, end) pair of timing events per call, recorded on the
-    current stream around the collective (the stream waits for the communicator's own stream, so the pair brackets it) -- bench.py's
-    ``allreduce_ms``; None (default): nothing is recorded."""
+def all_reduce_sum(buf, group, events=None, p2p=None, adam=None, n_params=0):
+    """The step's one collective: all-reduce(sum) of the fused buffer [gradient | loss sums], enqueued in stream order behind the kernels that
+    filled it.  Default: torch.distributed.all_reduce (RCCL under the "nccl" backend).  ``p2p`` (a p2p.P2PAllReduce): the library's one-shot
+    kernel over IPC-mapped peer buffers instead; with ``adam = (params, m, v, lr, step)`` it also applies the Adam update to the first
+    ``n_params`` entries of the sum -- returns True then.  ``events``: a list that receives one (start, end) pair of timing events per call,
+    recorded on the current stream around the collective (with RCCL the stream waits for the communicator's own stream, so the pair brackets
+    it) -- bench.py's ``allreduce_ms``; None (default): nothing is recorded."""
     if events is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
-    torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=group)
+    folded = False
+    if p2p is not None:
+        p2p.all_reduce(buf, adam=adam, n_params=n_params)
+        folded = adam is not None
+    else:
+        torch.distributed.all_reduce(buf, op=torch.distributed.ReduceOp.SUM, group=group)
     if events is not None:
         ev[1].record()
         events.append(ev)
+    return folded
 
 
 def lbfgs_on_device(theta, loss_and_grad, options, callback=None):
@@ -164,7 +172,7 @@ class DeepHPM(NetApi):
 
     def __init__(self, Collo, SRC, IC, UP, uv_layers, lb, ub, ExistModel=0, modelDir='', *, case="infinite",
                  FIX=None, precision="f16x3", engine=None, seed=1111, process_group=None, verbose=True,
-                 E=2.5, mu=0.25, rho=1.0, always_reduce=False, shard_as=None):
+                 E=2.5, mu=0.25, rho=1.0, always_reduce=False, shard_as=None, collective="rccl"):
         self.count = 0                      # callback counter (INF:26)
         self._shift_state = {}              # adjoint-shift bookkeeping of evaluate_with_finite_gradient
         self.loss_rec = []                  # SEMI:39
@@ -254,6 +262,14 @@ class DeepHPM(NetApi):
 
         P = self.n_params
         self._buf = torch.zeros(P + 8 * len(_SLOTS), dtype=torch.float32, device=self.device)
+        # ``collective``: "rccl" (default) = torch.distributed.all_reduce of the fused buffer; "p2p" = the library's one-shot all-reduce over
+        # IPC-mapped peer buffers with the Adam update in the same kernel (p2p.P2PAllReduce, include/pinn_hip.h: pinn_p2p_*)
+        if collective not in ("rccl", "p2p"):
+            raise ValueError("collective must be 'rccl' or 'p2p'")
+        self._p2p = None
+        if collective == "p2p" and self._reduce:
+            from .p2p import P2PAllReduce
+            self._p2p = P2PAllReduce(self.engine.lib, self._buf.numel(), self.pg)
 
     # ------------------------------------------------------------------------------------------
     # checkpoints: the reference's [W_list, b_list] pickle (INF:159-186); .npz is accepted too
@@ -439,7 +455,9 @@ class DeepHPM(NetApi):
         if self._reduce:
             # one fused buffer [gradient | loss sums] (latency-bound message); enqueued behind the kernels in stream order, and Adam is
             # enqueued behind it: the host never waits
-            all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None))
+            fold = adam is not None and self._p2p is not None
+            stepped = all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None), self._p2p,
+                                     (self.theta, self.adam_m, self.adam_v, adam[0], adam[1]) if fold else None, P)
         return stepped
 
     def _terms_from_sums(self, sums, n_blk):

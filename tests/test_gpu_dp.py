@@ -75,3 +75,23 @@ def test_two_ranks_on_one_gpu_plate_and_nc3d(tmp_path, model):
     assert np.array_equal(z["theta0"], z["theta1"])
     assert np.linalg.norm(z["theta0"] - theta) < 1e-5 * np.linalg.norm(theta)
     np.testing.assert_allclose(z["loss"], loss, rtol=1e-4)
+
+
+@pytest.mark.gpu
+def test_p2p_one_shot_allreduce_two_ranks_on_one_gpu(tmp_path):
+    """The latency-floor collective (include/pinn_hip.h: pinn_p2p_*): two processes on cuda:0 exchange hipIpcMemHandles, every call
+    is one kernel -- push into the peer's slot, flag, sum in rank order, Adam.  25 back-to-back calls on rank-dependent data give the exact fp32
+    sums (both slot parities, no host synchronisation in between), the folded Adam equals pinn_adam_step on the same sums, and
+    DeepHPM(collective="p2p") leaves the ranks bit-identical and reproduces the run over gloo's all_reduce."""
+    out = str(tmp_path / "p2p.npz")
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29536", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29536", os.path.join(ROOT, "tests", "_dp_worker_p2p.py"), out], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = np.load(out)
+    assert float(z["worst"]) == 0.0, float(z["worst"])                              # the sums, exactly
+    assert float(z["adam_err"]) <= 1e-7                                              # the folded Adam = pinn_adam_step (same expression)
+    assert np.array_equal(z["p2p0"], z["p2p1"])                                      # ranks stay bit-identical
+    assert np.linalg.norm(z["p2p0"] - z["gloo0"]) <= 1e-6 * np.linalg.norm(z["gloo0"])
+    np.testing.assert_allclose(z["loss_p2p"], z["loss_gloo"], rtol=1e-5)

@@ -23,8 +23,9 @@ for name in names:
     for _ in range(2):
         eng.wave_loss_grad(theta, *xs, [0, 0, 0], [30, 30, 20], True, tw)
     engs[name] = (eng, err, [])
+order_rng = np.random.default_rng(7)
 for rnd in range(int(os.environ.get("EXP_ROUNDS", "4"))):                        # interleaved rounds: box-to-box and clock drift hit every variant alike
-    for name in names:
+    for name in order_rng.permutation(names):                                    # (in a new order every round: a variant that always runs behind a lighter one inherits its clock)
         eng, err, ts = engs[name]
         for _ in range(6):
             ts.append(eng.wave_loss_grad_profile(theta, *xs, [0, 0, 0], [30, 30, 20], True, tw)['chain'])
