@@ -189,6 +189,8 @@ def main():
     ap.add_argument("--rank-share", type=int, default=1, help="N > 1 (one GPU, wave config): run what ONE of N data-parallel ranks executes per step -- 1/N of the "
                     "--global-points collocation rows AND 1/N of every side set, sharded as DeepHPM._shard does, sums weighted with the global 1/N -- "
                     "with --always-reduce the collective branch included; `value` counts this rank's points")
+    ap.add_argument("--collective", default="rccl", choices=["rccl", "p2p"], help="the step's all-reduce: torch.distributed (RCCL under nccl; default) or the "
+                    "library's one-shot all-reduce over IPC-mapped peer buffers with Adam in the same kernel (pinn_p2p_*; wave config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-config", action="store_true")
     ap.add_argument("--extra-modes", default="bf16,f16x3_fp16state",
@@ -261,7 +263,7 @@ def main():
         SRC, IC = ricker_source(), ic_grid()
         eng = HipEngine(layers, precision=args.precision, device=dev, max_points=args.chunk_points)
         model = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, case="infinite", engine=eng, seed=1111, verbose=False,
-                        always_reduce=args.always_reduce, shard_as=(0, share) if share > 1 else None)
+                        always_reduce=args.always_reduce, shard_as=(0, share) if share > 1 else None, collective=args.collective)
         step = lambda k: model.train(k, 1e-3, 1)
         side_note = (f"IC {model._sides['IC'][0].numel()} + SRC {model._sides['SRC'][0].numel()} (rank 0's 1/{share} share of IC 10201 / SRC 70400, of {n_global} collocation pts)"
                      if share > 1 else "IC 10201 + SRC 70400")
@@ -393,7 +395,11 @@ def main():
     }
     if allreduce_ms is not None:
         out["allreduce_note"] = ("mean of timing events recorded on the step's stream around torch.distributed.all_reduce of the fused buffer "
-                                 f"[gradient | loss sums] ({4 * model._buf.numel()} bytes), backend {backend}, world {world}")
+                                 f"[gradient | loss sums] ({4 * model._buf.numel()} bytes), backend {backend}, world {world}"
+                                 if args.collective == "rccl" else
+                                 f"mean of timing events recorded on the step's stream around the one-shot P2P all-reduce kernel (push to every peer's IPC-mapped "
+                                 f"slot, sum in rank order, Adam update in the same kernel: pinn_p2p_allreduce), {4 * model._buf.numel()} bytes, world {world}")
+        out["config"]["collective"] = args.collective
     if rank == 0:
         # MFMAs issued per algorithmic product (forward and reverse chain: 8 of 12 contractions, 3 per product; weight gradient: 4 of 12): the
         # narrow four- and five-stream collocation kernels multiply high parts only there (1, round 4), the LDS-operand layouts (padded width

@@ -260,6 +260,20 @@ int pinn_wave2d_step(float* params_flat, const int* layers, int n_layers,
                      float* grad_flat_out, int accumulate, const pinn_adam_state* adam,
                      int precision_mode, void* workspace, size_t ws_bytes, void* stream);
 
+/* The plate's step the same way (PLATE:187-217: loss = 10 (loss_f_uv + loss_f_s + loss_HOLE)): pinn_plate2d_loss_grad's collocation set and
+ * pinn_plate2d_traction_loss_grad's hole set in one persistent launch (five-stream part, then the one-stream part), one reduction (+ Adam).
+ * What it saves matters most where the reference spends its time: the L-BFGS stage on ~45 k points is latency-bound (a handful of steps per
+ * workgroup), and every evaluation is two launches less.  Same fall-back rule and the same bits as the separate calls. */
+int pinn_plate2d_step(float* params_flat, const int* layers, int n_layers,
+                      const float* x, const float* y, const float* t, int64_t n,
+                      const double lb[3], const double ub[3], int normalize,
+                      const float* frozen_streams, double E, double mu, double rho,
+                      const float term_weights[5], float* loss_terms_out,
+                      const float* hole_x, const float* hole_y, const float* hole_t, int64_t hole_n,
+                      const float* hole_frozen_and_normals, const float hole_weights[2], float* hole_loss_terms_out,
+                      float* grad_flat_out, int accumulate, const pinn_adam_state* adam,
+                      int precision_mode, void* workspace, size_t ws_bytes, void* stream);
+
 /* ---- 3-D Navier-Cauchy extension (BASELINE.json configs[4]).  NOT in the reference: all four reference scripts are 2-D + time
  * (SURVEY.md section 0), so these entry points have no reference lines to replace; they state the 3-D form of net_f_sig
  * (INF:221-265) the way oracle/nc3d_oracle.py spells it out, and parity for them is unpinned by definition.

@@ -87,6 +87,9 @@ class PinnLib:
         L.pinn_wave2d_step.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, f64, f64, f64, i32, pf32, vp, C.POINTER(PointSet), i32, vp, i32,
                                        C.POINTER(AdamState), i32, vp, sz, vp]
         L.pinn_wave2d_step.restype = i32
+        L.pinn_plate2d_step.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, f64, f64, f64, pf32, vp, vp, vp, vp, i64, vp, pf32, vp, vp, i32,
+                                        C.POINTER(AdamState), i32, vp, sz, vp]
+        L.pinn_plate2d_step.restype = i32
         L.pinn_wave2d_fields.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, i32, vp, sz, vp]
         L.pinn_wave2d_fields.restype = i32
         L.pinn_net_streams.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, i32, vp, sz, vp]
@@ -278,6 +281,18 @@ class PinnLib:
                                        float(E), float(mu), float(rho), int(bool(plane_strain)), self._floats(term_weights, 7), loss_out, arr, len(sets),
                                        grad_out, int(bool(accumulate)), C.byref(ad) if ad is not None else None, mode_bits(prec), ws, int(ws_bytes), stream)
         self.check(rc, "pinn_wave2d_step")
+
+    def plate2d_step(self, params, layers, x, y, t, n, lb, ub, normalize, frozen, E, mu, rho, term_weights, loss_out, hx, hy, ht, hn, haux, hweights,
+                     hloss_out, grad_out, accumulate, adam, prec, ws, ws_bytes, stream=0):
+        """pinn_plate2d_step.  adam: None or (m, v, lr, beta1, beta2, eps, step)."""
+        ad = None
+        if adam is not None:
+            ad = AdamState(adam[0], adam[1], float(adam[2]), float(adam[3]), float(adam[4]), float(adam[5]), int(adam[6]))
+        rc = self.lib.pinn_plate2d_step(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub), int(bool(normalize)), frozen,
+                                        float(E), float(mu), float(rho), self._floats(term_weights, 5), loss_out, hx, hy, ht, int(hn), haux,
+                                        self._floats(hweights, 2), hloss_out, grad_out, int(bool(accumulate)), C.byref(ad) if ad is not None else None,
+                                        mode_bits(prec), ws, int(ws_bytes), stream)
+        self.check(rc, "pinn_plate2d_step")
 
     def wave2d_fields(self, params, layers, x, y, t, n, lb, ub, normalize, fields_out, prec, ws, ws_bytes, stream=0):
         rc = self.lib.pinn_wave2d_fields(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),

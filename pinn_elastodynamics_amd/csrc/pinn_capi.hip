@@ -307,6 +307,13 @@ static int fp32_call(const Call& c, int head, int nterms, int ns, int din = 3) {
     return PINN_OK;
 }
 
+// lr_t of the TF1 rule (bias correction folded into the step size, computed in double)
+static float adam_lr_t(double lr, double beta1, double beta2, int64_t step) {
+    const double b1t = __builtin_pow(beta1, (double)step), b2t = __builtin_pow(beta2, (double)step);      // (pinn_adam_step's own expression: the same bits)
+    const double lr_t = lr * __builtin_sqrt(1.0 - b2t) / (1.0 - b1t);
+    return (float)lr_t;
+}
+
 // Hooke coefficients: plane strain INF:238-241, plane stress PLATE:416-418
 static void set_hooke(Call& c, double E, double mu, double rho, int plane_strain) {
     double c1, c2;
@@ -438,13 +445,6 @@ int pinn_data_loss_grad_multi(const float* params_flat, const int* layers, int n
         return PINN_OK;
     }
     return impl->data_loss_grad(c);
-}
-
-// lr_t of the TF1 rule (bias correction folded into the step size, computed in double)
-static float adam_lr_t(double lr, double beta1, double beta2, int64_t step) {
-    const double b1t = __builtin_pow(beta1, (double)step), b2t = __builtin_pow(beta2, (double)step);      // (pinn_adam_step's own expression: the same bits)
-    const double lr_t = lr * __builtin_sqrt(1.0 - b2t) / (1.0 - b1t);
-    return (float)lr_t;
 }
 
 int pinn_wave2d_step(float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t, int64_t n,
@@ -588,6 +588,67 @@ int pinn_plate2d_traction_loss_grad(const float* params_flat, const int* layers,
     if (n == 0) return empty_batch(c, 2);
     if (!impl) return fp32_call(c, HEAD_TRACTION, 2, 1);
     return impl->traction_loss_grad(c);
+}
+
+int pinn_plate2d_step(float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t, int64_t n,
+                      const double lb[3], const double ub[3], int normalize, const float* frozen_streams, double E, double mu, double rho,
+                      const float term_weights[5], float* loss_terms_out, const float* hole_x, const float* hole_y, const float* hole_t, int64_t hole_n,
+                      const float* hole_frozen_and_normals, const float hole_weights[2], float* hole_loss_terms_out, float* grad_flat_out, int accumulate,
+                      const pinn_adam_state* adam, int precision_mode, void* workspace, size_t ws_bytes, void* stream) {
+    if (hole_n < 0) return PINN_ERR_SIZE;
+    if (adam && (!adam->m || !adam->v || adam->step < 1)) return adam->step < 1 ? PINN_ERR_SIZE : PINN_ERR_NULL;
+    if (hole_n > 0 && (!hole_x || !hole_y || !hole_t || !hole_frozen_and_normals || !hole_weights || !hole_loss_terms_out)) return PINN_ERR_NULL;
+    // ---- the one-launch form (fused_step_kernel<..., NSC = 5>): the five-stream collocation set and the hole-traction set
+    if (n > 0 && hole_n > 0 && frozen_streams && term_weights && loss_terms_out && grad_flat_out) {
+        Call c;
+        const Impl* impl = nullptr;
+        int rc = prepare(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, precision_mode, workspace, ws_bytes, stream, c, impl);
+        if (rc) return rc;
+        if (c.net.nout != 5) return PINN_ERR_LAYERS;
+        if (impl) {
+            c.c1 = (float)(E / (1.0 - mu * mu));               // plane stress, PLATE:416-418
+            c.c2 = (float)(E * mu / (1.0 - mu * mu));
+            c.G = (float)(E / (2.0 * (1.0 + mu)));
+            c.rho = (float)rho;
+            for (int i = 0; i < 5; ++i) c.tw[i] = term_weights[i];
+            c.aux = frozen_streams;
+            c.loss_out = loss_terms_out;
+            c.grad_out = grad_flat_out;
+            c.accumulate = accumulate;
+            Call d = c;                                        // the traction set as a one-set call of the one-stream kernel (head kind 1)
+            d.x = hole_x;
+            d.y = hole_y;
+            d.t = hole_t;
+            d.n = (long)hole_n;
+            for (int i = 0; i < 16; ++i) d.tw[i] = 0.0f;
+            d.tw[0] = hole_weights[0];
+            d.tw[1] = hole_weights[1];
+            d.aux = hole_frozen_and_normals;
+            d.loss_out = hole_loss_terms_out;
+            d.one_stream_head = 1;
+            d.nsets = 0;
+            AdamEpilogue ep = {nullptr, nullptr, nullptr, 0.f, 0.f, 0.f, 0.f};
+            if (adam) ep = AdamEpilogue{params_flat, adam->m, adam->v, adam_lr_t(adam->lr, adam->beta1, adam->beta2, adam->step), (float)adam->beta1, (float)adam->beta2, (float)adam->eps};
+            if (impl->plate_step(c, d, ep, &rc)) return rc;
+        }
+    }
+    // ---- every other case: the calls one after the other, the same bits
+    int rc = pinn_plate2d_loss_grad(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, frozen_streams, E, mu, rho, term_weights, loss_terms_out,
+                                    grad_flat_out, accumulate, precision_mode, workspace, ws_bytes, stream);
+    if (rc) return rc;
+    if (hole_loss_terms_out && hole_weights) {             // (an empty hole set reports zeros; no hole set at all: NULL outputs)
+        const int packed = n > 0 ? PINN_FLAG_WEIGHTS_PACKED : 0;
+        rc = pinn_plate2d_traction_loss_grad(params_flat, layers, n_layers, hole_x, hole_y, hole_t, hole_n, lb, ub, normalize, hole_frozen_and_normals,
+                                             hole_weights, hole_loss_terms_out, grad_flat_out, 1, precision_mode | packed, workspace, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    if (adam) {
+        NetDesc net;
+        int width = 0;
+        if ((rc = decode_net(layers, n_layers, net, width, 3))) return rc;
+        return pinn_adam_step(params_flat, adam->m, adam->v, grad_flat_out, net.nparams, adam->lr, adam->beta1, adam->beta2, adam->eps, adam->step, stream);
+    }
+    return PINN_OK;
 }
 
 int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,

@@ -2575,9 +2575,10 @@ __global__ __launch_bounds__(512) void fused_wave_kernel(const FusedArgs a) {
 // workgroups are dispatched as compute units run out of collocation steps -- a collocation set of N points is ceil(N / 64) steps over 256
 // workgroups, so in its last step most compute units idle (250,000 points, one of 8 GPUs' share of BASELINE's 2 M: 67 workgroups have a
 // 16th step, 189 do not) -- instead of waiting, as a second launch, for the whole first one; and a step is one launch less.
-template <class Op, int SPLIT, int WIDTH, int NL, bool FASTSTATE>
+// (NSC = 5: the plate's step -- its five-stream collocation set and the hole-traction set, PLATE:187-217 -- the same way.)
+template <class Op, int SPLIT, int WIDTH, int NL, int NSC, bool FASTSTATE>
 __global__ __launch_bounds__(512) void fused_step_kernel(const FusedArgs a4, const FusedArgs a1) {
-    typedef Fused<Op, SPLIT, WIDTH, NL, 4, FASTSTATE, 3> F4;
+    typedef Fused<Op, SPLIT, WIDTH, NL, NSC, FASTSTATE, 3> F4;
     typedef Fused<Op, SPLIT, WIDTH, NL, 1, false, 3> F1;
     __shared__ __attribute__((aligned(16))) char lds[F4::LDS_B > F1::LDS_B ? F4::LDS_B : F1::LDS_B];
     if ((int)blockIdx.x < a4.grid) F4::run(a4, lds);

@@ -91,6 +91,7 @@ extern long g_path_counts[5];
 struct Impl {
     int (*path_for)(const NetDesc&, int head, size_t ws_bytes);
     int (*wave_step)(const Call&, const Call&, const AdamEpilogue&, int* rc);      // 1: ran (narrow fused layouts), 0: make the calls one by one
+    int (*plate_step)(const Call&, const Call&, const AdamEpilogue&, int* rc);
     int (*wave_loss_grad)(const Call&);
     int (*data_loss_grad)(const Call&);
     int (*fields)(const Call&);
@@ -142,6 +143,8 @@ struct Host {
     static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? FUSED_ACC_W64 : (WIDTH <= 96 ? 72 * 1024 : 160 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
     // fused_step_kernel (collocation set + side sets of a training step in one launch): the narrow layouts
     static constexpr bool step_has() { return WIDTH <= 64; }
+    template <int NSC>
+    static constexpr bool step_has_ns() { return step_has() && (NSC == 4 || SPLIT == 3); }      // (the plate's five streams: split-precision families)
     template <int NS>
     static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5 || NS == 1)) || (WIDTH <= 128 && (NS == 4 || NS == 1)) || (WIDTH == 160 && NS == 4))); }
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
@@ -522,35 +525,39 @@ struct Host {
     // One training step's sets in one launch + one reduction (+ Adam): fused_step_kernel, reduce_step_kernel.  c = the collocation call
     // (pinn_wave2d_loss_grad's arguments), d = the side sets (pinn_data_loss_grad_multi's; d.nsets > 0).  Returns 1 if it ran (rc in *out), 0 if
     // this net / workspace / set sizes do not take it -- the caller then makes the two calls (+ pinn_adam_step) one after the other: same bits.
-    template <int NL, bool FS>
-    static int step_launch(const Call& c, const Call& d, const AdamEpilogue& adam, const Plan& p, int grid4, long nsteps4, int grid1, long nsteps1, size_t off1) {
-        typedef Fused<Op, SPLIT, WIDTH, NL, 4, FS, 3> F4;
+    template <int NL, int NSC, bool FS>
+    static int step_launch(const Call& c, const Call& d, const AdamEpilogue& adam, const Plan& p, int grid4, long nsteps4, int grid1, long nsteps1, size_t off1,
+                           int nterms_a, int nterms_b) {
+        typedef Fused<Op, SPLIT, WIDTH, NL, NSC, FS, 3> F4;
         typedef Fused<Op, SPLIT, WIDTH, NL, 1, false, 3> F1;
         int rc = repack(c, p);
         if (rc) return rc;
         char* b = static_cast<char*>(c.ws);
         FusedSetup s4, s1;
-        fused_setup<NL, 4, FS, 3>(c, p, grid4, nsteps4, 0, 0, 0, s4);
+        fused_setup<NL, NSC, FS, 3>(c, p, grid4, nsteps4, 0, 0, 0, s4);
         fused_setup<NL, 1, false, 3>(d, p, grid1, nsteps1, 1, off1, grid4, s1);
-        const int ring_slot = c.ring ? c.ring->begin(c.stream, 4) : -1;
-        hipLaunchKernelGGL((fused_step_kernel<Op, SPLIT, WIDTH, NL, FS>), dim3(grid4 + grid1), dim3(512), 0, c.stream, s4.a, s1.a);
+        const int ring_slot = c.ring ? c.ring->begin(c.stream, NSC) : -1;
+        hipLaunchKernelGGL((fused_step_kernel<Op, SPLIT, WIDTH, NL, NSC, FS>), dim3(grid4 + grid1), dim3(512), 0, c.stream, s4.a, s1.a);
         if (c.ring) c.ring->end(ring_slot, c.stream);
         if ((rc = (int)hipGetLastError())) return rc;
         StepPart A = {(const float*)s4.a.partial, grid4, s4.twmax, (const float*)s4.a.loss_part, (long)grid4 * F4::TILES};
         StepPart B = {(const float*)s1.a.partial, grid1, s1.twmax, (const float*)s1.a.loss_part, (long)grid1 * F1::TILES};
         hipLaunchKernelGGL((reduce_step_kernel<0>), dim3((c.net.nparams + 63) / 64 + s1.nsets + 1), dim3(256), 0, c.stream, A, B, c.net.nparams, c.grad_out,
-                           c.accumulate, 7, c.loss_out, c.net.nout, s1.nsets, (int)FUSED_MAX_SETS, s1.lo, adam, (const int*)(b + p.wflags),
+                           c.accumulate, nterms_a, c.loss_out, nterms_b, s1.nsets, (int)FUSED_MAX_SETS, s1.lo, adam, (const int*)(b + p.wflags),
                            SPLIT == 3 ? repack_blocks(c.net) : 0);
         return (int)hipGetLastError();
     }
-    static int wave_step(const Call& c, const Call& d, const AdamEpilogue& adam, int* out) {
-        if constexpr (step_has()) {
-            if (!c.use_fused || c.prof_ms != nullptr || !fused_depth<4>(c.net) || !fused_depth<1>(c.net)) return 0;
+    // NSC = 4: the wave step (c: pinn_wave2d_loss_grad's call, d: the value-only sets, nterms 7 / n_out); NSC = 5: the plate's (c: pinn_plate2d_loss_grad's
+    // call, d: the hole-traction set as a one-set call with one_stream_head = 1, nterms 5 / 2)
+    template <int NSC>
+    static int step(const Call& c, const Call& d, const AdamEpilogue& adam, int* out, int nterms_a, int nterms_b) {
+        if constexpr (step_has_ns<NSC>()) {
+            if (!c.use_fused || c.prof_ms != nullptr || !fused_depth<NSC>(c.net) || !fused_depth<1>(c.net)) return 0;
             if (((uintptr_t)c.ws & 255) != 0 || c.n <= 0) return 0;
             Plan p;
             plan_fixed<4>(c.net, c.n, p);
-            constexpr int T4 = Fused<Op, SPLIT, WIDTH, 4, 4>::TILES, T1 = Fused<Op, SPLIT, WIDTH, 4, 1>::TILES;
-            const size_t per4 = (size_t)T4 * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, 4>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, 4>::SCRATCH_BYTES);
+            constexpr int T4 = Fused<Op, SPLIT, WIDTH, 4, NSC>::TILES, T1 = Fused<Op, SPLIT, WIDTH, 4, 1>::TILES;
+            const size_t per4 = (size_t)T4 * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NSC>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NSC>::SCRATCH_BYTES);
             const size_t per1 = (size_t)T1 * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, 1>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, 1>::SCRATCH_BYTES);
             const long nsteps4 = (c.n + 16 * T4 - 1) / (16 * T4);
             long nsteps1 = 0;
@@ -561,15 +568,18 @@ struct Host {
             const long grid4 = nsteps4 < FUSED_GRID ? nsteps4 : FUSED_GRID, grid1 = nsteps1 < FUSED_GRID ? nsteps1 : FUSED_GRID;
             const size_t off1 = align_up((size_t)grid4 * per4, 256);
             if (c.ws_bytes < p.fixed_end + off1 + (size_t)grid1 * per1) return 0;      // (the two calls then size their grids to the workspace one by one)
-            if (c.fast_state && SPLIT == 3 && c.net.nl == 8) *out = step_launch<8, true>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1);
-            else *out = c.net.nl == 4 ? step_launch<4, false>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1)
-                                      : step_launch<8, false>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1);
+            if (NSC == 4 && c.fast_state && SPLIT == 3 && c.net.nl == 8)
+                *out = step_launch<8, NSC, NSC == 4>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1, nterms_a, nterms_b);
+            else *out = c.net.nl == 4 ? step_launch<4, NSC, false>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1, nterms_a, nterms_b)
+                                      : step_launch<8, NSC, false>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1, nterms_a, nterms_b);
             g_path_counts[PINN_PATH_FUSED_REGISTERS] += 2;      // (both families of the step)
             return 1;
         } else {
             return 0;
         }
     }
+    static int wave_step(const Call& c, const Call& d, const AdamEpilogue& adam, int* out) { return step<4>(c, d, adam, out, 7, c.net.nout); }
+    static int plate_step(const Call& c, const Call& d, const AdamEpilogue& adam, int* out) { return step<5>(c, d, adam, out, 5, 2); }
 
     // The depths the fused kernel is compiled for (the ones the reference's scripts use): the rule of try_fused AND of pinn_path_for.
     template <int NS>
@@ -780,7 +790,7 @@ struct Host {
     }
 
     static const Impl* impl() {
-        static const Impl I = {&path_for, &wave_step, &wave_loss_grad, &data_loss_grad, &fields, &ws_bytes,
+        static const Impl I = {&path_for, &wave_step, &plate_step, &wave_loss_grad, &data_loss_grad, &fields, &ws_bytes,
                                &plate_loss_grad, &traction_loss_grad, &stream_loss_grad, &streams,
                                &nc3d_loss_grad, &nc3d_data_loss_grad, &nc3d_fields};
         return &I;

@@ -247,6 +247,29 @@ class HipEngine:
                                    self._mode(False), self._ws_ptr, self.ws_bytes, self._stream())
         return loss_out[:5], grad_out
 
+    def plate_step(self, params, x, y, t, lb, ub, normalize, frozen, term_weights, hole, grad_out, loss_out, hole_loss_out, E=20.0, mu=0.25, rho=1.0,
+                   accumulate: bool = False, adam=None):
+        """The plate's step in one library call (pinn_plate2d_step): collocation set (frozen: [2, 5, 5, n]) + hole-traction set
+        ``hole = (x, y, t, aux[12, n], weights[2])`` -> gradient in ``grad_out``, sums in ``loss_out`` / ``hole_loss_out``, and with
+        ``adam = (m, v, lr, step[, beta1, beta2, eps])`` the TF1 Adam update of ``params`` in the same final launch."""
+        n = x.numel()
+        for v in (x, y, t):
+            self._chk(v, n)
+        self._chk(params, self.n_params)
+        self._chk(frozen, 50 * n)
+        hx, hy, ht, haux, hw = hole
+        hn = hx.numel()
+        self._chk(haux, 12 * hn)
+        ad = None
+        if adam is not None:
+            m, v, lr, step = adam[:4]
+            b1, b2, eps = (list(adam[4:]) + [0.9, 0.999, 1e-8][len(adam) - 4:])[:3]
+            ad = (m.data_ptr(), v.data_ptr(), lr, b1, b2, eps, step)
+        self.lib.plate2d_step(params.data_ptr(), self.layers, x.data_ptr(), y.data_ptr(), t.data_ptr(), n, lb, ub, normalize, frozen.data_ptr(), E, mu, rho,
+                              term_weights, loss_out.data_ptr(), hx.data_ptr(), hy.data_ptr(), ht.data_ptr(), hn, haux.data_ptr(), hw, hole_loss_out.data_ptr(),
+                              grad_out.data_ptr(), accumulate, ad, self._mode(False), self._ws_ptr, self.ws_bytes, self._stream())
+        return grad_out
+
     def traction_loss_grad(self, params, x, y, t, lb, ub, normalize, aux, weights, grad_out=None, accumulate=False, loss_out=None, packed=False):
         """aux: [12, n] = D values, P values, nx, ny.  Returns ((sum tx^2, sum ty^2), grad)."""
         n = x.numel()

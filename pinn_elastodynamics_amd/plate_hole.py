@@ -231,13 +231,24 @@ class PINN(NetApi):
     callback_part = callback
 
     # ---- main stage: loss = 10 (loss_f_uv + loss_f_s + loss_HOLE) wrt the uv net (PLATE:187-193,217) -----------------------
-    def _loss_and_grad(self):
+    def _loss_and_grad(self, adam=None):
+        """self._buf = [grad | 8 collocation sums | 8 hole sums], all-reduced.  ``adam = (learning_rate, step)``: where the whole evaluation is one
+        library call (engine.plate_step) and no collective stands in between, the Adam update rides in its reduction: returns True then."""
         P = self.theta["uv"].numel()
         buf, eng = self._buf, self.eng["uv"]
-        buf[P:].zero_()
         grad = buf[:P]
-        wrote = False
         x, y, t = self._collo
+        hx, hy, ht = self._hole
+        if x.numel() and hx.numel() and hasattr(eng, "plate_step"):
+            fold = adam is not None and not self._reduce
+            eng.plate_step(self.theta["uv"], x, y, t, self.lb, self.ub, False, self._frozen_collo, [10.0 / self.n_collo] * 5,
+                           (hx, hy, ht, self._aux_hole, [10.0 / self.n_hole] * 2), grad, buf[P:P + 8], buf[P + 8:P + 16], self.E, self.mu, self.rho,
+                           adam=(self.adam_m, self.adam_v, adam[0], adam[1]) if fold else None)
+            if self._reduce:
+                all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None))
+            return fold
+        buf[P:].zero_()
+        wrote = False
         if x.numel():
             tw = [10.0 / self.n_collo] * 5
             eng.plate_loss_grad(self.theta["uv"], x, y, t, self.lb, self.ub, False, self._frozen_collo, tw, self.E, self.mu, self.rho,
@@ -275,10 +286,11 @@ class PINN(NetApi):
             evaluate_with_finite_gradient(self.eng["uv"], probe, P, self._shift_state)
             self._shift_state["probed"] = True
         for it in range(iter):
-            self._loss_and_grad()
-            rec[it].copy_(self._buf[P:])
             self.adam_t += 1
-            self.eng["uv"].adam_step(self.theta["uv"], self.adam_m, self.adam_v, self._buf[:P], learning_rate, self.adam_t)
+            updated = self._loss_and_grad(adam=(learning_rate, self.adam_t))
+            rec[it].copy_(self._buf[P:])
+            if not updated:
+                self.eng["uv"].adam_step(self.theta["uv"], self.adam_m, self.adam_v, self._buf[:P], learning_rate, self.adam_t)
             if self.verbose and it % 10 == 0 and self.rank == 0:
                 print('It: %d, Loss: %.6e' % (it, self._terms(rec[it].detach().cpu().numpy())["loss"]))
         sums = rec.detach().cpu().numpy()

@@ -787,3 +787,55 @@ def test_step_call_several_steps_per_workgroup_and_fallbacks_emulated(emu):
         assert a["counts"][path] >= 2 and a["counts"]["fused-registers"] == 0, a["counts"]
         for key in ("loss", "grad", "theta", "m", "v"):
             assert np.array_equal(a[key], b[key]), (layers, prec, key)
+
+
+@pytest.mark.parametrize("lN,n,nh", [([3] + 8 * [64] + [5], 150, 70), ([3] + 4 * [32] + [5], 300, 40)])
+def test_plate_step_call_is_the_separate_calls_bit_for_bit_emulated(emu, lN, n, nh):
+    """pinn_plate2d_step: the plate's five-stream collocation set and its hole-traction set in one launch (fused_step_kernel<..., NSC = 5>), one
+    reduction with Adam -- identical bits to pinn_plate2d_loss_grad + pinn_plate2d_traction_loss_grad + pinn_adam_step, and the oracle's numbers."""
+    from oracle import plate_oracle as pl
+    prec, LBp, UBp = "f16x3", [0, 0, 0], [0.5, 0.5, 10]
+    lD = [3, 10, 10, 5]
+    rng = np.random.default_rng(4)
+
+    def mk(l):
+        W, b = po.xavier_init(l, rng)
+        return po.pack_params(W, [0.2 * rng.standard_normal(x.shape) for x in b])
+
+    fN, fD, fP = mk(lN), mk(lD), mk(lD)
+    X = np.stack([0.12 + 0.38 * rng.random(n), 0.12 + 0.38 * rng.random(n), 10 * rng.random(n)], 1)
+    th = rng.random(nh) * np.pi / 2
+    H = np.stack([0.1 * np.cos(th), 0.1 * np.sin(th), rng.random(nh) * 10], 1)
+    frozen = np.ascontiguousarray(np.stack([pl.net_streams(f, lD, X[:, 0], X[:, 1], X[:, 2]) for f in (fD, fP)]).astype(np.float32))       # [2][5][5][n]
+    DH, PH = pl.net_streams(fD, lD, H[:, 0], H[:, 1], H[:, 2])[0], pl.net_streams(fP, lD, H[:, 0], H[:, 1], H[:, 2])[0]
+    aux = np.ascontiguousarray(np.concatenate([DH, PH, (-H[:, 0] / 0.1)[None], (-H[:, 1] / 0.1)[None]]).astype(np.float32))
+    x, y, t = (X[:, k].astype(np.float32).copy() for k in range(3))
+    hx, hy, ht = (H[:, k].astype(np.float32).copy() for k in range(3))
+    tw, hw = [10.0 / n] * 5, [10.0 / nh] * 2
+    wsb = emu.workspace_bytes(lN, 1 << 12, prec)
+    emu.set_fused(True)
+    out = {}
+    for mode in ("step", "calls"):
+        ws = aligned(wsb)
+        theta = fN.astype(np.float32)
+        m1, v1 = np.full(theta.size, 0.01, np.float32), np.full(theta.size, 0.02, np.float32)
+        loss, hloss, grad = np.full(8, np.nan, np.float32), np.full(8, np.nan, np.float32), np.full(theta.size, np.nan, np.float32)
+        emu.path_counts(reset=True)
+        if mode == "step":
+            emu.plate2d_step(theta.ctypes.data, lN, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, frozen.ctypes.data, 20.0, 0.25, 1.0, tw,
+                             loss.ctypes.data, hx.ctypes.data, hy.ctypes.data, ht.ctypes.data, nh, aux.ctypes.data, hw, hloss.ctypes.data, grad.ctypes.data,
+                             False, (m1.ctypes.data, v1.ctypes.data, 1e-3, 0.9, 0.999, 1e-8, 2), prec, ws.ctypes.data, wsb)
+        else:
+            emu.plate2d_loss_grad(theta.ctypes.data, lN, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, frozen.ctypes.data, 20.0, 0.25, 1.0,
+                                  tw, loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+            emu.plate2d_traction_loss_grad(theta.ctypes.data, lN, hx.ctypes.data, hy.ctypes.data, ht.ctypes.data, nh, LBp, UBp, False, aux.ctypes.data, hw,
+                                           hloss.ctypes.data, grad.ctypes.data, True, prec, ws.ctypes.data, wsb)
+            emu.adam_step(theta.ctypes.data, m1.ctypes.data, v1.ctypes.data, grad.ctypes.data, theta.size, 1e-3, 2)
+        out[mode] = dict(theta=theta, m=m1, v=v1, loss=loss[:5].copy(), hloss=hloss[:2].copy(), grad=grad, counts=emu.path_counts(reset=True))
+    a, b = out["step"], out["calls"]
+    assert a["counts"]["fused-registers"] == 2 and b["counts"]["fused-registers"] == 2, (a["counts"], b["counts"])
+    for key in ("loss", "hloss", "grad", "theta", "m", "v"):
+        assert np.array_equal(a[key], b[key]), key
+    ss, g = pl.plate_loss_grad(fN, lN, X[:, 0], X[:, 1], X[:, 2], frozen[0].astype(np.float64), frozen[1].astype(np.float64), term_weights=np.asarray(tw))[:2]
+    ssh, gh = pl.traction_loss_grad(fN, lN, H[:, 0], H[:, 1], H[:, 2], DH, PH, weight=10.0 / nh)
+    assert rel(a["loss"], ss) < 5e-6 and rel(a["hloss"], ssh) < 5e-6 and rel(a["grad"], g + gh) < 3e-4
