@@ -163,7 +163,7 @@ def traffic_from_profiles(name):
                     "ea_read_bytes": pm.get("ea_read_bytes_per_launch"), "ea_write_bytes": pm.get("ea_write_bytes_per_launch"),
                     "note": "L2<->fabric request bytes (FETCH_SIZE x 2 per the gfx950 correction + WRITE_SIZE; ea_*: TCC_EA0 request counters of the same "
                             "passes at 64 B per request -- a read request fetches a 128-byte line); the kernel's own parked states and in-memory "
-                            "weight-gradient sums (DESIGN.md section 6); MALL vs HBM is not observable from the L2 (profiles/README.md)"}
+                            "weight-gradient sums (DESIGN_HISTORY.md section 6); MALL vs HBM is not observable from the L2 (profiles/README.md)"}
         except Exception:
             continue
     return None
@@ -491,7 +491,7 @@ def main():
                                "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; measured limiter of the LDS-operand layouts: the bytes "
-                                       "of parked states and in-memory weight-gradient sums through L2 (DESIGN.md section 6).  traffic not measured in this run"}
+                                       "of parked states and in-memory weight-gradient sums through L2 (DESIGN_HISTORY.md section 6).  traffic not measured in this run"}
             out["kernel_ms_per_step"] = acc
         else:
             # two-kernel path: the step is a sequence of chain + weight-gradient launches over workspace passes; report the whole step
@@ -517,7 +517,7 @@ def main():
                     modes[mode] = {"value": n_global * 20 / (time.perf_counter() - t1), "unit": "collocation-points/s",
                                    "note": "fields off by 5-10 % at trained weights (DESIGN.md section 3): not parity-grade" if mode == "bf16" else
                                            ("states parked as fp16 only (PINN_FLAG_STATE_FP16): gradient at trained weights 5e-3 off in the first-layer "
-                                            "blocks by cancellation (fp32: 2e-4), DESIGN.md section 6: not parity-grade" if fast else "")}
+                                            "blocks by cancellation (fp32: 2e-4), DESIGN_HISTORY.md section 6: not parity-grade" if fast else "")}
                     del m2, e2
                 out["other_precision_modes"] = modes
                 if not args.no_small_config and args.width == 64:

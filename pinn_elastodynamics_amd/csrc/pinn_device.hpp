@@ -87,7 +87,7 @@ __device__ __forceinline__ void split2(float a, float b, uint32_t& hi, uint32_t&
 // fp16 on the GPU: the same arithmetic pinned to  v_cvt_pk_f16_f32 ; v_fma_mixlo_f16 ; v_fma_mixhi_f16  (the mixed-precision
 // FMA reads the fp16 hi part directly and writes the rounded fp16 low part into its half of the destination).  Left to
 // itself the compiler SLP-vectorises the two FMAs into v_pk_fma_f32 and pays two v_cvt_f32_f16 plus a second v_cvt_pk for
-// them; the split is 18 % of the fused kernel's time (measured by deleting it).
+// them; the split is 18 % of the fused kernel's time (measured by deleting it, DESIGN_HISTORY.md section 6).
 template <>
 __device__ __forceinline__ void split2<OpF16>(float a, float b, uint32_t& hi, uint32_t& lo) {
     const uint32_t h = pack2<OpF16>(a, b);
@@ -314,7 +314,7 @@ struct FragIndex {
 //   S panels: layer 0 has 16 rows (the inputs), layers 1..nl have WIDTH rows (hidden states h_l)
 //   Z panels: layers 0..nl-1 have WIDTH rows (adjoints of the pre-activations), layer nl has 16 rows
 // Both keep the high and the scaled low part: this path is the accurate one (gradient 2e-7 from the float64 oracle at fresh weights;
-// the fused kernel parks its state as high parts only and trades a 1/sqrt(points) rounding noise for LDS room).
+// the fused kernel parks its state as high parts only and trades a 1/sqrt(points) rounding noise for LDS room, DESIGN_HISTORY.md section 6).
 template <int WIDTH, int NB, int NS, int NP>
 struct PanelGeom {
     static constexpr int TP = 16 * NB;

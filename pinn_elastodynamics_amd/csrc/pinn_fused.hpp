@@ -165,7 +165,7 @@ struct Fused {
     // LDSOP keeps the state images with BOTH parts (records ((s * KS + kk) * NP + p), the operand layout): the chain wave's reverse
     // reads its state in full precision.  (At the reference's trained weights the activation reverse amplifies a 2^-12 rounding of
     // the state ~20x by cancellation -- first-layer gradient blocks 5e-3 off against 2e-4 for fp32 --, while rounding the state
-    // only as the weight gradient's operand costs nothing: tests/test_gpu_parity.py)
+    // only as the weight gradient's operand costs nothing: tests/test_gpu_parity.py, DESIGN_HISTORY.md section 6.)
     static constexpr int SP = LDSOP ? NP : 1;                 // parts per state-image record group
     static constexpr int IMG_B = NS * KS * SP * 1024;
     // "SLDS": where S_0..S_NL of a tile fit in LDS (NL+1 slots: every 1-stream case, and the 4-stream 4x32 net) nothing is parked in
@@ -234,7 +234,7 @@ struct Fused {
     // per tile: parked states S_1..S_{NL-1}.  Narrow layouts: [high-part images | low-part images]: the high parts return to LDS by
     // LDS-DMA (they are also the weight gradient's operand), the (unscaled) low parts are read back by the chain wave itself, block by
     // block, so that the activation reverse sees the state in full precision.  (With fp16-rounded states the gradient at the
-    // reference's trained weights is 5e-3 off in the first-layer blocks -- fp32: 2e-4 --, amplified by cancellation)
+    // reference's trained weights is 5e-3 off in the first-layer blocks -- fp32: 2e-4 --, amplified by cancellation; DESIGN_HISTORY.md section 6.)
     static constexpr bool STATE_LO = !LDSOP && NP == 2 && !FASTSTATE;
     static constexpr unsigned SCRATCH_LO = (unsigned)((NL - 1) * IMG_B);          // byte offset of the low-part images
     // LO8 (round 4, the narrow collocation kernels -- wave head and plate head -- of padded width 64): the parked LOW parts travel as ONE BYTE per value -- the top byte of the fp16 low
@@ -243,7 +243,7 @@ struct Fused {
     // against float64: exact states 8.5e-7, fp16 high parts only 7.7e-5, + 3 significant bits of low part 3.1e-6, + 8 bits 9.2e-7): a few bits
     // carry it.  Half the low-part bytes each way, one 16-byte store per stream and layer instead of two, four 16-byte loads per layer (requested
     // with the layer's first fragments) instead of sixteen 8-byte ones.  The launch is sensitive to its bytes through the vector-memory path more
-    // than to the instructions that move them (DESIGN section 6 "Round 4"); the low image of a layer is then NS records: (stream) -> 16 bytes per
+    // than to the instructions that move them (DESIGN_HISTORY.md section 6 "Round 4"); the low image of a layer is then NS records: (stream) -> 16 bytes per
     // lane = the four blocks' four values each.
     static constexpr bool LO8 = PINN_LO8_ENABLED && Op::TOP_BYTE_IS_FLOAT && !LDSOP && !SLDS && WB == 4 && NP == 2 && !FASTSTATE && KS == 2;      // (four- and five-stream narrow layouts)
     // LO_FROM (round 5, the per-layer low-part policy): parked states S_2 .. S_{LO_FROM-1} travel WITHOUT a low-part record -- the activation reverse

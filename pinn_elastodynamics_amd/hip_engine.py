@@ -32,7 +32,7 @@ class HipEngine:
         self.layers = [int(v) for v in layers]
         self.precision = precision
         # fast_state: PINN_FLAG_STATE_FP16 -- the fused 8-layer collocation kernel parks its states as fp16 only: 17 % faster, but the
-        # gradient at trained weights loses accuracy by cancellation.  Off by default.
+        # gradient at trained weights loses accuracy by cancellation (DESIGN_HISTORY.md section 6).  Off by default.
         self.fast_state = bool(fast_state)
         self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
         self.n_params = param_count(self.layers)

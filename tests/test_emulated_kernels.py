@@ -284,7 +284,7 @@ def test_emulated_plate_fused(emu, lN, n):
         emu.plate2d_loss_grad(pN.ctypes.data, lN, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LBp, UBp, False, frozen.ctypes.data, 20.0, 0.25, 1.0,
                               tw, loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
         res[fused] = (loss[:5].copy(), grad.copy())
-        # the fused kernel parks the layer states as fp16 high parts: a 2^-12 rounding noise per state element
+        # the fused kernel parks the layer states as fp16 high parts (DESIGN_HISTORY.md section 6): a 2^-12 rounding noise per state element
         # that averages out as 1/sqrt(points) in the gradient -- 3e-5 at ~100 points, 5e-6 at 4096 (GPU tests use real sizes)
         # (the width-96 layout keeps both state parts in LDS: the two-kernel path's accuracy)
         assert rel(loss[:5], ss) < 3e-6 and rel(grad, g) < (1e-4 if fused and lN[1] <= 64 else 2e-6), fused

@@ -38,8 +38,10 @@ def test_bench_line(cfg, extra):
     # the events runs after the timed ones -- the by-construction bound is the next line, this one allows that block 3 % of clock drift)
     # (round 5: the wave step is ONE launch for all point sets -- 99 % of the step --, and the two events around a bracketed launch cost it
     # 0.02-0.03 ms that the unbracketed steps of the timed blocks do not pay: an absolute allowance, which at full size is 0.6 % of the launch)
-    assert r["avg_launch_ms"] > 0 and r["avg_launch_ms"] <= (d["ms_per_step"] + 0.04 if cfg == "wave" else 1.03 * d["ms_per_step"]) and r["launches_timed"] >= 4
-    assert r["avg_launch_ms"] <= r["timed_block_ms_per_step"]      # by construction: the launches are a part of that block's steps
+    # (the plate's step is one launch as well since round 5; nc3d: the collocation launch is 98-99 % of the step and the block that carries
+    # the events runs after the timed ones -- 3 % of clock drift allowed on top)
+    assert r["avg_launch_ms"] > 0 and r["avg_launch_ms"] <= (d["ms_per_step"] if cfg == "wave" else 1.03 * d["ms_per_step"]) + 0.04 and r["launches_timed"] >= 4
+    assert r["avg_launch_ms"] <= r["timed_block_ms_per_step"] + 0.04      # by construction: the launches are a part of that block's steps (+ the events' own cost)
     # round 5: the line carries the clock the dominant kernel ran at (power-limited part: a line without it cannot tell a code change from a
     # box), and for the wave step a decomposition that adds up -- events on every 8th step only, so the bracketed block is the timed loop
     assert d["shader_clock_ghz"] is not None and 0.8 < d["shader_clock_ghz"] < 2.6, d["shader_clock_ghz"]
