@@ -427,7 +427,7 @@ def main():
             tflops = kflop * pts_per_rank / (acc["chain"] * 1e-3) / 1e12
             out["roofline"] = {"kernel": "fused_wave_kernel (forward + reverse chain + weight gradient)" if fused else "chain_kernel (forward + reverse chain)",
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
-                               "traffic": None, "traffic_from_profiles": traffic_from_profiles({64: "fused", 80: "wide80", 100: "wide100"}.get(args.width, "none")) if fused and args.precision == "f16x3" else None,
+                               "traffic": None, "traffic_measured_in_this_run": False, "traffic_from_profiles": traffic_from_profiles({64: "fused", 80: "wide80", 100: "wide100"}.get(args.width, "none")) if fused and args.precision == "f16x3" else None,
                                "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch, "algorithmic_flop_per_point": kflop,
                                "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "launch_ms_min_max": [float(collo_ms.min()), float(collo_ms.max())] if collo_ms.size else None,
                                "side_sets_launch_ms": float(side_ms.mean()) if side_ms.size else None,
@@ -454,7 +454,7 @@ def main():
             tflops = flop_pt * pts_per_rank / (acc["chain"] * 1e-3) / 1e12 if fused else 0.0
             out["roofline"] = {"kernel": "fused_wave_kernel<..., NS = 5> (forward with the second time derivative + plate head + reverse chain + weight gradient)",
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
-                               "traffic": None, "traffic_from_profiles": traffic_from_profiles("plate") if fused and args.precision == "f16x3" and args.width == 64 else None,
+                               "traffic": None, "traffic_measured_in_this_run": False, "traffic_from_profiles": traffic_from_profiles({64: "plate", 70: "plate70"}.get(args.width, "none")) if fused and args.precision == "f16x3" else None,
                                "launches_per_step": 1, "avg_launch_ms": acc["chain"], "algorithmic_flop_per_point": flop_pt,
                                "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
@@ -486,7 +486,7 @@ def main():
             out["roofline"] = {"kernel": "fused_wave_kernel<OpF16, 3, 128, 10, 5, false, 4> (3-D: forward with four tangent streams + 12-residual head + reverse "
                                          "chain + weight gradient)" if fused else "chain_kernel + wgrad_kernel (two-kernel path)",
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
-                               "traffic": None, "traffic_from_profiles": traffic_from_profiles("nc3d") if fused else None,
+                               "traffic": None, "traffic_measured_in_this_run": False, "traffic_from_profiles": traffic_from_profiles("nc3d") if fused else None,
                                "launches_per_step": n_launch, "avg_launch_ms": t_ms / n_launch, "algorithmic_flop_per_point": flop_pt,
                                "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
@@ -497,7 +497,7 @@ def main():
             # two-kernel path: the step is a sequence of chain + weight-gradient launches over workspace passes; report the whole step
             tflops = flop_pt * pts_per_rank / (1e-3 * out["ms_per_step"]) / 1e12
             out["roofline"] = {"kernel": "chain_kernel + wgrad_kernel (whole step, two-kernel path)", "bound": "hbm (spill panels) / mfma", "achieved": tflops,
-                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS, "traffic": None,
+                               "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS, "traffic": None, "traffic_measured_in_this_run": False,
                                "issued_mfma_tflops": tflops * issued, "algorithmic_flop_per_point": flop_pt,
                                "note": "whole-step algorithmic flops / wall time per step (HIP work of a step is back-to-back on one stream); this path "
                                        "spills the per-layer state and adjoint panels to HBM and is bound by that traffic, not by the matrix pipe"}

@@ -107,7 +107,18 @@ class NetApi:
         if weights is None:
             eng, theta = self.engine, self._current_theta()
         else:
+            if biases is None or len(biases) != len(weights):
+                raise ValueError("neural_net(X, weights, biases): one bias per weight matrix is required when weights are given (INF:188-199)")
             layers = [int(np.asarray(weights[0]).shape[0])] + [int(np.asarray(w).shape[1]) for w in weights]
-            eng = self._engine_for(layers)
+            d_in = int(self.engine.layers[0])
+            if layers[0] != d_in or X.ndim != 2 or X.shape[1] != d_in:
+                # (the value-stream kernels behind this class take its own input columns: 3 = (x, y, t), the 3-D class 4)
+                raise ValueError(f"neural_net: this model's kernels evaluate nets on {d_in} input columns; got X {tuple(X.shape)} and a first weight "
+                                 f"matrix with {layers[0]} rows")
+            try:
+                eng = self._engine_for(layers)
+            except Exception as e:      # unsupported width / output count of the sibling net: say which
+                raise ValueError(f"neural_net: no kernel variant for a net of layers {layers} (hidden width <= 160, one width for all hidden layers, "
+                                 f"<= 8 outputs -- 16 for the 4-input class): {e}") from e
             theta = torch.from_numpy(pack_params(weights, biases)).to(eng.device)
         return self._net_fields(eng, theta, X).T.detach().cpu().numpy()

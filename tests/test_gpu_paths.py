@@ -153,3 +153,24 @@ def test_small_batch_precision_statement_trained_weights(dev, golden_dir, n):
                 worst = max(worst, ef / bound)
                 assert ef <= bound, (n, off, l, k, ef, e2, e32)
     print(f"n={n}: worst fused error / bound = {worst:.2f}")
+
+
+def test_neural_net_on_a_net_of_another_output_count(dev):
+    """round-4 advisor: neural_net(X, weights, biases) with weights of other layer sizes goes through the model's own value-stream call; a net
+    with another OUTPUT COUNT than the model's (the plate's 4 x 20 distance net has 5) must come out right, and bad arguments say what is wrong"""
+    from pinn_elastodynamics_amd.elastic_wave import DeepHPM
+    rng = np.random.default_rng(0)
+    Collo = po.collocation_points(2000, LB, UB, rng)
+    m = DeepHPM(Collo, po.ricker_source_set(n_pt=8, n_time=8), po.ic_grid(num=8), np.zeros((0, 3)), net(4, 32), LB, UB, verbose=False)
+    layers = [3, 20, 20, 20, 5]
+    Ws, bs, _ = make_net(layers, 5)
+    X = Collo[:300]
+    Y = m.neural_net(X, [w.astype(np.float32) for w in Ws], [b.astype(np.float32) for b in bs])
+    Yo, _, _ = po.mlp_forward_tangent(X, Ws, bs, LB, UB, True, n_tangent=0)
+    assert Y.shape == (300, 5) and rel(Y, Yo) < 1e-5
+    with pytest.raises(ValueError, match="bias"):
+        m.neural_net(X, Ws, None)
+    with pytest.raises(ValueError, match="input columns"):
+        m.neural_net(X[:, :2], [np.zeros((2, 8)), np.zeros((8, 7))], [np.zeros((1, 8)), np.zeros((1, 7))])
+    with pytest.raises(ValueError, match="no kernel variant"):
+        m.neural_net(X, [np.zeros((3, 200)), np.zeros((200, 7))], [np.zeros((1, 200)), np.zeros((1, 7))])
