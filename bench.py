@@ -367,8 +367,19 @@ def main():
     side_ms = ring_ms[ring_streams == 1]
     st = stamps.cpu().numpy()
     launch_cycles = int(st[125] - st[124])                 # the LAST collocation launch of the block (every launch overwrites the slots)
-    # its duration: the block's last recorded launch is not necessarily the last launch; the mean of the recorded ones is the estimate
-    shader_clock_ghz = (launch_cycles / (float(collo_ms.mean()) * 1e-3) / 1e9) if collo_ms.size and launch_cycles > 0 else None
+    # The same workgroup stamps the device's constant-rate wall clock beside the cycle counter: the launch's duration and the clock it ran at
+    # then come from the kernel itself, without the 0.02-0.03 ms the two host events around a bracketed launch add to it.  (Workgroup 0's
+    # lifetime: the launch minus its dispatch latency and the last stragglers, within ~1 %.)  Without a wall-clock rate: cycles over the mean
+    # event duration of the recorded launches.
+    wall_khz = int(eng.lib.lib.pinn_debug_wall_clock_khz())
+    wall_ticks = int(st[121] - st[120])
+    launch_ms_device_clock = (1e3 * wall_ticks / (wall_khz * 1e3)) if wall_khz > 0 and wall_ticks > 0 else None
+    if launch_ms_device_clock is not None and collo_ms.size and not (0.9 < launch_ms_device_clock / float(collo_ms.mean()) < 1.05):
+        launch_ms_device_clock = None                      # (a rate that does not fit the events: do not quote it)
+    if launch_cycles > 0 and launch_ms_device_clock is not None:
+        shader_clock_ghz = launch_cycles / (launch_ms_device_clock * 1e-3) / 1e9
+    else:
+        shader_clock_ghz = (launch_cycles / (float(collo_ms.mean()) * 1e-3) / 1e9) if collo_ms.size and launch_cycles > 0 else None
     allreduce_ms = None
     if getattr(model, "collective_events", None):
         evs = model.collective_events
@@ -390,6 +401,10 @@ def main():
         "shader_clock_note": "shader cycles of workgroup 0 over one collocation launch (in-kernel stamps) / the mean HIP-event duration of the launches "
                              "recorded in the same block: the clock the dominant kernel ran at on THIS box -- it is power-limited, and box-to-box "
                              "differences of ms_per_step (+-2.5 %) follow it",
+        "launch_ms_device_clock": launch_ms_device_clock,
+        "launch_ms_device_clock_note": "duration of the block's last collocation launch as workgroup 0 saw it: device wall-clock ticks (constant rate, "
+                                       "hipDeviceAttributeWallClockRate) between its first and its last step; no host event in it -- roofline.avg_launch_ms (events) "
+                                       "is 0.02-0.03 ms longer; roofline.frac stays on the events (conservative), roofline.frac_device_clock uses this",
         "allreduce_ms": allreduce_ms,
         "rank_share": share if share > 1 else None,
     }
@@ -541,6 +556,9 @@ def main():
                     out["cpu_baseline"] = cpu_baseline_plate(c)
                 else:
                     out["cpu_baseline"] = cpu_baseline([3] + 8 * [args.width] + [7], 32768, 3, f"8x{args.width}")
+    if rank == 0 and "roofline" in out and launch_ms_device_clock is not None and out["roofline"].get("algorithmic_flop_per_point"):
+        out["roofline"]["frac_device_clock"] = (out["roofline"]["algorithmic_flop_per_point"] * pts_per_rank / (launch_ms_device_clock * 1e-3) / 1e12
+                                                / MFMA_PEAK_TFLOPS / max(1, out["roofline"].get("launches_per_step", 1)))
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()          # rank 0 is still profiling its kernel: leave together
         torch.distributed.destroy_process_group()

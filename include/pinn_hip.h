@@ -335,6 +335,9 @@ int pinn_debug_set_fused(int enable);
 /* Profiling hook (process-wide): device buffer of 128 uint64 that the fused kernel fills with shader-clock
  * stamps of its phases (workgroup 0 only); NULL turns it off. */
 void pinn_debug_set_stamp_buffer(void* device_u64x128);
+/* Rate in kHz of the device wall clock the launch-long stamps use (slots 120 / 121 of the stamp buffer: wall-clock ticks, 124 / 125: shader cycles of
+ * workgroup 0 around all of its steps -- a launch's duration and the clock it ran at, measured by the kernel itself); 0 if unknown. */
+int pinn_debug_wall_clock_khz(void);
 /* Profiling hook (process-wide): host array of 4 floats; while set, every loss+gradient call brackets its kernels with HIP
  * events on the call's stream, synchronises, and writes milliseconds {repack, chain (or the whole fused kernel), weight gradient,
  * reductions} of that call (what pinn_wave2d_loss_grad_profile does for one entry point, here for all of them: bench.py's

@@ -120,6 +120,8 @@ class PinnLib:
         L.pinn_debug_path_counts.restype = None
         L.pinn_debug_profile_ring_stride.argtypes = [i32]
         L.pinn_debug_profile_ring_stride.restype = None
+        L.pinn_debug_wall_clock_khz.argtypes = []
+        L.pinn_debug_wall_clock_khz.restype = i32
         L.pinn_debug_set_stamp_buffer.argtypes = [vp]
         L.pinn_debug_set_stamp_buffer.restype = None
         L.pinn_debug_profile_ring_arm.argtypes = [i32]

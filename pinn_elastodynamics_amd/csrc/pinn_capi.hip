@@ -87,6 +87,15 @@ int pinn_abi_version(void) { return 1; }
 
 float pinn_fused_weight_limit(void) { return FUSED_OPERAND_MAX / FUSED_WEIGHT_SCALE; }
 
+int pinn_debug_wall_clock_khz(void) {
+#if defined(PINN_SIMT_EMULATOR)
+    return 0;
+#else
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) return 0;
+    return khz;
+#endif
+}
 void pinn_debug_set_stamp_buffer(void* device_u64x128) { g_dbg_stamps = static_cast<unsigned long long*>(device_u64x128); }
 void pinn_debug_set_profile_buffer(float* host_ms4) { g_prof_ms = host_ms4; }
 

@@ -105,6 +105,16 @@ __device__ __forceinline__ unsigned in_loop(unsigned v) {
 __device__ __forceinline__ void fused_stamp(const FusedArgs& a, bool who, int slot) {
     if (a.dbg != nullptr && who) a.dbg[slot] = __builtin_readcyclecounter();
 }
+// the constant-rate wall clock of the device (hipDeviceAttributeWallClockRate; 100 MHz): with the shader-cycle stamp beside it, the launch's
+// duration AND its clock come from the kernel itself -- no host event in the measurement (the two events around a bracketed launch cost it
+// 0.02-0.03 ms)
+__device__ __forceinline__ void fused_stamp_wall(const FusedArgs& a, bool who, int slot) {
+#if defined(__AMDGCN__)
+    if (a.dbg != nullptr && who) a.dbg[slot] = (unsigned long long)wall_clock64();
+#else
+    if (a.dbg != nullptr && who) a.dbg[slot] = 0ull;
+#endif
+}
 
 // NS = 4: value + three tangent streams, residual head of net_f_sig (the collocation set).  NS = 1: value stream only, head
 // sum_o w_o (Y_o - target_o)^2 -- the side sets loss_IC / loss_SRC / loss_NB / loss_FIX (INF:111-118, CONF:145-146).
@@ -2457,11 +2467,12 @@ struct Fused {
                 for (int i = 0; i < LT; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, x.scr, x.lane16 >> 2, LSUM_OFF + i * 256, 0);
             }
         }
-        // launch-long stamps of workgroup 0 (slots 124 / 125; the one-stream launches 122 / 123): shader cycles of the whole launch, which over its
-        // HIP-event duration are the clock the launch ran at (bench.py: shader_clock_ghz -- the kernel is power-limited, and a bench line without
-        // its clock cannot tell a code change from a box)
+        // launch-long stamps of workgroup 0: shader cycles (slots 124 / 125; the one-stream part 122 / 123) and the device's constant-rate wall clock
+        // (120 / 121; 118 / 119) around all of its steps: duration = wall ticks / rate, clock = cycles / duration (bench.py: shader_clock_ghz,
+        // launch_ms_device_clock -- the kernel is power-limited, and a bench line without its clock cannot tell a code change from a box)
         const bool launch_tracer = x.tracer;
         fused_stamp(a, launch_tracer, NS == 1 ? 122 : 124);
+        fused_stamp_wall(a, launch_tracer, NS == 1 ? 118 : 120);
         for (long step = fused_bid(a); step < a.nsteps; step += a.grid) {
             float xin[4];
             bool valid;
@@ -2520,6 +2531,7 @@ struct Fused {
             }
         }
         fused_stamp(a, launch_tracer, NS == 1 ? 123 : 125);
+        fused_stamp_wall(a, launch_tracer, NS == 1 ? 119 : 121);
         if constexpr (LSUM_MEM) {
             if (half == 0) {
 #pragma unroll
