@@ -191,6 +191,8 @@ def main():
                     "with --always-reduce the collective branch included; `value` counts this rank's points")
     ap.add_argument("--collective", default="rccl", choices=["rccl", "p2p"], help="the step's all-reduce: torch.distributed (RCCL under nccl; default) or the "
                     "library's one-shot all-reduce over IPC-mapped peer buffers with Adam in the same kernel (pinn_p2p_*; wave config)")
+    ap.add_argument("--no-step-call", action="store_true", help="wave config: make the step's library calls one by one (collocation kernel, side-set kernel, two "
+                    "reductions, Adam: the round-4 sequence) instead of pinn_wave2d_step -- the same bits; for A / B timing on one box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-config", action="store_true")
     ap.add_argument("--extra-modes", default="bf16,f16x3_fp16state",
@@ -263,7 +265,7 @@ def main():
         SRC, IC = ricker_source(), ic_grid()
         eng = HipEngine(layers, precision=args.precision, device=dev, max_points=args.chunk_points)
         model = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), layers, LB, UB, case="infinite", engine=eng, seed=1111, verbose=False,
-                        always_reduce=args.always_reduce, shard_as=(0, share) if share > 1 else None, collective=args.collective)
+                        always_reduce=args.always_reduce, shard_as=(0, share) if share > 1 else None, collective=args.collective, step_call=not args.no_step_call)
         step = lambda k: model.train(k, 1e-3, 1)
         side_note = (f"IC {model._sides['IC'][0].numel()} + SRC {model._sides['SRC'][0].numel()} (rank 0's 1/{share} share of IC 10201 / SRC 70400, of {n_global} collocation pts)"
                      if share > 1 else "IC 10201 + SRC 70400")
@@ -367,19 +369,16 @@ def main():
     side_ms = ring_ms[ring_streams == 1]
     st = stamps.cpu().numpy()
     launch_cycles = int(st[125] - st[124])                 # the LAST collocation launch of the block (every launch overwrites the slots)
-    # The same workgroup stamps the device's constant-rate wall clock beside the cycle counter: the launch's duration and the clock it ran at
-    # then come from the kernel itself, without the 0.02-0.03 ms the two host events around a bracketed launch add to it.  (Workgroup 0's
-    # lifetime: the launch minus its dispatch latency and the last stragglers, within ~1 %.)  Without a wall-clock rate: cycles over the mean
-    # event duration of the recorded launches.
+    # The same workgroup stamps the device's constant-rate wall clock beside the cycle counter, around the same interval (its first to its last
+    # step): cycles / that duration IS the clock it ran at, with no host event in the measurement.  (NOT the launch's duration: workgroup 0 is a
+    # collocation workgroup -- the side sets' workgroups and the slowest collocation workgroups run on behind it, 3-6 % of the launch.  Round 5's
+    # first version divided its cycles by the launch's EVENT duration and so under-stated the clock by that much.)
     wall_khz = int(eng.lib.lib.pinn_debug_wall_clock_khz())
     wall_ticks = int(st[121] - st[120])
-    launch_ms_device_clock = (1e3 * wall_ticks / (wall_khz * 1e3)) if wall_khz > 0 and wall_ticks > 0 else None
-    if launch_ms_device_clock is not None and collo_ms.size and not (0.9 < launch_ms_device_clock / float(collo_ms.mean()) < 1.05):
-        launch_ms_device_clock = None                      # (a rate that does not fit the events: do not quote it)
-    if launch_cycles > 0 and launch_ms_device_clock is not None:
-        shader_clock_ghz = launch_cycles / (launch_ms_device_clock * 1e-3) / 1e9
-    else:
-        shader_clock_ghz = (launch_cycles / (float(collo_ms.mean()) * 1e-3) / 1e9) if collo_ms.size and launch_cycles > 0 else None
+    wg0_ms = (1e3 * wall_ticks / (wall_khz * 1e3)) if wall_khz > 0 and wall_ticks > 0 else None
+    if wg0_ms is not None and collo_ms.size and not (0.2 < wg0_ms / float(collo_ms.mean()) < 1.02):
+        wg0_ms = None                                      # (a rate that does not fit the events: do not quote it)
+    shader_clock_ghz = (launch_cycles / (wg0_ms * 1e-3) / 1e9) if launch_cycles > 0 and wg0_ms is not None else None
     allreduce_ms = None
     if getattr(model, "collective_events", None):
         evs = model.collective_events
@@ -398,13 +397,11 @@ def main():
                    "parallelism": f"dp{world}", "always_reduce": bool(args.always_reduce), "final_loss": final_loss, "algorithmic_flop_per_point": flop_pt},
         "whole_path": {"achieved_tflops": flop_pt * value / 1e12, "frac_of_mfma_peak": flop_pt * value / 1e12 / (MFMA_PEAK_TFLOPS * world)},
         "shader_clock_ghz": shader_clock_ghz,
-        "shader_clock_note": "shader cycles of workgroup 0 over one collocation launch (in-kernel stamps) / the mean HIP-event duration of the launches "
-                             "recorded in the same block: the clock the dominant kernel ran at on THIS box -- it is power-limited, and box-to-box "
-                             "differences of ms_per_step (+-2.5 %) follow it",
-        "launch_ms_device_clock": launch_ms_device_clock,
-        "launch_ms_device_clock_note": "duration of the block's last collocation launch as workgroup 0 saw it: device wall-clock ticks (constant rate, "
-                                       "hipDeviceAttributeWallClockRate) between its first and its last step; no host event in it -- roofline.avg_launch_ms (events) "
-                                       "is 0.02-0.03 ms longer; roofline.frac stays on the events (conservative), roofline.frac_device_clock uses this",
+        "shader_clock_note": "shader cycles of workgroup 0 between its first and its last step of one launch / the device wall-clock time (constant rate, "
+                             "hipDeviceAttributeWallClockRate) of the same interval, both stamped by the kernel (workgroup0_ms; no host event in it): the clock "
+                             "the dominant kernel ran at on THIS box -- it is power-limited, and box-to-box differences of ms_per_step follow it.  "
+                             "ms_per_step x shader_clock_ghz = shader cycles per step is what compares across boxes",
+        "workgroup0_ms": wg0_ms,
         "allreduce_ms": allreduce_ms,
         "rank_share": share if share > 1 else None,
     }
@@ -415,6 +412,7 @@ def main():
                                  f"mean of timing events recorded on the step's stream around the one-shot P2P all-reduce kernel (push to every peer's IPC-mapped "
                                  f"slot, sum in rank order, Adam update in the same kernel: pinn_p2p_allreduce), {4 * model._buf.numel()} bytes, world {world}")
         out["config"]["collective"] = args.collective
+    out["config"]["step_call"] = not args.no_step_call
     if rank == 0:
         # MFMAs issued per algorithmic product (forward and reverse chain: 8 of 12 contractions, 3 per product; weight gradient: 4 of 12): the
         # narrow four- and five-stream collocation kernels multiply high parts only there (1, round 4), the LDS-operand layouts (padded width
@@ -455,6 +453,10 @@ def main():
                                            "launch cost it 0.02-0.03 ms that the unbracketed steps of the timed blocks do not pay (events on every 8th step only), so "
                                            "avg_launch_ms over-states the launch by that much and frac is conservative (contract: launches <= 1.01 x ms_per_step + 0.04 ms)"},
                                "issued_mfma_tflops": tflops * issued,
+                               "frac_incl_side_sets": (lambda ns: (kflop * pts_per_rank + flop_per_point(layers, 1) * ns) / (acc["chain"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS)(
+                                   sum(v[0].numel() for v in model._sides.values())) if fused else None,
+                               "frac_incl_side_sets_note": "since round 5 the launch also evaluates the value-only side sets (one stream: 3 x 2 sum|W| flops per "
+                                                           "side point); `achieved` / `frac` count the collocation points only, as in the earlier rounds",
                                "note": "achieved = algorithmic flops (one product per contraction) / mean HIP-event duration of the launches of one "
                                        "more block of steps behind the timed ones (events in stream order, nothing synchronises in between); the f16x3 mode issues 3 MFMAs per "
                                        f"product in the forward / reverse chain and {wg_mfma} in the weight gradient, so a 100 %-busy matrix pipe is frac {1.0 / issued:.3f}. "
@@ -556,9 +558,6 @@ def main():
                     out["cpu_baseline"] = cpu_baseline_plate(c)
                 else:
                     out["cpu_baseline"] = cpu_baseline([3] + 8 * [args.width] + [7], 32768, 3, f"8x{args.width}")
-    if rank == 0 and "roofline" in out and launch_ms_device_clock is not None and out["roofline"].get("algorithmic_flop_per_point"):
-        out["roofline"]["frac_device_clock"] = (out["roofline"]["algorithmic_flop_per_point"] * pts_per_rank / (launch_ms_device_clock * 1e-3) / 1e12
-                                                / MFMA_PEAK_TFLOPS / max(1, out["roofline"].get("launches_per_step", 1)))
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()          # rank 0 is still profiling its kernel: leave together
         torch.distributed.destroy_process_group()

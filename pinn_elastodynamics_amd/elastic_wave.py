@@ -172,8 +172,9 @@ class DeepHPM(NetApi):
 
     def __init__(self, Collo, SRC, IC, UP, uv_layers, lb, ub, ExistModel=0, modelDir='', *, case="infinite",
                  FIX=None, precision="f16x3", engine=None, seed=1111, process_group=None, verbose=True,
-                 E=2.5, mu=0.25, rho=1.0, always_reduce=False, shard_as=None, collective="rccl"):
+                 E=2.5, mu=0.25, rho=1.0, always_reduce=False, shard_as=None, collective="rccl", step_call=True):
         self.count = 0                      # callback counter (INF:26)
+        self._step_call = bool(step_call)   # False: the step as separate library calls (collocation, side sets, Adam) -- the same bits; for A / B timing
         self._shift_state = {}              # adjoint-shift bookkeeping of evaluate_with_finite_gradient
         self.loss_rec = []                  # SEMI:39
         self.case = case
@@ -433,7 +434,7 @@ class DeepHPM(NetApi):
                 ow[o] = lay[name] / n
             side.append((x, y, t, tg, ow, sums[8 * k:8 * k + 8]))
         stepped = False
-        if e > s and 1 <= len(side) <= 4 and hasattr(eng, "wave_step"):
+        if e > s and 1 <= len(side) <= 4 and hasattr(eng, "wave_step") and self._step_call:
             # the whole evaluation as ONE library call: repack | one persistent launch for all sets | one reduction (+ Adam)
             x, y, t = self._rows(idx_start, idx_end)
             fold = adam is not None and not self._reduce

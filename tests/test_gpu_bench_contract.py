@@ -45,10 +45,8 @@ def test_bench_line(cfg, extra):
     # round 5: the line carries the clock the dominant kernel ran at (power-limited part: a line without it cannot tell a code change from a
     # box), and for the wave step a decomposition that adds up -- events on every 8th step only, so the bracketed block is the timed loop
     assert d["shader_clock_ghz"] is not None and 0.8 < d["shader_clock_ghz"] < 2.6, d["shader_clock_ghz"]
-    # ... and the launch's duration by the device's own wall clock (stamped by workgroup 0 beside its cycle counter): no host event in it, so it
-    # IS a part of the step (the event figure above is 0.02-0.03 ms longer)
-    assert d["launch_ms_device_clock"] is not None and 0 < d["launch_ms_device_clock"] <= 1.01 * d["ms_per_step"], (d["launch_ms_device_clock"], d["ms_per_step"])
-    assert d["launch_ms_device_clock"] <= r["avg_launch_ms"] * 1.02 and r["frac_device_clock"] >= 0.98 * r["frac"]
+    # (clock = workgroup 0's shader cycles / its device wall-clock time over the same interval -- a part of the launch, hence of the step)
+    assert d["workgroup0_ms"] is not None and 0 < d["workgroup0_ms"] <= r["avg_launch_ms"] and d["workgroup0_ms"] <= 1.01 * d["ms_per_step"]
     if cfg == "wave":
         sd = r["step_decomposition_ms"]
         assert sd["collocation_launch"] + sd["side_sets_launch"] <= 1.01 * d["ms_per_step"] + 0.04, (sd, d["ms_per_step"])

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Dev tool (GPU box): everything a round commits under profiles/ -- rocprofv3 stats + PMC (tools/collect_profiles.sh) and the bench lines.
-#   tools/collect_round.sh TAG      -> gpurun_out/TAG_*.{csv,json}
+#   tools/collect_round.sh TAG [bench-only]     -> gpurun_out/TAG_*.{csv,json}
 TAG=${1:-r05}
 OUT=gpurun_out
 mkdir -p $OUT build/exp/prod
 cp pinn_elastodynamics_amd/lib/libpinn_hip.so build/exp/prod/libpinn_hip.so
+if [ "$2" != "bench-only" ]; then       # (bench-only: the PMC summaries committed under profiles/ are of these kernel sources already)
 bash tools/collect_profiles.sh $TAG > $OUT/collect_$TAG.log 2>&1
 for k in 80 100 nc3d plate plate70 conf; do
     bash tools/pmc_collect.sh prod $k > $OUT/pmc_$k.log 2>&1
@@ -18,6 +19,7 @@ cp $OUT/pmc_prod_conf/summary.json $OUT/${TAG}_conf_pmc_summary.json
 # the bench lines below quote the counters of THIS tree (bench.py refuses a summary whose kernel_source_sha differs): the fresh summaries
 # take the place of the committed ones on the box, and are copied into profiles/ from gpurun_out/ afterwards
 cp $OUT/${TAG}_*_pmc_summary.json profiles/
+fi
 python bench.py > $OUT/${TAG}_bench_wave.json 2> $OUT/bench_wave.err
 python bench.py --config plate > $OUT/${TAG}_bench_plate.json 2> $OUT/bench_plate.err
 python bench.py --config plate --width 70 --no-cpu-baseline > $OUT/${TAG}_bench_plate70.json 2> $OUT/bench_plate70.err
