@@ -29,7 +29,8 @@ for _k in list(PREC):                      # "<mode>+packed": the workspace stil
     PREC[_k + "+packed"] = PREC[_k] | FLAG_WEIGHTS_PACKED
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "lib", "libpinn_hip.so")
+# (PINN_HIP_LIB: another build of the same library -- the A / B experiments of tools/ run the product's own bench against build/exp/NAME/libpinn_hip.so)
+DEFAULT_LIB = os.environ.get("PINN_HIP_LIB") or os.path.join(_HERE, "lib", "libpinn_hip.so")
 
 
 class PointSet(C.Structure):
