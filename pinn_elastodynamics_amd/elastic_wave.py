@@ -269,6 +269,8 @@ class DeepHPM(NetApi):
             raise ValueError("collective must be 'rccl' or 'p2p'")
         self._p2p = None
         if collective == "p2p" and self._reduce:
+            if not hasattr(self.engine, "lib"):
+                raise ValueError("collective='p2p' needs the HIP engine (the one-shot all-reduce is a kernel of libpinn_hip.so)")
             from .p2p import P2PAllReduce
             self._p2p = P2PAllReduce(self.engine.lib, self._buf.numel(), self.pg)
 

@@ -251,3 +251,21 @@ def test_reduced_slot_of_a_set_without_local_rows_is_not_accumulated(monkeypatch
         m._loss_and_grad(0, 64)
         seen.append(float(m._buf[P + 16]))
     assert seen == [0.25, 0.25, 0.25, 0.25], seen
+
+
+def test_shard_as_holds_and_weights_one_ranks_share():
+    """shard_as=(r, w) (bench.py --rank-share): one process holds and evaluates rank r's rows of EVERY set, weighted with the global 1/N -- the
+    two shares of a 2-rank job add up to the whole job's sums and gradient, with no process group involved."""
+    Collo, SRC, IC, UP = small_sets(n=301)
+    kw = dict(case="semi_infinite", verbose=False, seed=4)
+    whole = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), **kw)
+    whole._loss_and_grad(0, 301)
+    parts = []
+    for r in range(2):
+        m = DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), shard_as=(r, 2), **kw)
+        assert not m._reduce and m._rows(0, 301)[0].shape[0] in (150, 151) and m._sides["SRC"][0].numel() in (SRC.shape[0] // 2, SRC.shape[0] - SRC.shape[0] // 2)
+        m._loss_and_grad(0, 301)
+        parts.append(m._buf.numpy().copy())
+    np.testing.assert_allclose(parts[0] + parts[1], whole._buf.numpy(), rtol=2e-5, atol=1e-7)
+    with pytest.raises(ValueError, match="collective"):
+        DeepHPM(Collo, SRC, IC, UP, LAYERS, LB, UB, engine=OracleEngine(LAYERS), collective="ring", **kw)
