@@ -174,3 +174,45 @@ def test_neural_net_on_a_net_of_another_output_count(dev):
         m.neural_net(X[:, :2], [np.zeros((2, 8)), np.zeros((8, 7))], [np.zeros((1, 8)), np.zeros((1, 7))])
     with pytest.raises(ValueError, match="no kernel variant"):
         m.neural_net(X, [np.zeros((3, 200)), np.zeros((200, 7))], [np.zeros((1, 200)), np.zeros((1, 7))])
+
+
+def test_step_call_is_the_separate_calls_bit_for_bit_on_the_gpu(dev):
+    """pinn_wave2d_step against the three calls it replaces ON THE DEVICE (the emulator tests assert the same on the CPU): five Adam steps of the
+    8 x 64 model with and without the one-launch step -- parameters, both Adam moments and the recorded loss sums identical bit for bit."""
+    from pinn_elastodynamics_amd.elastic_wave import DeepHPM
+    rng = np.random.default_rng(1)
+    Collo = po.collocation_points(30001, LB, UB, rng)                      # 469 steps over 256 workgroups: two steps on most of them
+    SRC, IC = po.ricker_source_set(n_pt=40, n_time=31), po.ic_grid(num=41)
+    out = {}
+    for step_call in (True, False):
+        m = DeepHPM(Collo, SRC, IC, np.zeros((0, 3)), net(8, 64), LB, UB, verbose=False, seed=9, step_call=step_call)
+        m.engine.lib.path_counts(reset=True)
+        losses = m.train(5, 1e-3, 1)
+        out[step_call] = (m.theta.cpu().numpy(), m.adam_m.cpu().numpy(), m.adam_v.cpu().numpy(), np.array(losses), m.engine.lib.path_counts(reset=True))
+    for a, b in zip(out[True][:4], out[False][:4]):
+        assert np.array_equal(a, b)
+    assert out[True][4]["fused-registers"] == out[False][4]["fused-registers"] and out[True][4]["two-kernel"] == 0
+
+
+def test_plate_step_call_is_the_separate_calls_bit_for_bit_on_the_gpu(dev):
+    """pinn_plate2d_step (five-stream collocation set + hole-traction set in one launch, one reduction) against pinn_plate2d_loss_grad +
+    pinn_plate2d_traction_loss_grad on the device: gradient and all loss sums identical bit for bit"""
+    layers = net(8, 64, 5)
+    n, nh = 50000, 3000
+    Ws, bs, rng = make_net(layers, 6)
+    theta = to_dev(po.pack_params(Ws, bs), dev)
+    X = po.collocation_points(n, [0, 0, 0], [0.5, 0.5, 10.0], rng)
+    H = po.collocation_points(nh, [0, 0, 0], [0.1, 0.1, 10.0], rng)
+    xs = [to_dev(X[:, k], dev) for k in range(3)]
+    hs = [to_dev(H[:, k], dev) for k in range(3)]
+    frozen = to_dev(0.3 * rng.standard_normal((2, 5, 5, n)), dev)
+    aux = to_dev(0.3 * rng.standard_normal((12, nh)), dev)
+    eng = engine(layers, "f16x3", dev, 1 << 16)
+    lb, ub = [0, 0, 0], [0.5, 0.5, 10.0]
+    tw, hw = [10.0 / n] * 5, [10.0 / nh] * 2
+    g1, l1, h1 = (torch.full((eng.n_params,), float("nan"), device=dev), torch.zeros(8, device=dev), torch.zeros(8, device=dev))
+    eng.plate_step(theta, *xs, lb, ub, False, frozen, tw, (*hs, aux, hw), g1, l1, h1)
+    g2, l2, h2 = (torch.full((eng.n_params,), float("nan"), device=dev), torch.zeros(8, device=dev), torch.zeros(8, device=dev))
+    eng.plate_loss_grad(theta, *xs, lb, ub, False, frozen, tw, grad_out=g2, accumulate=False, loss_out=l2)
+    eng.traction_loss_grad(theta, *hs, lb, ub, False, aux, hw, grad_out=g2, accumulate=True, loss_out=h2, packed=True)
+    assert torch.isfinite(g1).all() and torch.equal(g1, g2) and torch.equal(l1[:5], l2[:5]) and torch.equal(h1[:2], h2[:2])
