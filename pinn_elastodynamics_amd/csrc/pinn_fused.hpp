@@ -82,8 +82,37 @@ struct FusedArgs {
     // grid).  fused_step_kernel (round 5) runs the collocation set AND the value-only side sets of a training step in ONE launch -- the side
     // sets' workgroups are the blocks behind the collocation set's and start on the compute units that run out of collocation steps first.
     int block0, grid;
+    // XCD-aware step assignment (round 5).  Workgroups are dispatched round-robin over the 8 XCDs (XCD = blockIdx % 8), and the odd XCDs of an
+    // MI355X run this kernel 2-3 % slower than the even ones -- measured with every workgroup's lifetime on the device wall clock, the same
+    // pattern on two boxes and in every repetition (profiles/r05_workgroup_lifetimes.txt: us per step by XCD 36.7 37.6 35.9 37.2 36.5 37.7 36.2 37.3
+    // and 35.3 35.9 35.0 35.7 35.1 36.1 34.9 35.6) --, so with one step per workgroup and round the launch ends with its slowest XCD, 2 % behind
+    // the mean.  bonus_every = k > 0: behind every k plain rounds comes a BONUS round in which only the even-XCD workgroups take a step.  Static,
+    // hence deterministic: which workgroup sums which points depends on the launch's shape alone.  0: every round is plain.
+    int bonus_every;
 };
 __device__ __forceinline__ int fused_bid(const FusedArgs& a) { return (int)blockIdx.x - a.block0; }
+// the steps of this workgroup, in order; -1 when there are none left
+struct StepWalk {
+    long base = 0;
+    int plain = 0;
+};
+__device__ __forceinline__ long fused_next_step(const FusedArgs& a, StepWalk& w) {
+    const int b = fused_bid(a);
+    for (;;) {
+        if (w.base >= a.nsteps) return -1;
+        if (a.bonus_every > 0 && w.plain == a.bonus_every) {      // bonus round: the even-XCD workgroups, densely numbered
+            w.plain = 0;
+            const long s = w.base + ((b >> 3) * 4 + ((b & 7) >> 1));
+            w.base += a.grid >> 1;
+            if ((b & 1) == 0 && s < a.nsteps) return s;
+        } else {
+            ++w.plain;
+            const long s = w.base + b;
+            w.base += a.grid;
+            if (s < a.nsteps) return s;
+        }
+    }
+}
 
 // A launch constant, made opaque at its point of use inside the step loop.  Otherwise the compiler hoists whatever is computed from
 // such constants alone (2 * term weight, the packed tangent seeds of the input state ...) out of the loop into registers it then has
@@ -1118,7 +1147,8 @@ struct Fused {
             xs1.c = c;
             xs1.q = q;
         }
-        for (long step = fused_bid(a); step < a.nsteps; step += a.grid) {
+        StepWalk walk;
+        for (long step = fused_next_step(a, walk); step >= 0; step = fused_next_step(a, walk)) {
             if constexpr (S1_WG_ANY) {                    // the tile's inputs: requested here, used a forward and six reverse layers later
                 bool valid;
                 long pidx;
@@ -2473,7 +2503,8 @@ struct Fused {
         const bool launch_tracer = x.tracer;
         fused_stamp(a, launch_tracer, NS == 1 ? 122 : 124);
         fused_stamp_wall(a, launch_tracer, NS == 1 ? 118 : 120);
-        for (long step = fused_bid(a); step < a.nsteps; step += a.grid) {
+        StepWalk walk;
+        for (long step = fused_next_step(a, walk); step >= 0; step = fused_next_step(a, walk)) {
             float xin[4];
             bool valid;
             long pidx;

@@ -87,6 +87,8 @@ struct Call {
 
 // paths taken by the loss + gradient calls of this process (pinn_debug_path_counts); defined in pinn_capi.hip
 extern long g_path_counts[5];
+// rounds between two bonus rounds of the even XCDs (FusedArgs::bonus_every; pinn_debug_set_xcd_bonus); 0 = off
+extern int g_xcd_bonus_every;
 
 struct Impl {
     int (*path_for)(const NetDesc&, int head, size_t ws_bytes);
@@ -471,6 +473,9 @@ struct Host {
         a.dbg = c.dbg_stamps;
         a.block0 = block0;
         a.grid = grid;
+        // XCD-aware step assignment (FusedArgs::bonus_every): the four-stream collocation part of a full grid with enough rounds for a 2.5 % skew to
+        // be expressible in whole steps; not the side-set part (its workgroups start wherever a compute unit frees up)
+        a.bonus_every = (NS >= 4 && block0 == 0 && grid == FUSED_GRID && nsteps >= 64L * FUSED_GRID) ? g_xcd_bonus_every : 0;
         su.twmax = twmax;
         su.lo = lo;
         su.nsets = nsets;
