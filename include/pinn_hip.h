@@ -333,10 +333,10 @@ int pinn_p2p_destroy(pinn_p2p_comm* comm);
  * compute the same numbers to the precision mode's accuracy (tests/test_gpu_parity.py). */
 int pinn_debug_set_fused(int enable);
 /* Tuning hook (process-wide): the XCD-aware step assignment of the fused collocation kernels.  Workgroups are dispatched round-robin over the 8
- * XCDs and the odd XCDs of an MI355X run these kernels 2-3 % slower than the even ones (profiles/r05_workgroup_lifetimes.txt), so behind every
- * `every` plain rounds (one step per workgroup) the even-XCD workgroups take a bonus step.  0 turns it off; returns the previous setting.  The
+ * XCDs and the odd XCDs of an MI355X run these kernels 2-3 % slower than the even ones (profiles/r05_workgroup_lifetimes.txt), so the even-XCD
+ * workgroups take `permille` / 1000 more steps (as the tail of the launch; default 16).  0 turns it off; returns the previous setting.  The
  * assignment is static: results stay a deterministic function of the inputs and the launch shape. */
-int pinn_debug_set_xcd_bonus(int every);
+int pinn_debug_set_xcd_bonus(int permille);
 /* Profiling hook (process-wide): device buffer of 128 uint64 that the fused kernel fills with shader-clock
  * stamps of its phases (workgroup 0 only); NULL turns it off. */
 void pinn_debug_set_stamp_buffer(void* device_u64x128);

@@ -111,8 +111,9 @@ class PinnLib:
         L.pinn_adam_step.restype = i32
         L.pinn_debug_set_profile_buffer.argtypes = [vp]
         L.pinn_debug_set_profile_buffer.restype = None
-        L.pinn_debug_set_xcd_bonus.argtypes = [i32]
-        L.pinn_debug_set_xcd_bonus.restype = i32
+        if hasattr(L, "pinn_debug_set_xcd_bonus"):      # (tuning hook; experiment builds of older trees do not have it)
+            L.pinn_debug_set_xcd_bonus.argtypes = [i32]
+            L.pinn_debug_set_xcd_bonus.restype = i32
         L.pinn_debug_set_fused.argtypes = [i32]
         L.pinn_debug_set_fused.restype = i32
         L.pinn_fused_weight_limit.argtypes = []

@@ -79,7 +79,10 @@ static unsigned long long* g_dbg_stamps = nullptr;
 static float* g_prof_ms = nullptr;
 static ProfRing g_ring;
 static int g_ring_every = 1;
-namespace pinn { long g_path_counts[5] = {0, 0, 0, 0, 0}; int g_xcd_bonus_every = 80; }      // (1.25 % more steps for the even XCDs: A / B 0 / 100 / 80 / 64 / 40 / 20 rounds: 4.427 / 4.402 / 4.388 / 4.403 / 4.412 / 4.472 ms per 2 M-point launch)
+#ifndef PINN_XCD_TAIL_DEFAULT
+#define PINN_XCD_TAIL_DEFAULT 16      // 1.6 % more steps for the even XCDs (A / B on one box, 96 interleaved launches each: 0 / 12 / 20 permille -> 4.492 / 4.437 / 4.432 ms per 2 M points; profiles/r05_xcd_bonus_ab.txt)
+#endif
+namespace pinn { long g_path_counts[5] = {0, 0, 0, 0, 0}; int g_xcd_tail_permille = PINN_XCD_TAIL_DEFAULT; }
 
 extern "C" {
 
@@ -134,9 +137,9 @@ int pinn_debug_profile_ring_read(float* ms_out, int* streams_out, int capacity) 
     return m;
 }
 
-int pinn_debug_set_xcd_bonus(int every) {
-    const int old = g_xcd_bonus_every;
-    g_xcd_bonus_every = every < 0 ? 0 : every;
+int pinn_debug_set_xcd_bonus(int permille) {
+    const int old = g_xcd_tail_permille;
+    g_xcd_tail_permille = permille < 0 ? 0 : (permille > 200 ? 200 : permille);
     return old;
 }
 

@@ -86,32 +86,20 @@ struct FusedArgs {
     // MI355X run this kernel 2-3 % slower than the even ones -- measured with every workgroup's lifetime on the device wall clock, the same
     // pattern on two boxes and in every repetition (profiles/r05_workgroup_lifetimes.txt: us per step by XCD 36.7 37.6 35.9 37.2 36.5 37.7 36.2 37.3
     // and 35.3 35.9 35.0 35.7 35.1 36.1 34.9 35.6) --, so with one step per workgroup and round the launch ends with its slowest XCD, 2 % behind
-    // the mean.  bonus_every = k > 0: behind every k plain rounds comes a BONUS round in which only the even-XCD workgroups take a step.  Static,
-    // hence deterministic: which workgroup sums which points depends on the launch's shape alone.  0: every round is plain.
-    int bonus_every;
+    // the mean.  Steps [0, n_plain) go one per workgroup and round as ever; the TAIL [n_plain, nsteps) goes to the even-XCD workgroups only,
+    // one per round of grid / 2.  Static, hence deterministic: which workgroup sums which points depends on the launch's shape alone.
+    // n_plain >= nsteps: no tail.  (A first version interleaved bonus rounds and carried two more loop counters: +20 spilled registers in the
+    // 8 x 64 kernel; this form keeps the loop's state at the step index.)
+    long n_plain;
 };
 __device__ __forceinline__ int fused_bid(const FusedArgs& a) { return (int)blockIdx.x - a.block0; }
-// the steps of this workgroup, in order; -1 when there are none left
-struct StepWalk {
-    long base = 0;
-    int plain = 0;
-};
-__device__ __forceinline__ long fused_next_step(const FusedArgs& a, StepWalk& w) {
-    const int b = fused_bid(a);
-    for (;;) {
-        if (w.base >= a.nsteps) return -1;
-        if (a.bonus_every > 0 && w.plain == a.bonus_every) {      // bonus round: the even-XCD workgroups, densely numbered
-            w.plain = 0;
-            const long s = w.base + ((b >> 3) * 4 + ((b & 7) >> 1));
-            w.base += a.grid >> 1;
-            if ((b & 1) == 0 && s < a.nsteps) return s;
-        } else {
-            ++w.plain;
-            const long s = w.base + b;
-            w.base += a.grid;
-            if (s < a.nsteps) return s;
-        }
-    }
+// the step of this workgroup behind `step` (>= nsteps: none)
+__device__ __forceinline__ long fused_next_step(const FusedArgs& a, long step) {
+    if (step >= a.n_plain) return step + (a.grid >> 1);
+    const long nx = step + a.grid;
+    if (nx < a.n_plain) return nx;
+    const int b = fused_bid(a);                                   // leaving the plain rounds: the tail is the even XCDs'
+    return (b & 1) ? a.nsteps : a.n_plain + ((b >> 3) * 4 + ((b & 7) >> 1));
 }
 
 // A launch constant, made opaque at its point of use inside the step loop.  Otherwise the compiler hoists whatever is computed from
@@ -1147,8 +1135,7 @@ struct Fused {
             xs1.c = c;
             xs1.q = q;
         }
-        StepWalk walk;
-        for (long step = fused_next_step(a, walk); step >= 0; step = fused_next_step(a, walk)) {
+        for (long step = fused_bid(a); step < a.nsteps; step = fused_next_step(a, step)) {
             if constexpr (S1_WG_ANY) {                    // the tile's inputs: requested here, used a forward and six reverse layers later
                 bool valid;
                 long pidx;
@@ -2503,8 +2490,7 @@ struct Fused {
         const bool launch_tracer = x.tracer;
         fused_stamp(a, launch_tracer, NS == 1 ? 122 : 124);
         fused_stamp_wall(a, launch_tracer, NS == 1 ? 118 : 120);
-        StepWalk walk;
-        for (long step = fused_next_step(a, walk); step >= 0; step = fused_next_step(a, walk)) {
+        for (long step = fused_bid(a); step < a.nsteps; step = fused_next_step(a, step)) {
             float xin[4];
             bool valid;
             long pidx;

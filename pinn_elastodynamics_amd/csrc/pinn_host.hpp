@@ -87,8 +87,8 @@ struct Call {
 
 // paths taken by the loss + gradient calls of this process (pinn_debug_path_counts); defined in pinn_capi.hip
 extern long g_path_counts[5];
-// rounds between two bonus rounds of the even XCDs (FusedArgs::bonus_every; pinn_debug_set_xcd_bonus); 0 = off
-extern int g_xcd_bonus_every;
+// extra steps of the even-XCD workgroups in 1/1000 (FusedArgs::n_plain; pinn_debug_set_xcd_bonus); 0 = off
+extern int g_xcd_tail_permille;
 
 struct Impl {
     int (*path_for)(const NetDesc&, int head, size_t ws_bytes);
@@ -473,9 +473,14 @@ struct Host {
         a.dbg = c.dbg_stamps;
         a.block0 = block0;
         a.grid = grid;
-        // XCD-aware step assignment (FusedArgs::bonus_every): the four-stream collocation part of a full grid with enough rounds for a 2.5 % skew to
-        // be expressible in whole steps; not the side-set part (its workgroups start wherever a compute unit frees up)
-        a.bonus_every = (NS >= 4 && block0 == 0 && grid == FUSED_GRID && nsteps >= 64L * FUSED_GRID) ? g_xcd_bonus_every : 0;
+        // XCD-aware step assignment (FusedArgs::n_plain): the collocation part of a full grid with enough rounds for the skew to be expressible in
+        // whole steps: g_xcd_tail_permille / 1000 more steps for the even-XCD workgroups, taken as a tail behind R plain rounds with
+        // 128 (R + e) + 128 R = nsteps, e = skew * R; not the side-set part (its workgroups start wherever a compute unit frees up)
+        a.n_plain = 0x7fffffffffffffffL;
+        if (NS >= 4 && block0 == 0 && grid == FUSED_GRID && nsteps >= 64L * FUSED_GRID && g_xcd_tail_permille > 0) {
+            const long R = (long)((double)nsteps / ((FUSED_GRID / 2) * (2.0 + 0.001 * g_xcd_tail_permille)));
+            a.n_plain = R * FUSED_GRID;
+        }
         su.twmax = twmax;
         su.lo = lo;
         su.nsets = nsets;

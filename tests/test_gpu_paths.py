@@ -216,3 +216,30 @@ def test_plate_step_call_is_the_separate_calls_bit_for_bit_on_the_gpu(dev):
     eng.plate_loss_grad(theta, *xs, lb, ub, False, frozen, tw, grad_out=g2, accumulate=False, loss_out=l2)
     eng.traction_loss_grad(theta, *hs, lb, ub, False, aux, hw, grad_out=g2, accumulate=True, loss_out=h2, packed=True)
     assert torch.isfinite(g1).all() and torch.equal(g1, g2) and torch.equal(l1[:5], l2[:5]) and torch.equal(h1[:2], h2[:2])
+
+
+def test_xcd_aware_step_assignment_changes_the_grouping_not_the_sums(dev):
+    """The even-XCD workgroups take the launch's tail (FusedArgs::n_plain; 1.6 % more steps for them on full grids of >= 64 rounds): every step is
+    still taken exactly once -- loss sums and gradient agree with the unskewed assignment to fp32 summation noise, at a size where the tail exists
+    (1.2 M points: 18 750 steps) and for a skew far larger than the shipped one; repeated calls give the same bits (static assignment)."""
+    layers = net(8, 64)
+    n = 1_200_000
+    Ws, bs, rng = make_net(layers, 2)
+    theta = to_dev(po.pack_params(Ws, bs), dev)
+    X = po.collocation_points(n, LB, UB, rng)
+    xs = [to_dev(X[:, k], dev) for k in range(3)]
+    eng = engine(layers, "f16x3", dev, 1 << 18)
+    out = {}
+    try:
+        for permille in (0, 16, 150):
+            eng.lib.lib.pinn_debug_set_xcd_bonus(permille)
+            l1, g1 = eng.wave_loss_grad(theta, *xs, LB, UB, True, np.ones(7) / n)
+            l1, g1 = l1.cpu().numpy().copy(), g1.cpu().numpy().copy()
+            l2, g2 = eng.wave_loss_grad(theta, *xs, LB, UB, True, np.ones(7) / n)
+            assert np.array_equal(g1, g2.cpu().numpy()) and np.array_equal(l1, l2.cpu().numpy())
+            out[permille] = (l1, g1)
+    finally:
+        eng.lib.lib.pinn_debug_set_xcd_bonus(16)
+    for permille in (16, 150):
+        assert rel(out[permille][0], out[0][0]) < 2e-6 and rel(out[permille][1], out[0][1]) < 2e-6
+        assert not np.array_equal(out[permille][1], out[0][1])              # another grouping of the partial sums did run
