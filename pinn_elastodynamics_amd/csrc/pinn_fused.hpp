@@ -142,6 +142,9 @@ __device__ __forceinline__ void fused_stamp_wall(const FusedArgs& a, bool who, i
 template <class Op, int SPLIT, int WIDTH, int NL, int NS_ = 4, bool FASTSTATE = false, int DIN_ = 3>
 struct Fused {
     static constexpr int NS = NS_, WB = WIDTH / 16, KS = WIDTH / 32, NP = SPLIT == 3 ? 2 : 1, DIN = DIN_;
+    // the XCD-aware step assignment (FusedArgs::n_plain) -- not in the 3-D instantiation: the most register-starved kernel of the file (785 spilled
+    // SGPRs) took the three extra scalar values of the loop as +10 % launch time (25.2 against 22.3-23.3 ms per 1 M points, with the tail on or off)
+    static constexpr bool XCD_TAIL = DIN_ == 3;
     static_assert(NS == 4 || NS == 1 || NS == 5, "wave residual head (4 streams), value-only data head (1 stream) or plate / 3-D head (5 streams)");
     static_assert(DIN == 3 || (DIN == 4 && NS == 5), "4 inputs: the five-stream 3-D head only");
     // NS = 5, 3 inputs: streams (value, x, y, t, tt) -- the fifth carries the second time derivative (PLATE:417-419) -- and the plate head:
@@ -1135,7 +1138,7 @@ struct Fused {
             xs1.c = c;
             xs1.q = q;
         }
-        for (long step = fused_bid(a); step < a.nsteps; step = fused_next_step(a, step)) {
+        for (long step = fused_bid(a); step < a.nsteps; step = XCD_TAIL ? fused_next_step(a, step) : step + a.grid) {
             if constexpr (S1_WG_ANY) {                    // the tile's inputs: requested here, used a forward and six reverse layers later
                 bool valid;
                 long pidx;
@@ -2490,7 +2493,7 @@ struct Fused {
         const bool launch_tracer = x.tracer;
         fused_stamp(a, launch_tracer, NS == 1 ? 122 : 124);
         fused_stamp_wall(a, launch_tracer, NS == 1 ? 118 : 120);
-        for (long step = fused_bid(a); step < a.nsteps; step = fused_next_step(a, step)) {
+        for (long step = fused_bid(a); step < a.nsteps; step = XCD_TAIL ? fused_next_step(a, step) : step + a.grid) {
             float xin[4];
             bool valid;
             long pidx;

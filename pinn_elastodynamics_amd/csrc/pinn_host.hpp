@@ -477,7 +477,7 @@ struct Host {
         // whole steps: g_xcd_tail_permille / 1000 more steps for the even-XCD workgroups, taken as a tail behind R plain rounds with
         // 128 (R + e) + 128 R = nsteps, e = skew * R; not the side-set part (its workgroups start wherever a compute unit frees up)
         a.n_plain = 0x7fffffffffffffffL;
-        if (NS >= 4 && block0 == 0 && grid == FUSED_GRID && nsteps >= 64L * FUSED_GRID && g_xcd_tail_permille > 0) {
+        if (NS >= 4 && DIN == 3 && block0 == 0 && grid == FUSED_GRID && nsteps >= 64L * FUSED_GRID && g_xcd_tail_permille > 0) {
             const long R = (long)((double)nsteps / ((FUSED_GRID / 2) * (2.0 + 0.001 * g_xcd_tail_permille)));
             a.n_plain = R * FUSED_GRID;
         }
