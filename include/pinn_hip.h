@@ -47,7 +47,10 @@ enum {
                              heads, 8 or 4 hidden layers) hand the per-layer states to their activation reverse as fp16 high part + the TOP BYTE
                              of the fp16 low part (14 significant bits; round 4): measured at the reference's trained nets the gradient blocks
                              stay where full low parts put them (tools/studies/wgrad_operand_study.py, the per-layer fp32 bounds of the GPU
-                             tests); PINN_FLAG_STATE_FP16 drops the low parts altogether and is NOT parity-grade. */
+                             tests); since round 5 the lowest parked state of the four-stream kernel (S_2) travels without that byte -- which layers'
+                             low parts the reverse needs was priced layer by layer (tools/studies/lo_policy_study.py: the upper layers carry it; at
+                             the most sensitive reference net the worst per-layer multiple of fp32's own error moves 3.9 -> 4.6 of the tests' bound
+                             of 6, elsewhere not at all); PINN_FLAG_STATE_FP16 drops the low parts altogether and is NOT parity-grade. */
     PINN_PREC_F16 = 2,    /* fp16 operands, one MFMA per product */
     PINN_PREC_BF16X3 = 3, /* bf16 hi/lo split, three MFMAs per product (16-bit significand) */
     PINN_PREC_FP32 = 4,   /* plain fp32 FMA arithmetic, no matrix pipe (the reference's own precision, INF:71-92): ~100x slower,
