@@ -340,6 +340,9 @@ int pinn_debug_set_fused(int enable);
  * workgroups take `permille` / 1000 more steps (as the tail of the launch; default 16).  0 turns it off; returns the previous setting.  The
  * assignment is static: results stay a deterministic function of the inputs and the launch shape. */
 int pinn_debug_set_xcd_bonus(int permille);
+/* Testing hook (process-wide): at most `cap` workgroups in a fused per-family launch (0: the default, one per compute unit) -- several steps per
+ * workgroup on small test inputs.  Returns the previous setting. */
+int pinn_debug_set_fused_grid_cap(int cap);
 /* Profiling hook (process-wide): device buffer of 128 uint64 that the fused kernel fills with shader-clock
  * stamps of its phases (workgroup 0 only); NULL turns it off. */
 void pinn_debug_set_stamp_buffer(void* device_u64x128);

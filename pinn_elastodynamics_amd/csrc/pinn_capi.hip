@@ -82,7 +82,7 @@ static int g_ring_every = 1;
 #ifndef PINN_XCD_TAIL_DEFAULT
 #define PINN_XCD_TAIL_DEFAULT 16      // 1.6 % more steps for the even XCDs (A / B on one box, 96 interleaved launches each: 0 / 12 / 20 permille -> 4.492 / 4.437 / 4.432 ms per 2 M points; profiles/r05_xcd_bonus_ab.txt)
 #endif
-namespace pinn { long g_path_counts[5] = {0, 0, 0, 0, 0}; int g_xcd_tail_permille = PINN_XCD_TAIL_DEFAULT; }
+namespace pinn { long g_path_counts[5] = {0, 0, 0, 0, 0}; int g_xcd_tail_permille = PINN_XCD_TAIL_DEFAULT; int g_fused_grid_cap = 0; }
 
 extern "C" {
 
@@ -142,6 +142,8 @@ int pinn_debug_set_xcd_bonus(int permille) {
     g_xcd_tail_permille = permille < 0 ? 0 : (permille > 200 ? 200 : permille);
     return old;
 }
+
+int pinn_debug_set_fused_grid_cap(int cap) { const int old = g_fused_grid_cap; g_fused_grid_cap = cap < 0 ? 0 : cap; return old; }
 
 int pinn_debug_set_fused(int enable) {
     const int old = g_use_fused;

@@ -89,6 +89,8 @@ struct Call {
 extern long g_path_counts[5];
 // extra steps of the even-XCD workgroups in 1/1000 (FusedArgs::n_plain; pinn_debug_set_xcd_bonus); 0 = off
 extern int g_xcd_tail_permille;
+// testing hook (pinn_debug_set_fused_grid_cap): at most this many workgroups in a fused launch (0: no cap beyond FUSED_GRID)
+extern int g_fused_grid_cap;
 
 struct Impl {
     int (*path_for)(const NetDesc&, int head, size_t ws_bytes);
@@ -477,9 +479,14 @@ struct Host {
         // whole steps: g_xcd_tail_permille / 1000 more steps for the even-XCD workgroups, taken as a tail behind R plain rounds with
         // 128 (R + e) + 128 R = nsteps, e = skew * R; not the side-set part (its workgroups start wherever a compute unit frees up)
         a.n_plain = 0x7fffffffffffffffL;
-        if (NS >= 4 && DIN == 3 && block0 == 0 && grid == FUSED_GRID && nsteps >= 64L * FUSED_GRID && g_xcd_tail_permille > 0) {
-            const long R = (long)((double)nsteps / ((FUSED_GRID / 2) * (2.0 + 0.001 * g_xcd_tail_permille)));
-            a.n_plain = R * FUSED_GRID;
+#if defined(PINN_SIMT_EMULATOR)
+        const bool shape_ok = grid >= 8 && grid % 8 == 0 && nsteps >= 4L * grid;      // (the x86 test build: small grids, a few rounds -- the index arithmetic is the point)
+#else
+        const bool shape_ok = grid == FUSED_GRID && nsteps >= 64L * FUSED_GRID;
+#endif
+        if (NS >= 4 && DIN == 3 && block0 == 0 && shape_ok && g_xcd_tail_permille > 0) {
+            const long R = (long)((double)nsteps / ((grid / 2) * (2.0 + 0.001 * g_xcd_tail_permille)));
+            a.n_plain = R * grid;
         }
         su.twmax = twmax;
         su.lo = lo;
@@ -659,6 +666,7 @@ struct Host {
             long grid = fused_images<NS>(c.net, c.ws_bytes);
             if (grid == 0) return 0;
             if (grid > FUSED_GRID) grid = FUSED_GRID;
+            if (g_fused_grid_cap > 0 && grid > g_fused_grid_cap) grid = g_fused_grid_cap;
             long nsteps = 0;
             if (NS == 1) {
                 DataSet sets[4];

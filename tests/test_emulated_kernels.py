@@ -839,3 +839,43 @@ def test_plate_step_call_is_the_separate_calls_bit_for_bit_emulated(emu, lN, n, 
     ss, g = pl.plate_loss_grad(fN, lN, X[:, 0], X[:, 1], X[:, 2], frozen[0].astype(np.float64), frozen[1].astype(np.float64), term_weights=np.asarray(tw))[:2]
     ssh, gh = pl.traction_loss_grad(fN, lN, H[:, 0], H[:, 1], H[:, 2], DH, PH, weight=10.0 / nh)
     assert rel(a["loss"], ss) < 5e-6 and rel(a["hloss"], ssh) < 5e-6 and rel(a["grad"], g + gh) < 3e-4
+
+
+@pytest.mark.parametrize("layers,permille", [([3] + 4 * [32] + [7], 16), ([3] + 8 * [64] + [7], 150)])
+def test_xcd_aware_tail_takes_every_step_once_emulated(emu, layers, permille):
+    """The XCD-aware step assignment (FusedArgs::n_plain, fused_next_step): steps [0, n_plain) one per workgroup and round, the tail to the
+    even-numbered workgroups of every group of eight.  The x86 build applies it to small grids (multiples of 8, >= 4 rounds), so the index
+    arithmetic runs here: 8 workgroups, 6.2 rounds, a ragged last step -- sums and gradient equal the oracle's and the unskewed assignment's
+    to summation noise, and differ from the latter in the last bits (another grouping did run)."""
+    prec = "f16x3"
+    rng = np.random.default_rng(11)
+    Ws, bs = po.xavier_init(layers, rng)
+    bs = [0.3 * rng.standard_normal(b.shape) for b in bs]
+    n = 8 * 64 * 6 + 100
+    X = po.collocation_points(n, LB, UB, rng)
+    flat = po.pack_params(Ws, bs)
+    tw = np.array([1, 2, 3, 1, 0.5, 1, 2.0]) / n
+    ss, g, _ = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, True, term_weights=tw)
+    p32 = flat.astype(np.float32)
+    x, y, t = (X[:, k].astype(np.float32).copy() for k in range(3))
+    emu.set_fused(True)
+    wsb = emu.workspace_bytes(layers, 1 << 14, prec)
+    out = {}
+    emu.lib.pinn_debug_set_fused_grid_cap(8)                    # 8 workgroups: 6.2 rounds of 64 points
+    try:
+        for pm in (0, permille):
+            emu.lib.pinn_debug_set_xcd_bonus(pm)
+            ws = aligned(wsb)
+            loss = np.full(8, np.nan, np.float32)
+            grad = np.full(p32.size, np.nan, np.float32)
+            emu.path_counts(reset=True)
+            emu.wave2d_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, True, 2.5, 0.25, 1.0, True,
+                                 tw, loss.ctypes.data, grad.ctypes.data, False, prec, ws.ctypes.data, wsb)
+            assert emu.path_counts(reset=True)["fused-registers"] == 1
+            out[pm] = (loss[:7].copy(), grad.copy())
+    finally:
+        emu.lib.pinn_debug_set_xcd_bonus(16)
+        emu.lib.pinn_debug_set_fused_grid_cap(0)
+    for pm in out:
+        assert rel(out[pm][0], ss) < 2e-6 and rel(out[pm][1], g) < 1e-4, pm
+    assert rel(out[permille][1], out[0][1]) < 2e-6 and not np.array_equal(out[permille][1], out[0][1])
