@@ -34,7 +34,7 @@ class NavierCauchy3D(NetApi):
 
     def __init__(self, Collo, SRC, IC, TOP, uv_layers, lb, ub, ExistModel=0, modelDir='', *, precision="f16x3", engine=None, seed=1111,
                  process_group=None, verbose=True, E=2.5, mu=0.25, rho=1.0, normalize=True, layout: Optional[dict] = None,
-                 always_reduce=False):
+                 always_reduce=False, collective="rccl"):
         self.count = 0
         self._shift_state = {}
         self.loss_rec = []
@@ -108,6 +108,15 @@ class NavierCauchy3D(NetApi):
         side("NB", TOP, (8, 10, 11))                       # s33 = s13 = s23 = 0 on the free top  (as SEMI:125-126)
         self.SRC, self.IC, self.TOP = SRC, IC, TOP
         self._buf = torch.zeros(self.n_params + 16 * len(_SLOTS), dtype=torch.float32, device=self.device)
+        # collective: "rccl" (torch.distributed.all_reduce) or "p2p" (the library's one-shot all-reduce over IPC-mapped peer buffers; elastic_wave.DeepHPM)
+        if collective not in ("rccl", "p2p"):
+            raise ValueError("collective must be 'rccl' or 'p2p'")
+        self._p2p = None
+        if collective == "p2p" and self._reduce:
+            if not hasattr(self.engine, "lib"):
+                raise ValueError("collective='p2p' needs the HIP engine")
+            from .p2p import P2PAllReduce
+            self._p2p = P2PAllReduce(self.engine.lib, self._buf.numel(), self.pg)
 
     # ---- checkpoints: the reference's [W_list, b_list] pickle / npz (INF:159-186) ---------------------------------
     def save_NN(self, fileDir, TYPE=''):
@@ -226,7 +235,7 @@ class NavierCauchy3D(NetApi):
         if not wrote:
             grad.zero_()
         if self._reduce:
-            all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None))
+            all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None), getattr(self, "_p2p", None))
 
     def _terms_from_sums(self, sums, n_blk):
         lay = self.layout

@@ -30,7 +30,7 @@ BFGS_OPTIONS = {   # PLATE:220-247
 class PINN(NetApi):
     def __init__(self, Collo, HOLE, IC, LF, RT, UP, LW, DIST, uv_layers, dist_layers, part_layers, lb, ub,
                  partDir='', distDir='', uvDir='', *, precision="f16x3", engines=None, seed=1111, process_group=None, verbose=True,
-                 always_reduce=False):
+                 always_reduce=False, collective="rccl"):
         self.count = 0
         self._shift_state = {}
         self.lb = np.asarray(lb, dtype=np.float64).reshape(-1)
@@ -112,6 +112,15 @@ class PINN(NetApi):
                 tgt = dev(tg)
             self._part_sets.append((xyt(A, False)[1], tgt, w, A.shape[0]))
         self._buf = torch.zeros(self.theta["uv"].numel() + 16, dtype=torch.float32, device=self.device)
+        # collective: "rccl" (torch.distributed.all_reduce) or "p2p" (the library's one-shot all-reduce over IPC-mapped peer buffers; elastic_wave.DeepHPM)
+        if collective not in ("rccl", "p2p"):
+            raise ValueError("collective must be 'rccl' or 'p2p'")
+        self._p2p = None
+        if collective == "p2p" and self._reduce:
+            if not hasattr(self.eng["uv"], "lib"):
+                raise ValueError("collective='p2p' needs the HIP engine")
+            from .p2p import P2PAllReduce
+            self._p2p = P2PAllReduce(self.eng["uv"].lib, self._buf.numel(), self.pg)
         self.refresh_frozen()
 
     # ------------------------------------------------------------------------------------------------------------------
@@ -245,7 +254,7 @@ class PINN(NetApi):
                            (hx, hy, ht, self._aux_hole, [10.0 / self.n_hole] * 2), grad, buf[P:P + 8], buf[P + 8:P + 16], self.E, self.mu, self.rho,
                            adam=(self.adam_m, self.adam_v, adam[0], adam[1]) if fold else None)
             if self._reduce:
-                all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None))
+                all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None), getattr(self, "_p2p", None))
             return fold
         buf[P:].zero_()
         wrote = False
@@ -263,7 +272,7 @@ class PINN(NetApi):
         if not wrote:
             grad.zero_()
         if self._reduce:
-            all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None))
+            all_reduce_sum(buf, self.pg, getattr(self, "collective_events", None), getattr(self, "_p2p", None))
 
     def _terms(self, sums):
         out = {"loss_f_uv": float(sums[0:2].sum() / self.n_collo), "loss_f_s": float(sums[2:5].sum() / self.n_collo),

@@ -57,16 +57,16 @@ def test_rccl_collective_branch_on_one_gpu(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("model", ["plate", "nc3d"])
-def test_two_ranks_on_one_gpu_plate_and_nc3d(tmp_path, model):
+@pytest.mark.parametrize("model,collective", [("plate", "rccl"), ("nc3d", "rccl"), ("plate", "p2p")])
+def test_two_ranks_on_one_gpu_plate_and_nc3d(tmp_path, model, collective):
     """The 2-process run with the real HipEngine (both ranks on cuda:0, gloo) for the plate class (Adam steps, then an L-BFGS stage with its
     per-evaluation all-reduce) and the 3-D class: ranks bit-identical, and the same numbers as one process to 1e-5."""
     import torch
     out = str(tmp_path / f"dp_{model}.npz")
-    port = "29534" if model == "plate" else "29535"
+    port = {"plate": "29534", "nc3d": "29535"}[model] if collective == "rccl" else "29537"      # ("rccl": the class default; these ranks run it over gloo)
     env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", port, os.path.join(ROOT, "tests", "_dp_worker_gpu2.py"), model, out], env=env, capture_output=True, text=True,
+                        "--master-port", port, os.path.join(ROOT, "tests", "_dp_worker_gpu2.py"), model, out, collective], env=env, capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     z = np.load(out)
