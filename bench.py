@@ -352,7 +352,12 @@ def main():
     # 3.8 % slower than the timed ones in round 4).  The same block carries (a) shader-clock stamps of workgroup 0 around the whole launch
     # -> the clock the kernel ran at (it is power-limited: 1.9-2.0 GHz of a 2.4 GHz part, box to box), (b) with a collective, events around
     # the all-reduce.
-    RING_EVERY = 8
+    # Round 6: at least RING_LAUNCHES bracketed launches whatever --steps is (the driver's --steps 20 used to bracket FOUR, and one 5.5 ms outlier
+    # moved their mean by 7 %: the round-5 record had avg_launch_ms > ms_per_step), and the MEDIAN launch is what the roofline is computed from
+    # (min / max / mean stand beside it).  A step of tens of milliseconds (the 3-D net) is bracketed every time: 0.03 ms of events do not show there.
+    RING_EVERY = 8 if 1e3 * dt / steps < 20.0 else 1
+    RING_LAUNCHES = 32
+    ring_steps = max(steps, RING_LAUNCHES * RING_EVERY)
     stamps = torch.zeros(128, dtype=torch.int64, device=dev)
     eng.lib.set_stamp_buffer(stamps.data_ptr())
     if getattr(model, "_reduce", False):
@@ -360,13 +365,28 @@ def main():
     eng.lib.profile_ring_arm(4096, every=RING_EVERY)
     barrier()
     t0 = time.perf_counter()
-    step(max(steps, 4 * RING_EVERY))
+    step(ring_steps)
     barrier()
-    ring_block_ms_per_step = 1e3 * (time.perf_counter() - t0) / max(steps, 4 * RING_EVERY)      # this block's own wall time: the launches below are a part of THESE steps
+    ring_block_ms_per_step = 1e3 * (time.perf_counter() - t0) / ring_steps      # this block's own wall time: the launches below are a part of THESE steps
     ring_ms, ring_streams = eng.lib.profile_ring_read()
     eng.lib.set_stamp_buffer(None)
     collo_ms = ring_ms[ring_streams >= 4]
     side_ms = ring_ms[ring_streams == 1]
+    ms_step = 1e3 * dt / steps
+
+    def launch_stat():
+        """the dominant launch's duration for the roofline: MEDIAN of the bracketed launches; checked against the step it is a part of
+        (launch <= 1.01 x ms_per_step + 0.04 ms: tests/test_gpu_bench_contract.py) -- events that do not fit are not quoted: the kernel's own
+        wall-clock stamps (workgroup 0, first to last step: workgroup0_ms) take their place and the line says so"""
+        if not collo_ms.size:
+            return None
+        med = float(np.median(collo_ms))
+        st_ = {"launch_ms": med, "launch_ms_median": med, "launch_ms_min": float(collo_ms.min()), "launch_ms_max": float(collo_ms.max()),
+               "launch_ms_mean": float(collo_ms.mean()), "launches_timed": int(collo_ms.size), "launch_events_inconsistent": False}
+        if med > 1.01 * ms_step + 0.04:
+            st_["launch_events_inconsistent"] = True
+            st_["launch_ms"] = wg0_ms_raw if wg0_ms_raw is not None else min(med, ms_step)
+        return st_
     st = stamps.cpu().numpy()
     launch_cycles = int(st[125] - st[124])                 # the LAST collocation launch of the block (every launch overwrites the slots)
     # The same workgroup stamps the device's constant-rate wall clock beside the cycle counter, around the same interval (its first to its last
@@ -376,7 +396,8 @@ def main():
     wall_khz = int(eng.lib.lib.pinn_debug_wall_clock_khz())
     wall_ticks = int(st[121] - st[120])
     wg0_ms = (1e3 * wall_ticks / (wall_khz * 1e3)) if wall_khz > 0 and wall_ticks > 0 else None
-    if wg0_ms is not None and collo_ms.size and not (0.2 < wg0_ms / float(collo_ms.mean()) < 1.02):
+    wg0_ms_raw = wg0_ms
+    if wg0_ms is not None and collo_ms.size and not (0.2 < wg0_ms / float(np.median(collo_ms)) < 1.02):
         wg0_ms = None                                      # (a rate that does not fit the events: do not quote it)
     shader_clock_ghz = (launch_cycles / (wg0_ms * 1e-3) / 1e9) if launch_cycles > 0 and wg0_ms is not None else None
     allreduce_ms = None
@@ -402,6 +423,9 @@ def main():
                              "the dominant kernel ran at on THIS box -- it is power-limited, and box-to-box differences of ms_per_step follow it.  "
                              "ms_per_step x shader_clock_ghz = shader cycles per step is what compares across boxes",
         "workgroup0_ms": wg0_ms,
+        "mcycles_per_step": (ms_step * shader_clock_ghz) if shader_clock_ghz is not None else None,
+        "mcycles_per_step_note": "ms_per_step x shader_clock_ghz: million shader cycles per step -- the figure that compares across boxes (the kernel is power-limited "
+                                 "and boxes differ by +-2.5 % in clock)",
         "allreduce_ms": allreduce_ms,
         "rank_share": share if share > 1 else None,
     }
@@ -414,6 +438,7 @@ def main():
         out["config"]["collective"] = args.collective
     out["config"]["step_call"] = not args.no_step_call
     if rank == 0:
+        ls = launch_stat()
         # MFMAs issued per algorithmic product (forward and reverse chain: 8 of 12 contractions, 3 per product; weight gradient: 4 of 12): the
         # narrow four- and five-stream collocation kernels multiply high parts only there (1, round 4), the LDS-operand layouts (padded width
         # > 64) both parts of both (3)
@@ -423,8 +448,8 @@ def main():
             # ---- roofline of the dominant kernel: HIP events around its launches in the running step loop (the ring block above); on
             # the two-kernel path (no fused launch recorded) the synchronous per-kernel profile of one call
             acc = {"repack": 0.0, "chain": 0.0, "wgrad": 0.0, "reduce": 0.0}
-            if collo_ms.size:
-                acc["chain"] = float(collo_ms.mean())
+            if ls is not None:
+                acc["chain"] = ls["launch_ms"]
             else:
                 x, y, t = (a[:pts_per_rank] for a in model._collo)
                 tw = [1.0 / pts_per_rank] * 7
@@ -443,21 +468,23 @@ def main():
                                "traffic": None, "traffic_measured_in_this_run": False, "traffic_from_profiles": traffic_from_profiles({64: "fused", 80: "wide80", 100: "wide100"}.get(args.width, "none")) if fused and args.precision == "f16x3" else None,
                                "launches_per_step": n_launch, "avg_launch_ms": acc["chain"] / n_launch, "algorithmic_flop_per_point": kflop,
                                "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "launch_ms_min_max": [float(collo_ms.min()), float(collo_ms.max())] if collo_ms.size else None,
+                               "launch_stat": ls,
                                "side_sets_launch_ms": float(side_ms.mean()) if side_ms.size else None,
                                "ring_every": RING_EVERY,
                                "step_decomposition_ms": None if not collo_ms.size else {
-                                   "collocation_launch": float(collo_ms.mean()), "side_sets_launch": float(side_ms.mean()) if side_ms.size else 0.0,
-                                   "rest_of_step": 1e3 * dt / steps - float(collo_ms.mean()) - (float(side_ms.mean()) if side_ms.size else 0.0),
+                                   "collocation_launch": ls["launch_ms"], "side_sets_launch": float(np.median(side_ms)) if side_ms.size else 0.0,
+                                   "rest_of_step": ms_step - ls["launch_ms"] - (float(np.median(side_ms)) if side_ms.size else 0.0),
                                    "note": "rest_of_step = ms_per_step - the fused launch(es) = repack + reduction + Adam (+ collective) + launch gaps.  Since round 5 "
                                            "the collocation set and the side sets are ONE launch (fused_step_kernel; side_sets_launch 0).  The two events around a bracketed "
                                            "launch cost it 0.02-0.03 ms that the unbracketed steps of the timed blocks do not pay (events on every 8th step only), so "
-                                           "avg_launch_ms over-states the launch by that much and frac is conservative (contract: launches <= 1.01 x ms_per_step + 0.04 ms)"},
+                                           "avg_launch_ms (the median of launch_stat) over-states the launch by that much and frac is conservative (contract: launch <= 1.01 x "
+                                           "ms_per_step + 0.04 ms, checked in this run: launch_stat.launch_events_inconsistent)"},
                                "issued_mfma_tflops": tflops * issued,
                                "frac_incl_side_sets": (lambda ns: (kflop * pts_per_rank + flop_per_point(layers, 1) * ns) / (acc["chain"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS)(
                                    sum(v[0].numel() for v in model._sides.values())) if fused else None,
                                "frac_incl_side_sets_note": "since round 5 the launch also evaluates the value-only side sets (one stream: 3 x 2 sum|W| flops per "
                                                            "side point); `achieved` / `frac` count the collocation points only, as in the earlier rounds",
-                               "note": "achieved = algorithmic flops (one product per contraction) / mean HIP-event duration of the launches of one "
+                               "note": "achieved = algorithmic flops (one product per contraction) / MEDIAN HIP-event duration (launch_stat) of >= 32 bracketed launches of one "
                                        "more block of steps behind the timed ones (events in stream order, nothing synchronises in between); the f16x3 mode issues 3 MFMAs per "
                                        f"product in the forward / reverse chain and {wg_mfma} in the weight gradient, so a 100 %-busy matrix pipe is frac {1.0 / issued:.3f}. "
                                        "Measured limiter: one wave's in-order issue of vector instructions + MFMAs and its vector-memory instructions (DESIGN.md section 4, profiles/r04_opcode_issue_costs.md). traffic: NOT MEASURED IN THIS "
@@ -466,14 +493,14 @@ def main():
         elif cfg == "plate" and eng.lib.supported_width(layers[1]) <= 96 and len(layers) - 2 in (4, 8):
             # ---- the five-stream instantiation of the fused kernel: HIP events around the kernel on the launch stream (process-wide
             # profiling hook of the library, include/pinn_hip.h)
-            acc = {"repack": 0.0, "chain": float(collo_ms.mean()) if collo_ms.size else 0.0, "wgrad": 0.0 if collo_ms.size else 1.0, "reduce": 0.0}
+            acc = {"repack": 0.0, "chain": ls["launch_ms"] if ls is not None else 0.0, "wgrad": 0.0 if ls is not None else 1.0, "reduce": 0.0}
             fused = acc["wgrad"] == 0.0
             tflops = flop_pt * pts_per_rank / (acc["chain"] * 1e-3) / 1e12 if fused else 0.0
             out["roofline"] = {"kernel": "fused_wave_kernel<..., NS = 5> (forward with the second time derivative + plate head + reverse chain + weight gradient)",
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
                                "traffic": None, "traffic_measured_in_this_run": False, "traffic_from_profiles": traffic_from_profiles({64: "plate", 70: "plate70"}.get(args.width, "none")) if fused and args.precision == "f16x3" else None,
                                "launches_per_step": 1, "avg_launch_ms": acc["chain"], "algorithmic_flop_per_point": flop_pt,
-                               "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "issued_mfma_tflops": tflops * issued,
+                               "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "launch_stat": ls, "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; the hole-traction set (9960 points) is a second, one-stream "
                                        "launch of the fused kernel.  The launches are timed in one more block of `steps` steps behind the timed ones "
@@ -483,8 +510,8 @@ def main():
         elif cfg == "nc3d" and args.precision == "f16x3" and layers[1:-1] == [128] * 10:
             # ---- the 3-D instantiation of the fused kernel (Fused<..., NL = 10, NS = 5, DIN = 4>): HIP events around the collocation launch
             acc = {"repack": 0.0, "chain": 0.0, "wgrad": 0.0, "reduce": 0.0}
-            if collo_ms.size:
-                acc["chain"] = float(collo_ms.mean())
+            if ls is not None:
+                acc["chain"] = ls["launch_ms"]
             else:
                 x, y, z, t = model._rows(0, model._n_collo)
                 tw = [1.0 / pts_per_rank] * 12
@@ -505,7 +532,7 @@ def main():
                                "bound": "mfma", "achieved": tflops, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / MFMA_PEAK_TFLOPS,
                                "traffic": None, "traffic_measured_in_this_run": False, "traffic_from_profiles": traffic_from_profiles("nc3d") if fused else None,
                                "launches_per_step": n_launch, "avg_launch_ms": t_ms / n_launch, "algorithmic_flop_per_point": flop_pt,
-                               "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "issued_mfma_tflops": tflops * issued,
+                               "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "launch_stat": ls, "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; measured limiter of the LDS-operand layouts: the bytes "
                                        "of parked states and in-memory weight-gradient sums through L2 (DESIGN_HISTORY.md section 6).  traffic not measured in this run"}

@@ -5,7 +5,9 @@
 //   build/c_abi_demo [n_points]
 //
 // Prints the seven residual mean squares of net_f_sig (INF:221-265,104-110) of a fresh Xavier 8x64 net on random collocation
-// points, the gradient norm, and the loss after 20 Adam steps (TF1 rule, INF:131-133).
+// points, the gradient norm, and the loss after 20 Adam steps (TF1 rule, INF:131-133).  Every evaluation goes through
+// pinn_wave2d_loss_grad_checked: the finite-gradient ladder (weight range of the fused format, fp16 range of the reverse pass) that the
+// Python classes run around their calls, here as a library call; the last lines provoke both rungs on purpose.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
@@ -58,9 +60,10 @@ int main(int argc, char** argv) {
     for (float& w : tw) w = 1.0f / (float)n;        // loss = loss_f_uv + loss_f_s with mean squares (INF:104-110,119)
     float loss[8];
     std::vector<float> grad(nparams);
+    pinn_range_state range = {0, 0, 0, 0};          // kept across the run: adjoint shift / two-kernel flag the ladder has settled on
     for (int step = 0; step <= 20; ++step) {
-        CHECK_PINN(pinn_wave2d_loss_grad(d_theta, layers, n_layers, d_x, d_y, d_t, n, lb, ub, 1, 2.5, 0.25, 1.0, 1, tw, d_loss, d_grad, 0, PINN_PREC_F16X3,
-                                         d_ws, ws_bytes, nullptr));
+        CHECK_PINN(pinn_wave2d_loss_grad_checked(d_theta, layers, n_layers, d_x, d_y, d_t, n, lb, ub, 1, 2.5, 0.25, 1.0, 1, tw, d_loss, d_grad, PINN_PREC_F16X3,
+                                                 d_ws, ws_bytes, nullptr, &range));
         if (step == 0 || step == 20) {
             CHECK_HIP(hipMemcpy(loss, d_loss, 7 * 4, hipMemcpyDeviceToHost));
             CHECK_HIP(hipMemcpy(grad.data(), d_grad, nparams * 4, hipMemcpyDeviceToHost));
@@ -74,6 +77,31 @@ int main(int argc, char** argv) {
         if (step < 20) CHECK_PINN(pinn_adam_step(d_theta, d_m, d_v, d_grad, nparams, 1e-3, 0.9, 0.999, 1e-8, step + 1, nullptr));
     }
     CHECK_HIP(hipDeviceSynchronize());
+    std::printf("ladder after training: shift %d two_kernel %d\n", range.adjoint_shift, range.two_kernel);
+    {   // both rungs on purpose.  (a) output layer x 3000: residuals ~1e3 x their trained size, the fp16 reverse pass overflows -> adjoint shift
+        CHECK_HIP(hipMemcpy(theta.data(), d_theta, nparams * 4, hipMemcpyDeviceToHost));
+        std::vector<float> big(theta);
+        const int last_w = nparams - (layers[n_layers - 2] * layers[n_layers - 1] + layers[n_layers - 1]);
+        for (int i = last_w; i < nparams - layers[n_layers - 1]; ++i) big[i] *= 3000.0f;
+        CHECK_HIP(hipMemcpy(d_theta, big.data(), nparams * 4, hipMemcpyHostToDevice));
+        pinn_range_state r1 = {0, 0, 0, 0};
+        CHECK_PINN(pinn_wave2d_loss_grad_checked(d_theta, layers, n_layers, d_x, d_y, d_t, n, lb, ub, 1, 2.5, 0.25, 1.0, 1, tw, d_loss, d_grad, PINN_PREC_F16X3,
+                                                 d_ws, ws_bytes, nullptr, &r1));
+        int finite = 0;
+        float wmax = 0;
+        CHECK_PINN(pinn_probe_ranges(d_theta, d_grad, nparams, d_ws, ws_bytes, nullptr, &finite, &wmax));
+        std::printf("ladder overflow: shift %d two_kernel %d attempts %d finite %d\n", r1.adjoint_shift, r1.two_kernel, r1.attempts, finite);
+        // (b) one hidden weight beyond the fused kernels' format (|w| <= %g): the fused path returns NaN throughout -> two-kernel path
+        big = theta;
+        big[layers[0] * layers[1] + layers[1] + 5] = 2100.0f;
+        CHECK_HIP(hipMemcpy(d_theta, big.data(), nparams * 4, hipMemcpyHostToDevice));
+        pinn_range_state r2 = {0, 0, 0, 0};
+        CHECK_PINN(pinn_wave2d_loss_grad_checked(d_theta, layers, n_layers, d_x, d_y, d_t, n, lb, ub, 1, 2.5, 0.25, 1.0, 1, tw, d_loss, d_grad, PINN_PREC_F16X3,
+                                                 d_ws, ws_bytes, nullptr, &r2));
+        CHECK_PINN(pinn_probe_ranges(d_theta, d_grad, nparams, d_ws, ws_bytes, nullptr, &finite, &wmax));
+        std::printf("ladder range: shift %d two_kernel %d attempts %d finite %d wmax %g limit %g\n", r2.adjoint_shift, r2.two_kernel, r2.attempts, finite, wmax,
+                    pinn_fused_weight_limit());
+    }
     std::printf("abi %d ok\n", pinn_abi_version());
     return 0;
 }

@@ -78,7 +78,9 @@ enum {
     PINN_ERR_PRECISION = -3,   /* unknown precision_mode */
     PINN_ERR_WORKSPACE = -4,   /* workspace smaller than pinn_min_workspace_bytes() or misaligned */
     PINN_ERR_SIZE = -5,        /* n < 0 (n == 0 is a valid empty batch: zero sums, zero / untouched gradient) */
-    PINN_ERR_COLLECTIVE = -6   /* pinn_p2p_*: not connected, or a rank did not arrive within the bounded wait (~2 s) */
+    PINN_ERR_COLLECTIVE = -6,  /* pinn_p2p_*: not connected; a coarse-grained buffer across devices (pinn_p2p_connect); or a rank did not arrive within the
+                                * bounded wait of some call (pinn_p2p_set_timeout_ms, default 30 s) -- that call's buffer is then NaN on this rank */
+    PINN_ERR_RANGE = -7        /* pinn_wave2d_loss_grad_checked: gradient non-finite even on the two-kernel path with the reverse pass scaled by 2^-24 */
 };
 
 /* Padded hidden width the kernels use for a real hidden width h (0 if unsupported). */
@@ -215,6 +217,35 @@ int pinn_stream_loss_grad(const float* params_flat, const int* layers, int n_lay
  * (pinn_stream_loss_grad, whose reported sums carry the normalised weights, ignores the shift.) */
 #define PINN_ADJOINT_SHIFT(k) (((k) & 0x1f) << 16)
 
+/* ---- The finite-gradient ladder as library calls (round 6): what the host classes do around every evaluation whose result they look at
+ * (pinn_elastodynamics_amd/elastic_wave.py: evaluate_with_finite_gradient / leave_fused_path_if_weights_out_of_range), for callers of this ABI
+ * that are not Python.  Two ranges bound the 16-bit modes: |w| <= pinn_fused_weight_limit() in the fused kernels' weight format (beyond it a
+ * call returns NaN throughout: sums AND gradient) and the fp16 range of the reverse pass's adjoints (beyond it the gradient alone is non-finite).
+ *   pinn_probe_ranges              one small reduction + a stream synchronisation: is grad_flat[0..n_params) finite, and max |params_flat[i]|
+ *                                  (either pointer may be NULL).  Uses 16 bytes at the end of `workspace` (dead data between calls).
+ *   pinn_wave2d_loss_grad_checked  pinn_wave2d_loss_grad (overwrite form) + the ladder, SYNCHRONOUS: evaluates with the flags in `state`, probes, and
+ *                                  on a non-finite gradient either sets state->two_kernel (a weight beyond the fused format: the calls leave the
+ *                                  fused path for good) or raises state->adjoint_shift by 4 (up to 24) and repeats.  PINN_OK: loss sums and gradient
+ *                                  are finite and final; PINN_ERR_RANGE: the ladder is exhausted.  The caller keeps `state` between calls (start
+ *                                  from zeros) and may lower adjoint_shift again as its loss falls (the host classes do at 1/256 of the loss the
+ *                                  shift was raised at).  The TWO_KERNEL flag and the shift bits of precision_mode are ignored: `state` owns them.
+ * The other families take the same ladder around their own call: probe, then PINN_FLAG_TWO_KERNEL or PINN_ADJOINT_SHIFT(k + 4). */
+typedef struct pinn_range_state {
+    int adjoint_shift;   /* in/out: 0..24 */
+    int two_kernel;      /* in/out: 0 / 1 */
+    int attempts;        /* out: evaluations the last checked call made */
+    int reserved;
+} pinn_range_state;
+int pinn_probe_ranges(const float* params_flat, const float* grad_flat, int64_t n_params, void* workspace, size_t ws_bytes, void* stream,
+                      int* grad_finite_out, float* max_abs_weight_out);
+int pinn_wave2d_loss_grad_checked(const float* params_flat, const int* layers, int n_layers,
+                                  const float* x, const float* y, const float* t, int64_t n,
+                                  const double lb[3], const double ub[3], int normalize,
+                                  double E, double mu, double rho, int plane_strain,
+                                  const float term_weights[7],
+                                  float* loss_terms_out, float* grad_flat_out,
+                                  int precision_mode, void* workspace, size_t ws_bytes, void* stream, pinn_range_state* state);
+
 /* Several value-only sets in ONE call (the reference evaluates loss_IC, loss_SRC, loss_NB / loss_FIX of a step from one set of
  * variables, INF:111-119,297-305): same arithmetic as pinn_data_loss_grad per set, gradients summed, sums of set k written to
  * sets[k].loss_terms_out[0..n_out).  For nets the fused kernel covers this is one launch instead of n_sets; otherwise the sets
@@ -321,15 +352,36 @@ int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_fla
  *   the caller exchanges the world's handles (any out-of-band channel: the model classes use torch.distributed.all_gather_object);
  *   pinn_p2p_connect  opens the peers' buffers;   pinn_p2p_allreduce  buf[0..n) <- sum over ranks, enqueued on `stream`; with `adam` the
  *                     first n_params entries of the sum also update params_flat / adam->m / adam->v;   every rank must make the same calls.
- *   pinn_p2p_status   synchronises and returns 0, or PINN_ERR_COLLECTIVE if a rank did not arrive within the bounded wait of some call
- *                     (the kernel then returns without hanging the GPU; its results are void). */
-#define PINN_IPC_HANDLE_BYTES 64
+ *   pinn_p2p_status   synchronises the device and returns 0, or PINN_ERR_COLLECTIVE if some call failed;   pinn_p2p_peek_status reads the same
+ *                     word (pinned host memory, written by the kernel) WITHOUT synchronising: meaningful behind a synchronisation the caller
+ *                     made anyway -- the model classes read it at every host sync point of train() / train_bfgs() and raise.
+ * Failure semantics (round 6):
+ *   - a call succeeds or fails AS A WHOLE on a rank (grid agreement of its 64 workgroups): never a half-applied sum or Adam update;
+ *   - a failed call leaves buf[0..n) = NaN on that rank (a caller that only looks at its loss / gradient still notices), skips Adam, sets the
+ *     status word, and writes its call number into every peer's abort word: a peer that arrives later -- or had completed the call already --
+ *     fails its current or next call at once.  Failure is sticky: every later call on the comm fails immediately;
+ *   - the wait is bounded by the device's constant-rate wall clock: pinn_p2p_set_timeout_ms (default 30 000 ms, or the environment variable
+ *     PINN_P2P_TIMEOUT_MS at create time): longer than legitimate skew between ranks (first-step lazy initialisation, a rank writing a
+ *     checkpoint), short enough that a dead rank ends the run instead of hanging the GPU;
+ *   - pinn_p2p_connect returns PINN_ERR_COLLECTIVE, before mapping anything, if this rank's or a peer's buffer is coarse-grained
+ *     (hipExtMallocWithFlags(hipDeviceMallocFinegrained) refused) AND the two live on different physical devices (PCI bus ids travel with the
+ *     handles): coarse-grained memory is coherent at kernel boundaries only.  Ranks that share one GPU (the tests) may use it.
+ *   - calls of one comm are made on ONE stream (the grid agreement counts workgroups per call number);
+ *   - pushes are 16-byte stores when buf is 16-byte aligned and n % 4 == 0 (the model classes' buffers are), 4-byte stores otherwise.
+ * Single-node use across physical GPUs is UNVERIFIED on hardware (the builder's boxes have one GPU: world 2 on one device is what the tests run;
+ * tests/test_gpu_dp.py::test_p2p_across_two_devices runs where torch.cuda.device_count() >= 2). */
+#define PINN_IPC_HANDLE_BYTES 128      /* hipIpcMemHandle_t (64) + memory kind + PCI bus id of the owning device */
 typedef struct pinn_p2p_comm pinn_p2p_comm;
 int pinn_p2p_create(int rank, int world, int64_t max_floats, pinn_p2p_comm** comm_out, unsigned char handle_out[PINN_IPC_HANDLE_BYTES]);
 int pinn_p2p_connect(pinn_p2p_comm* comm, const unsigned char* all_handles /* world x PINN_IPC_HANDLE_BYTES, rank order */);
+int pinn_p2p_set_timeout_ms(pinn_p2p_comm* comm, double timeout_ms);
 int pinn_p2p_allreduce(pinn_p2p_comm* comm, float* buf, int64_t n, float* params_flat, const pinn_adam_state* adam, int64_t n_params, void* stream);
 int pinn_p2p_status(pinn_p2p_comm* comm, int* fine_grained_out);
+int pinn_p2p_peek_status(pinn_p2p_comm* comm);
 int pinn_p2p_destroy(pinn_p2p_comm* comm);
+/* Testing hook (process-wide): 1 makes pinn_p2p_create allocate plain (coarse-grained) device memory, as if the runtime had refused the
+ * fine-grained flag; returns the previous setting.  For the refusal test of pinn_p2p_connect. */
+int pinn_p2p_debug_force_coarse(int enable);
 
 /* Testing hook (process-wide): 0 forces the two-kernel path (chain + wgrad kernels) even where the
  * fused kernel applies; 1 (default) prefers the fused kernel.  Returns the previous setting.  Both paths

@@ -45,6 +45,11 @@ class AdamState(C.Structure):
                 ("step", C.c_int64)]
 
 
+class RangeState(C.Structure):
+    """pinn_range_state of include/pinn_hip.h: what the finite-gradient ladder of pinn_wave2d_loss_grad_checked carries between calls"""
+    _fields_ = [("adjoint_shift", C.c_int32), ("two_kernel", C.c_int32), ("attempts", C.c_int32), ("reserved", C.c_int32)]
+
+
 class PinnLibError(RuntimeError):
     pass
 
@@ -81,6 +86,12 @@ class PinnLib:
         L.pinn_wave2d_loss_grad.restype = i32
         L.pinn_wave2d_loss_grad_profile.argtypes = L.pinn_wave2d_loss_grad.argtypes + [pf32]
         L.pinn_wave2d_loss_grad_profile.restype = i32
+        # (round 6) the finite-gradient ladder as library calls: no `accumulate` argument, a pinn_range_state at the end
+        L.pinn_wave2d_loss_grad_checked.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, f64, f64, f64, i32, pf32,
+                                                    vp, vp, i32, vp, sz, vp, C.POINTER(RangeState)]
+        L.pinn_wave2d_loss_grad_checked.restype = i32
+        L.pinn_probe_ranges.argtypes = [vp, vp, i64, vp, sz, vp, C.POINTER(i32), pf32]
+        L.pinn_probe_ranges.restype = i32
         L.pinn_data_loss_grad.argtypes = [vp, pi32, i32, vp, vp, vp, i64, pf64, pf64, i32, vp, pf32, vp, vp, i32, i32, vp, sz, vp]
         L.pinn_data_loss_grad.restype = i32
         L.pinn_data_loss_grad_multi.argtypes = [vp, pi32, i32, C.POINTER(PointSet), i32, pf64, pf64, i32, vp, i32, i32, vp, sz, vp]
@@ -154,6 +165,9 @@ class PinnLib:
     def check(self, rc: int, what: str):
         if rc != 0:
             raise PinnLibError(f"{what} failed: {self.lib.pinn_error_string(rc).decode()} (code {rc})")
+
+    def error_string(self, rc: int) -> str:
+        return f"{self.lib.pinn_error_string(rc).decode()} (code {rc})"
 
     # -- entry points --------------------------------------------------------------------------
     def abi_version(self) -> int:
@@ -242,6 +256,24 @@ class PinnLib:
                                             self._floats(term_weights, 7), loss_out, grad_out, int(bool(accumulate)), mode_bits(prec),
                                             ws, int(ws_bytes), stream)
         self.check(rc, "pinn_wave2d_loss_grad")
+
+    def wave2d_loss_grad_checked(self, params, layers, x, y, t, n, lb, ub, normalize, E, mu, rho, plane_strain, term_weights,
+                                 loss_out, grad_out, prec, ws, ws_bytes, state: "RangeState", stream=0) -> int:
+        """pinn_wave2d_loss_grad_checked: the call + the finite-gradient ladder, synchronous; ``state`` is kept by the caller.  Returns the rc
+        (PINN_ERR_RANGE = -7 is a result a caller may want to handle, everything else raises)."""
+        rc = self.lib.pinn_wave2d_loss_grad_checked(params, self._ints(layers), len(layers), x, y, t, int(n), self._d3(lb), self._d3(ub),
+                                                    int(bool(normalize)), float(E), float(mu), float(rho), int(bool(plane_strain)),
+                                                    self._floats(term_weights, 7), loss_out, grad_out, mode_bits(prec), ws, int(ws_bytes), stream,
+                                                    C.byref(state))
+        if rc != -7:
+            self.check(rc, "pinn_wave2d_loss_grad_checked")
+        return rc
+
+    def probe_ranges(self, params, grad, n_params, ws, ws_bytes, stream=0):
+        """(gradient finite?, max |w|) -- one small reduction and a stream synchronisation"""
+        fin, wmax = C.c_int32(0), C.c_float(0.0)
+        self.check(self.lib.pinn_probe_ranges(params or None, grad or None, int(n_params), ws, int(ws_bytes), stream, C.byref(fin), C.byref(wmax)), "pinn_probe_ranges")
+        return bool(fin.value), float(wmax.value)
 
     def wave2d_loss_grad_profile(self, params, layers, x, y, t, n, lb, ub, normalize, E, mu, rho, plane_strain, term_weights,
                                  loss_out, grad_out, accumulate, prec, ws, ws_bytes, stream=0):

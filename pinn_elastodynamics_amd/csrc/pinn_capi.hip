@@ -86,7 +86,7 @@ namespace pinn { long g_path_counts[5] = {0, 0, 0, 0, 0}; int g_xcd_tail_permill
 
 extern "C" {
 
-int pinn_abi_version(void) { return 1; }
+int pinn_abi_version(void) { return 2; }      // 2 (round 6): PINN_IPC_HANDLE_BYTES 64 -> 128, pinn_p2p_set_timeout_ms / _peek_status, pinn_wave2d_step_checked
 
 float pinn_fused_weight_limit(void) { return FUSED_OPERAND_MAX / FUSED_WEIGHT_SCALE; }
 
@@ -166,7 +166,8 @@ const char* pinn_error_string(int code) {
         case PINN_ERR_PRECISION: return "unknown precision_mode";
         case PINN_ERR_WORKSPACE: return "workspace too small or not 256-byte aligned";
         case PINN_ERR_SIZE: return "n must not be negative";
-        case PINN_ERR_COLLECTIVE: return "p2p collective: not connected, or a rank did not arrive within the bounded wait";
+        case PINN_ERR_COLLECTIVE: return "p2p collective: not connected, a coarse-grained buffer across devices, or a rank did not arrive within the bounded wait (the call failed as a whole: buffer NaN, no Adam update)";
+        case PINN_ERR_RANGE: return "gradient non-finite even on the two-kernel path with the reverse pass scaled by 2^-24 (pinn_wave2d_loss_grad_checked)";
         default: return code > 0 ? hipGetErrorString((hipError_t)code) : "unknown error";
     }
 }
@@ -759,6 +760,83 @@ int pinn_adam_step(float* params_flat, float* m, float* v, const float* grad_fla
     hipLaunchKernelGGL((adam_tf1_kernel<0>), dim3((unsigned)((n_params + 255) / 256)), dim3(256), 0, (hipStream_t)stream, params_flat, m, v,
                        grad_flat, (long)n_params, (float)lr_t, (float)beta1, (float)beta2, (float)eps);
     return (int)hipGetLastError();
+}
+
+
+// ---- the finite-gradient ladder for callers that are not Python (round 6; elastic_wave.py: evaluate_with_finite_gradient) ----------------
+namespace {
+__global__ __launch_bounds__(256) void probe_ranges_kernel(const float* params, const float* grad, long n, unsigned* out /* {non-finite count (saturating flag), bits of max |w|} */) {
+    unsigned bad = 0u, wmax = 0u;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        if (grad != nullptr) {
+            const unsigned g = __builtin_bit_cast(unsigned, grad[i]);
+            if ((g & 0x7f800000u) == 0x7f800000u) bad = 1u;              // Inf or NaN
+        }
+        if (params != nullptr) {
+            const unsigned w = __builtin_bit_cast(unsigned, params[i]) & 0x7fffffffu;      // |w|: non-negative floats order like their bits (NaN sorts above Inf)
+            wmax = w > wmax ? w : wmax;
+        }
+    }
+    if (bad) atomicOr(&out[0], 1u);
+    if (wmax) atomicMax(&out[1], wmax);
+}
+}  // namespace
+
+int pinn_probe_ranges(const float* params_flat, const float* grad_flat, int64_t n_params, void* workspace, size_t ws_bytes, void* stream,
+                      int* grad_finite_out, float* max_abs_weight_out) {
+    if (!workspace || (!params_flat && !grad_flat)) return PINN_ERR_NULL;
+    if (n_params < 1) return PINN_ERR_SIZE;
+    if (ws_bytes < 256) return PINN_ERR_WORKSPACE;
+    // two words at the very end of the workspace: behind a finished call that region is dead data (scratch images / panels are written before
+    // they are read in every call), and nothing a later PINN_FLAG_WEIGHTS_PACKED call relies on lives there
+    unsigned* out = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + ((ws_bytes - 16) & ~(size_t)15));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    int rc = (int)hipMemsetAsync(out, 0, 8, st);
+    if (rc) return rc;
+    const long blocks = (n_params + 255) / 256;
+    hipLaunchKernelGGL(probe_ranges_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(256), 0, st, params_flat, grad_flat, (long)n_params, out);
+    if ((rc = (int)hipGetLastError())) return rc;
+    unsigned host[2] = {0u, 0u};
+    if ((rc = (int)hipMemcpyAsync(host, out, 8, hipMemcpyDeviceToHost, st))) return rc;
+    if ((rc = (int)hipStreamSynchronize(st))) return rc;
+    if (grad_finite_out) *grad_finite_out = host[0] ? 0 : 1;
+    if (max_abs_weight_out) *max_abs_weight_out = __builtin_bit_cast(float, host[1]);
+    return PINN_OK;
+}
+
+int pinn_wave2d_loss_grad_checked(const float* params_flat, const int* layers, int n_layers, const float* x, const float* y, const float* t,
+                                  int64_t n, const double lb[3], const double ub[3], int normalize, double E, double mu, double rho,
+                                  int plane_strain, const float term_weights[7], float* loss_terms_out, float* grad_flat_out,
+                                  int precision_mode, void* workspace, size_t ws_bytes, void* stream, pinn_range_state* state) {
+    if (!state) return PINN_ERR_NULL;
+    if (state->adjoint_shift < 0 || state->adjoint_shift > 24) return PINN_ERR_SIZE;
+    if (n_layers < 2 || !layers) return PINN_ERR_LAYERS;
+    long np_ = 0;
+    for (int i = 0; i + 1 < n_layers; ++i) np_ += (long)layers[i] * layers[i + 1] + layers[i + 1];
+    // the caller's mode word without the two things the ladder owns
+    const int base = precision_mode & ~(PINN_FLAG_TWO_KERNEL | PINN_ADJOINT_SHIFT(31));
+    const bool f16x3 = (base & 0xff) == PINN_PREC_F16X3;
+    state->attempts = 0;
+    for (int attempt = 0; attempt < 9; ++attempt) {
+        const int mode = base | (state->two_kernel ? PINN_FLAG_TWO_KERNEL : 0) | PINN_ADJOINT_SHIFT(state->adjoint_shift);
+        int rc = pinn_wave2d_loss_grad(params_flat, layers, n_layers, x, y, t, n, lb, ub, normalize, E, mu, rho, plane_strain, term_weights, loss_terms_out,
+                                       grad_flat_out, 0, attempt == 0 ? mode : (mode & ~PINN_FLAG_WEIGHTS_PACKED), workspace, ws_bytes, stream);
+        ++state->attempts;
+        if (rc) return rc;
+        int finite = 1;
+        float wmax = 0.0f;
+        if ((rc = pinn_probe_ranges(params_flat, grad_flat_out, np_, workspace, ws_bytes, stream, &finite, &wmax))) return rc;
+        if (finite) return PINN_OK;
+        // 1. a weight beyond the fused kernels' format poisons the whole result with NaN: leave the fused path for good and repeat
+        if (f16x3 && !state->two_kernel && !(wmax <= pinn_fused_weight_limit())) {
+            state->two_kernel = 1;
+            continue;
+        }
+        // 2. the 16-bit reverse pass overflowed (residuals orders of magnitude above their trained size): scale it by another 2^-4
+        if (state->adjoint_shift >= 24) return PINN_ERR_RANGE;
+        state->adjoint_shift = state->adjoint_shift + 4 > 24 ? 24 : state->adjoint_shift + 4;
+    }
+    return PINN_ERR_RANGE;
 }
 
 }  // extern "C"

@@ -187,15 +187,10 @@ struct Host {
         o = align_up(o + (size_t)(NCHUNK > FUSED_GRID ? NCHUNK : FUSED_GRID) * net.nparams * sizeof(float), 256);
         p.wg_acc = o;           // fused kernel: weight-gradient accumulator blocks kept in memory (<= 2 layers x 4 blocks x 1 KB per wave)
         if (WIDTH <= FUSED_MAX_WIDTH) o = align_up(o + (size_t)FUSED_GRID * 4 * FUSED_ACC_BYTES, 256);
-        p.loss_part_b = p.partial_b = p.wg_acc_b = o;
-        if (step_has()) {
-            p.loss_part_b = o;
-            o = align_up(o + (size_t)FUSED_GRID * 4 * FUSED_MAX_SETS * 8 * sizeof(float), 256);
-            p.partial_b = o;
-            o = align_up(o + (size_t)FUSED_GRID * net.nparams * sizeof(float), 256);
-            p.wg_acc_b = o;
-            o = align_up(o + (size_t)FUSED_GRID * 4 * FUSED_ACC_BYTES, 256);
-        }
+        // (fused_step_kernel's second set of partial-sum areas -- the side-set part of the launch -- is NOT part of the fixed plan since round 6:
+        // step() places it behind the scratch images of the call that needs it, sized for that call's side-set grid.  Round 5 reserved
+        // FUSED_GRID x nparams x 4 + 32 MB here for every narrow-net engine, also the frozen 4 x 20 nets and inference-only use.)
+        p.loss_part_b = p.partial_b = p.wg_acc_b = 0;
         p.panels = o;
         p.fixed_end = o;
         p.s_tile = PG::s_tile(net.nl);
@@ -584,7 +579,15 @@ struct Host {
             if (nsteps1 == 0) return 0;
             const long grid4 = nsteps4 < FUSED_GRID ? nsteps4 : FUSED_GRID, grid1 = nsteps1 < FUSED_GRID ? nsteps1 : FUSED_GRID;
             const size_t off1 = align_up((size_t)grid4 * per4, 256);
-            if (c.ws_bytes < p.fixed_end + off1 + (size_t)grid1 * per1) return 0;      // (the two calls then size their grids to the workspace one by one)
+            // the side-set part's own partial sums, behind its scratch images: [loss partials | gradient partials | in-memory weight-gradient sums]
+            size_t bo = align_up(p.fixed_end + off1 + (size_t)grid1 * per1, 256);
+            p.loss_part_b = bo;
+            bo = align_up(bo + (size_t)grid1 * 4 * FUSED_MAX_SETS * 8 * sizeof(float), 256);
+            p.partial_b = bo;
+            bo = align_up(bo + (size_t)grid1 * c.net.nparams * sizeof(float), 256);
+            p.wg_acc_b = bo;
+            bo = align_up(bo + (size_t)grid1 * 4 * FUSED_ACC_BYTES, 256);
+            if (c.ws_bytes < bo) return 0;      // (the two calls then size their grids to the workspace one by one)
             if (NSC == 4 && c.fast_state && SPLIT == 3 && c.net.nl == 8)
                 *out = step_launch<8, NSC, NSC == 4>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1, nterms_a, nterms_b);
             else *out = c.net.nl == 4 ? step_launch<4, NSC, false>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1, nterms_a, nterms_b)

@@ -75,21 +75,28 @@ def unpack_params(flat, layers):
     return Ws, bs
 
 
-def evaluate_with_finite_gradient(engine, evaluate, n_params, state, device_check=0):
+def evaluate_with_finite_gradient(engine, evaluate, n_params, state, device_check=0, check=None):
     """Run ``evaluate()`` (it fills and returns the device buffer [grad | sums]) and bring the result to the host.  The 16-bit
     reverse pass can overflow when residuals are orders of magnitude above their trained size (include/pinn_hip.h,
     PINN_ADJOINT_SHIFT); the sums of squares are still right then, only the gradient is non-finite.  In that case the adjoint
     shift of the engine is raised by 4 (x1/16) and the evaluation repeated; once the loss has fallen 256-fold below where the shift
     was raised, it is lowered again.  ``state`` is a dict the caller keeps between evaluations.  ``device_check=P``: test the first P
     entries on the device and return only the sums behind them.  Deterministic in every rank of a
-    data-parallel job (all ranks see the same reduced buffer)."""
+    data-parallel job (all ranks see the same reduced buffer).  ``check``: called behind the host synchronisation of every evaluation,
+    BEFORE the result is looked at -- the model classes pass the status check of their collective (a failed P2P all-reduce leaves NaN in the
+    buffer: that must raise as a collective failure, not climb this ladder)."""
     for _ in range(7):
         buf = evaluate().detach()
         if device_check:         # gradient stays on the device: check it there, bring only the loss sums back
-            if bool(torch.isfinite(buf[:device_check]).all()):
+            finite = bool(torch.isfinite(buf[:device_check]).all())
+            if check is not None:
+                check()
+            if finite:
                 return buf[device_check:].cpu().numpy()
         else:
             host = buf.cpu().numpy()
+            if check is not None:
+                check()
             if np.isfinite(host[:n_params]).all():
                 return host
         # a weight beyond the fused kernels' format (|w| <= 2047) poisons the whole result with NaN: leave the fused path and repeat
@@ -172,7 +179,7 @@ class DeepHPM(NetApi):
 
     def __init__(self, Collo, SRC, IC, UP, uv_layers, lb, ub, ExistModel=0, modelDir='', *, case="infinite",
                  FIX=None, precision="f16x3", engine=None, seed=1111, process_group=None, verbose=True,
-                 E=2.5, mu=0.25, rho=1.0, always_reduce=False, shard_as=None, collective="rccl", step_call=True):
+                 E=2.5, mu=0.25, rho=1.0, always_reduce=False, shard_as=None, collective="rccl", step_call=True, p2p_timeout_s=None):
         self.count = 0                      # callback counter (INF:26)
         self._step_call = bool(step_call)   # False: the step as separate library calls (collocation, side sets, Adam) -- the same bits; for A / B timing
         self._shift_state = {}              # adjoint-shift bookkeeping of evaluate_with_finite_gradient
@@ -272,7 +279,20 @@ class DeepHPM(NetApi):
             if not hasattr(self.engine, "lib"):
                 raise ValueError("collective='p2p' needs the HIP engine (the one-shot all-reduce is a kernel of libpinn_hip.so)")
             from .p2p import P2PAllReduce
-            self._p2p = P2PAllReduce(self.engine.lib, self._buf.numel(), self.pg)
+            self._p2p = P2PAllReduce(self.engine.lib, self._buf.numel(), self.pg, timeout_s=p2p_timeout_s)
+
+    def _check_collective(self):
+        """collective='p2p': raise if a one-shot all-reduce has failed on this rank (p2p.P2PAllReduce.check: reads a host word, no
+        synchronisation) -- called behind every host sync point of train / train_bfgs / getloss, so that a rank that missed a call, or whose
+        peer did, stops at once instead of training on with diverged parameters (round-5 review)."""
+        if getattr(self, "_p2p", None) is not None:
+            self._p2p.check()
+
+    def close(self):
+        """Release the P2P communicator (collective: every rank calls it).  Nothing to do for collective='rccl'."""
+        p2p, self._p2p = getattr(self, "_p2p", None), None
+        if p2p is not None:
+            p2p.close()
 
     # ------------------------------------------------------------------------------------------
     # checkpoints: the reference's [W_list, b_list] pickle (INF:159-186); .npz is accepted too
@@ -503,7 +523,7 @@ class DeepHPM(NetApi):
 
             if iter > 0 and getattr(self.engine, "needs_finite_probe", False) and not self._shift_state.get("probed"):
                 # once per model: a synchronous evaluation settles the adjoint shift (Adam's steps are small, it rarely moves after)
-                evaluate_with_finite_gradient(self.engine, probe, P, self._shift_state)
+                evaluate_with_finite_gradient(self.engine, probe, P, self._shift_state, check=self._check_collective)
                 self._shift_state["probed"] = True
             for it in range(iter):
                 self.adam_t += 1
@@ -519,6 +539,7 @@ class DeepHPM(NetApi):
                     tm = self._terms_from_sums(rec[it].detach().cpu().numpy().reshape(len(_SLOTS), 8), idx_end - idx_start)
                     print('It: %d, Loss: %.3e' % (it, tm["loss"]))
             sums = rec.detach().cpu().numpy().reshape(iter, len(_SLOTS), 8)
+            self._check_collective()                 # (behind the block's one host synchronisation)
             if iter > 0 and not bool(torch.isfinite(self.theta).all()):
                 raise FloatingPointError("parameters became non-finite during train(): residuals outgrew the 16-bit reverse pass; "
                                          "lower the learning rate or raise engine.adjoint_shift")
@@ -553,7 +574,7 @@ class DeepHPM(NetApi):
 
             def fun(theta64):
                 self.theta.copy_(torch.from_numpy(theta64.astype(np.float32)).to(self.device))
-                host = evaluate_with_finite_gradient(self.engine, evaluate, P, self._shift_state)
+                host = evaluate_with_finite_gradient(self.engine, evaluate, P, self._shift_state, check=self._check_collective)
                 tm = self._terms_from_sums(host[P:].reshape(len(_SLOTS), 8), idx_end - idx_start)
                 relax_adjoint_shift(self.engine, tm["loss"], self._shift_state)
                 self.callback(tm["loss"])
@@ -561,7 +582,7 @@ class DeepHPM(NetApi):
 
             if backend == "torch":
                 def loss_and_grad():
-                    host = evaluate_with_finite_gradient(self.engine, evaluate, 0, self._shift_state, device_check=P)
+                    host = evaluate_with_finite_gradient(self.engine, evaluate, 0, self._shift_state, device_check=P, check=self._check_collective)
                     tm = self._terms_from_sums(host.reshape(len(_SLOTS), 8), idx_end - idx_start)
                     relax_adjoint_shift(self.engine, tm["loss"], self._shift_state)
                     return tm["loss"], self._buf[:P]
@@ -588,6 +609,7 @@ class DeepHPM(NetApi):
         n = self._n_collo
         self._loss_and_grad(0, n)
         host = self._buf[self.n_params:].detach().cpu().numpy().reshape(len(_SLOTS), 8)
+        self._check_collective()
         tm = self._terms_from_sums(host, n)
         if self.layout["NB"] == 0.0 and "NB" in self._sides:
             # loss_NB is reported by getloss even where it is excluded from the total (INF:117-119,374)

@@ -34,7 +34,7 @@ class NavierCauchy3D(NetApi):
 
     def __init__(self, Collo, SRC, IC, TOP, uv_layers, lb, ub, ExistModel=0, modelDir='', *, precision="f16x3", engine=None, seed=1111,
                  process_group=None, verbose=True, E=2.5, mu=0.25, rho=1.0, normalize=True, layout: Optional[dict] = None,
-                 always_reduce=False, collective="rccl"):
+                 always_reduce=False, collective="rccl", p2p_timeout_s=None):
         self.count = 0
         self._shift_state = {}
         self.loss_rec = []
@@ -116,7 +116,18 @@ class NavierCauchy3D(NetApi):
             if not hasattr(self.engine, "lib"):
                 raise ValueError("collective='p2p' needs the HIP engine")
             from .p2p import P2PAllReduce
-            self._p2p = P2PAllReduce(self.engine.lib, self._buf.numel(), self.pg)
+            self._p2p = P2PAllReduce(self.engine.lib, self._buf.numel(), self.pg, timeout_s=p2p_timeout_s)
+
+    def _check_collective(self):
+        """collective='p2p': raise if a one-shot all-reduce has failed on this rank (elastic_wave.DeepHPM._check_collective)"""
+        if getattr(self, "_p2p", None) is not None:
+            self._p2p.check()
+
+    def close(self):
+        """Release the P2P communicator (collective: every rank calls it).  Nothing to do for collective='rccl'."""
+        p2p, self._p2p = getattr(self, "_p2p", None), None
+        if p2p is not None:
+            p2p.close()
 
     # ---- checkpoints: the reference's [W_list, b_list] pickle / npz (INF:159-186) ---------------------------------
     def save_NN(self, fileDir, TYPE=''):
@@ -265,7 +276,7 @@ class NavierCauchy3D(NetApi):
                 return self._buf
 
             if iter > 0 and getattr(self.engine, "needs_finite_probe", False) and not self._shift_state.get("probed"):
-                evaluate_with_finite_gradient(self.engine, probe, P, self._shift_state)
+                evaluate_with_finite_gradient(self.engine, probe, P, self._shift_state, check=self._check_collective)
                 self._shift_state["probed"] = True
             for it in range(iter):
                 self._loss_and_grad(lo, hi)
@@ -275,6 +286,7 @@ class NavierCauchy3D(NetApi):
             if iter > 0 and not bool(torch.isfinite(self.theta).all()):
                 raise FloatingPointError("parameters became non-finite during train(): lower the learning rate or raise engine.adjoint_shift")
             sums = rec.detach().cpu().numpy().reshape(iter, L, 16)
+            self._check_collective()                 # (behind the block's one host synchronisation)
             for it in range(iter):
                 tm = self._terms_from_sums(sums[it], hi - lo)
                 for lst, key in zip(hist, ("loss_f_uv", "loss_f_s", "loss_IC", "loss_SRC", "loss")):
@@ -298,7 +310,7 @@ class NavierCauchy3D(NetApi):
 
             def fun(theta64):
                 self.theta.copy_(torch.from_numpy(theta64.astype(np.float32)).to(self.device))
-                host = evaluate_with_finite_gradient(self.engine, evaluate, P, self._shift_state)
+                host = evaluate_with_finite_gradient(self.engine, evaluate, P, self._shift_state, check=self._check_collective)
                 tm = self._terms_from_sums(host[P:].reshape(L, 16), hi - lo)
                 self.callback(tm["loss"])
                 return tm["loss"], host[:P].astype(np.float64)
@@ -321,6 +333,7 @@ class NavierCauchy3D(NetApi):
         """(loss, loss_f_uv, loss_f_s, loss_IC, loss_SRC, loss_NB) on the full sets (as SEMI:370-385)"""
         self._loss_and_grad(0, self._n_collo)
         tm = self._terms_from_sums(self._buf[self.n_params:].detach().cpu().numpy().reshape(len(_SLOTS), 16), self._n_collo)
+        self._check_collective()
         return tm["loss"], tm["loss_f_uv"], tm["loss_f_s"], tm["loss_IC"], tm["loss_SRC"], tm["loss_NB"]
 
 

@@ -30,7 +30,7 @@ BFGS_OPTIONS = {   # PLATE:220-247
 class PINN(NetApi):
     def __init__(self, Collo, HOLE, IC, LF, RT, UP, LW, DIST, uv_layers, dist_layers, part_layers, lb, ub,
                  partDir='', distDir='', uvDir='', *, precision="f16x3", engines=None, seed=1111, process_group=None, verbose=True,
-                 always_reduce=False, collective="rccl"):
+                 always_reduce=False, collective="rccl", p2p_timeout_s=None):
         self.count = 0
         self._shift_state = {}
         self.lb = np.asarray(lb, dtype=np.float64).reshape(-1)
@@ -120,8 +120,19 @@ class PINN(NetApi):
             if not hasattr(self.eng["uv"], "lib"):
                 raise ValueError("collective='p2p' needs the HIP engine")
             from .p2p import P2PAllReduce
-            self._p2p = P2PAllReduce(self.eng["uv"].lib, self._buf.numel(), self.pg)
+            self._p2p = P2PAllReduce(self.eng["uv"].lib, self._buf.numel(), self.pg, timeout_s=p2p_timeout_s)
         self.refresh_frozen()
+
+    def _check_collective(self):
+        """collective='p2p': raise if a one-shot all-reduce has failed on this rank (elastic_wave.DeepHPM._check_collective)"""
+        if getattr(self, "_p2p", None) is not None:
+            self._p2p.check()
+
+    def close(self):
+        """Release the P2P communicator (collective: every rank calls it).  Nothing to do for collective='rccl'."""
+        p2p, self._p2p = getattr(self, "_p2p", None), None
+        if p2p is not None:
+            p2p.close()
 
     # ------------------------------------------------------------------------------------------------------------------
     def _shard(self, lo, hi):
@@ -292,7 +303,7 @@ class PINN(NetApi):
 
         if iter > 0 and getattr(self.eng["uv"], "needs_finite_probe", False) and not self._shift_state.get("probed"):
             # once per model: settle the adjoint shift (E = 20 makes the plate's early residuals large)
-            evaluate_with_finite_gradient(self.eng["uv"], probe, P, self._shift_state)
+            evaluate_with_finite_gradient(self.eng["uv"], probe, P, self._shift_state, check=self._check_collective)
             self._shift_state["probed"] = True
         for it in range(iter):
             self.adam_t += 1
@@ -303,6 +314,7 @@ class PINN(NetApi):
             if self.verbose and it % 10 == 0 and self.rank == 0:
                 print('It: %d, Loss: %.6e' % (it, self._terms(rec[it].detach().cpu().numpy())["loss"]))
         sums = rec.detach().cpu().numpy()
+        self._check_collective()                     # (behind the loop's one host synchronisation)
         tms = [self._terms(s) for s in sums]
         return ([t["loss_f_uv"] for t in tms], [t["loss_f_s"] for t in tms], [t["loss_HOLE"] for t in tms], [t["loss"] for t in tms])
 
@@ -323,7 +335,7 @@ class PINN(NetApi):
 
         def fun(th):
             self.theta["uv"].copy_(torch.from_numpy(th.astype(np.float32)).to(self.device))
-            host = evaluate_with_finite_gradient(self.eng["uv"], evaluate, P, self._shift_state)
+            host = evaluate_with_finite_gradient(self.eng["uv"], evaluate, P, self._shift_state, check=self._check_collective)
             loss = self._terms(host[P:])["loss"]
             relax_adjoint_shift(self.eng["uv"], loss, self._shift_state)
             self.callback(loss)
@@ -332,7 +344,7 @@ class PINN(NetApi):
         opts = dict(BFGS_OPTIONS["uv"], **(options or {}))
         if backend == "torch":
             def loss_and_grad():
-                host = evaluate_with_finite_gradient(self.eng["uv"], evaluate, 0, self._shift_state, device_check=P)
+                host = evaluate_with_finite_gradient(self.eng["uv"], evaluate, 0, self._shift_state, device_check=P, check=self._check_collective)
                 loss = self._terms(host)["loss"]
                 relax_adjoint_shift(self.eng["uv"], loss, self._shift_state)
                 return loss, self._buf[:P]
@@ -386,6 +398,7 @@ class PINN(NetApi):
         P = self.theta["uv"].numel()
         self._loss_and_grad()
         tm = self._terms(self._buf[P:].detach().cpu().numpy())
+        self._check_collective()
         tm["loss_PART"] = self._pretrain_loss_grad("part", self._part_sets)[0]
         tm["loss_DIST"] = self._pretrain_loss_grad("dist", self._dist_sets)[0]
         if self.verbose and self.rank == 0:

@@ -1,6 +1,7 @@
 """Worker of tests/test_gpu_dp.py::test_p2p_*: ONE rank of a 2-process run on a single GPU (both ranks on cuda:0; gloo carries the IPC-handle
 exchange and the reference collective).  Part 1: P2PAllReduce alone, many back-to-back calls on rank-dependent data (the two slot parities, the
 bounded wait, the Adam fold).  Part 2: DeepHPM(collective="p2p") against DeepHPM over gloo's all_reduce."""
+import os
 import sys
 
 import numpy as np
@@ -16,8 +17,9 @@ from tests.test_gpu_dp import LAYERS, LB, UB, sets        # noqa: E402
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-torch.cuda.set_device(0)
-dev = torch.device("cuda:0")
+ndev = int(os.environ.get("PINN_TEST_NDEV", "1"))           # 1: both ranks on cuda:0 (the builder's boxes); 2: one device per rank (real xGMI / PCIe peer writes)
+torch.cuda.set_device(rank % ndev)
+dev = torch.device(f"cuda:{rank % ndev}")
 eng = HipEngine(LAYERS, precision="f16x3", device=dev, max_points=1 << 15)
 
 # ---- part 1: the collective alone
@@ -43,6 +45,19 @@ for call in range(25):                                        # back to back, no
         eng.adam_step(theta_ref, m_ref, v_ref, expect[:P].to(dev).contiguous(), 1e-3, call // 2 + 1)
 info = comm.status()
 adam_err = float((theta - theta_ref).abs().max())
+# a length that is not a multiple of four floats: the 4-byte push path (the model classes' buffers take the 16-byte one)
+for call in range(4):
+    n2 = n - 1 - call
+    mine = torch.randn(n2, generator=g).to(dev)
+    parts = [torch.zeros(n2) for _ in range(world)]
+    dist.all_gather(parts, mine.cpu())
+    expect = parts[0].clone()
+    for r in range(1, world):
+        expect += parts[r]
+    buf = mine.clone()
+    comm.all_reduce(buf)
+    worst = max(worst, float((buf.cpu() - expect).abs().max()))
+comm.check()
 comm.close()
 
 # ---- part 2: the model class
@@ -57,7 +72,7 @@ for name, kw in (("p2p", dict(collective="p2p")), ("gloo", {})):
     out[name] = (th, np.array(losses[4]))
     if mdl._p2p is not None:
         mdl._p2p.status()
-        mdl._p2p.close()
+    mdl.close()
 if rank == 0:
     np.savez(sys.argv[1], worst=worst, adam_err=adam_err, fine_grained=int(info["fine_grained"]),
              p2p0=out["p2p"][0][0].numpy(), p2p1=out["p2p"][0][1].numpy(), gloo0=out["gloo"][0][0].numpy(), loss_p2p=out["p2p"][1], loss_gloo=out["gloo"][1])

@@ -35,7 +35,7 @@ def test_shared_object_carries_gfx950_code():
 
 
 def test_host_only_entry_points(lib):
-    assert lib.abi_version() == 1
+    assert lib.abi_version() == 2
     assert [lib.supported_width(h) for h in (1, 32, 33, 64, 80, 100, 128, 140, 160, 161)] == [32, 32, 64, 64, 96, 128, 128, 160, 160, 0]
     layers = [3] + 8 * [64] + [7]
     full = lib.workspace_bytes(layers, 2_000_000, "f16x3")

@@ -879,3 +879,53 @@ def test_xcd_aware_tail_takes_every_step_once_emulated(emu, layers, permille):
     for pm in out:
         assert rel(out[pm][0], ss) < 2e-6 and rel(out[pm][1], g) < 1e-4, pm
     assert rel(out[permille][1], out[0][1]) < 2e-6 and not np.array_equal(out[permille][1], out[0][1])
+
+
+def test_checked_call_ladder_emulated(emu):
+    """pinn_wave2d_loss_grad_checked / pinn_probe_ranges (round 6): the model classes' finite-gradient ladder as library calls.  (a) In-range
+    weights: one evaluation, state untouched, the same bits as pinn_wave2d_loss_grad.  (b) A weight of 2100 (> 2047, the fused format's range):
+    the plain call returns NaN throughout; the checked call probes, sets state.two_kernel, repeats on the two-kernel path and agrees with the
+    float64 oracle.  (c) Output-layer weights x 3000 with the term weights of a 4000-point mean (the case of tests/test_gpu_parity.py): the
+    reverse pass overflows fp16, the ladder raises the adjoint shift until the gradient is finite."""
+    from pinn_elastodynamics_amd.capi import RangeState
+    emu.set_fused(True)
+    layers = [3] + 4 * [32] + [7]
+    rng = np.random.default_rng(5)
+    Ws, bs = po.xavier_init(layers, rng)
+    X = po.collocation_points(130, LB, UB, rng)
+    x, y, t = (X[:, k].astype(np.float32).copy() for k in range(3))
+    tw = np.ones(7) / 130
+    wsb = emu.workspace_bytes(layers, 130, "f16x3")
+    ws = aligned(wsb)
+
+    def both(flat, tw_):
+        p32 = flat.astype(np.float32)
+        la, ga = np.full(8, np.nan, np.float32), np.full(p32.size, np.nan, np.float32)
+        lb_, gb = la.copy(), ga.copy()
+        emu.wave2d_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, 130, LB, UB, True, 2.5, 0.25, 1.0, True, tw_,
+                             la.ctypes.data, ga.ctypes.data, False, "f16x3", ws.ctypes.data, wsb)
+        st = RangeState()
+        rc = emu.wave2d_loss_grad_checked(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, 130, LB, UB, True, 2.5, 0.25, 1.0, True, tw_,
+                                          lb_.ctypes.data, gb.ctypes.data, "f16x3", ws.ctypes.data, wsb, st)
+        ss, g, _ = po.wave2d_loss_grad(flat, layers, X[:, 0], X[:, 1], X[:, 2], LB, UB, True, term_weights=tw_)
+        return rc, st, (la, ga), (lb_, gb), (ss, g), p32
+
+    rc, st, plain, chk, ref, p32 = both(po.pack_params(Ws, bs), tw)
+    assert rc == 0 and (st.adjoint_shift, st.two_kernel, st.attempts) == (0, 0, 1)
+    assert np.array_equal(plain[0][:7], chk[0][:7]) and np.array_equal(plain[1], chk[1]) and rel(chk[1], ref[1]) < 1e-4
+    fin, wmax = emu.probe_ranges(p32.ctypes.data, chk[1].ctypes.data, p32.size, ws.ctypes.data, wsb)
+    assert fin and abs(wmax - np.abs(p32).max()) == 0.0
+
+    big = [W.copy() for W in Ws]
+    big[2][3, 5] = 2100.0
+    rc, st, plain, chk, ref, p32 = both(po.pack_params(big, bs), tw)
+    assert not np.isfinite(plain[1]).any() and not np.isfinite(plain[0][:7]).any()          # beyond the fused format: NaN throughout
+    assert rc == 0 and st.two_kernel == 1 and st.attempts == 2 and st.adjoint_shift == 0
+    assert rel(chk[0][:7], ref[0]) < 1e-4 and rel(chk[1], ref[1]) < 2e-3          # (one weight of 2100: a saturated unit; the float64 oracle against fp32-class arithmetic)
+
+    out = [W.copy() for W in Ws]
+    out[-1] = out[-1] * 3000.0
+    rc, st, plain, chk, ref, p32 = both(po.pack_params(out, bs), np.ones(7) / 130)
+    assert np.isfinite(plain[0][:7]).all() and not np.isfinite(plain[1]).all()                # sums fine, gradient overflowed
+    assert rc == 0 and st.adjoint_shift >= 4 and st.two_kernel == 0 and st.attempts == 1 + st.adjoint_shift // 4
+    assert np.isfinite(chk[1]).all() and rel(chk[1], ref[1]) < 1e-3

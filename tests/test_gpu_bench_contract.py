@@ -62,6 +62,23 @@ def test_bench_line(cfg, extra):
         assert d["config"]["collocation_points_global"] == 120000          # exactly the requested number of collocation points
 
 
+def test_bench_line_of_the_drivers_exact_command_is_self_consistent():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` -- the command the driver records as BENCH_rNN.json.  Round 5's record contradicted itself
+    (four bracketed launches, their mean above ms_per_step, rest_of_step negative, roofline.frac 0.1185 beside whole_path 0.1242).  Now: >= 32
+    bracketed launches whatever --steps is, the MEDIAN launch is the roofline's, the line checks launch <= 1.01 x step + 0.04 itself."""
+    d = run_bench(["--gpus", "1", "--steps", "20", "--warmup", "5"])
+    r, ls = d["roofline"], d["roofline"]["launch_stat"]
+    assert d["steps"] == 20 and d["warmup"] == 5 and d["config"]["collocation_points_global"] == 2_000_000
+    assert r["launches_timed"] >= 32 and ls["launches_timed"] == r["launches_timed"] and ls["launch_events_inconsistent"] is False
+    assert ls["launch_ms_min"] <= ls["launch_ms_median"] <= ls["launch_ms_max"] and r["avg_launch_ms"] == ls["launch_ms_median"]
+    assert r["avg_launch_ms"] <= 1.01 * d["ms_per_step"] + 0.04, (r["avg_launch_ms"], d["ms_per_step"])
+    sd = r["step_decomposition_ms"]
+    assert sd["rest_of_step"] >= -0.04, sd          # (the events' own cost on a bracketed launch: the allowance of the contract above)
+    assert abs(r["frac"] - d["whole_path"]["frac_of_mfma_peak"]) <= 0.003, (r["frac"], d["whole_path"])
+    assert d["mcycles_per_step"] is not None and abs(d["mcycles_per_step"] - d["ms_per_step"] * d["shader_clock_ghz"]) < 1e-9
+    assert "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
 def test_bench_two_ranks_strong_scaling_gloo():
     """the multi-process path on one GPU: 2 ranks, gloo, fixed total work split over the ranks"""
     d = run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--ramp-steps", "1", "--scaling", "strong", "--global-points", "200000", "--no-cpu-baseline",

@@ -95,3 +95,80 @@ def test_p2p_one_shot_allreduce_two_ranks_on_one_gpu(tmp_path):
     assert np.array_equal(z["p2p0"], z["p2p1"])                                      # ranks stay bit-identical
     assert np.linalg.norm(z["p2p0"] - z["gloo0"]) <= 1e-6 * np.linalg.norm(z["gloo0"])
     np.testing.assert_allclose(z["loss_p2p"], z["loss_gloo"], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_p2p_timeout_makes_both_ranks_raise(tmp_path):
+    """Round-5 review: a rank that missed the bounded wait returned before the sum and the folded Adam on SOME blocks, and nobody read the status
+    word.  Now (csrc/pinn_p2p.hip): rank 1 sleeps 2 s past a 0.4 s bound -- rank 0's call fails AS A WHOLE (all of the buffer NaN, parameters
+    untouched, status word set, later calls fail at once), rank 1's next call fails at once through the abort word rank 0 wrote into its buffer,
+    and DeepHPM.train() raises PinnLibError on BOTH ranks at its block's host sync point."""
+    out = str(tmp_path / "p2p_timeout.npz")
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29538", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29538", os.path.join(ROOT, "tests", "_dp_worker_p2p_timeout.py"), out], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = np.load(out)
+    for rk in (0, 1):
+        assert bool(z[f"ok_first{rk}"]), rk                                          # call 1 (both ranks there): the sum, Adam applied
+        assert bool(z[f"raised{rk}"]) and bool(z[f"poisoned{rk}"]) and bool(z[f"untouched{rk}"]) and bool(z[f"sticky{rk}"]), (rk, {k: z[k] for k in z.files if k.endswith(str(rk))})
+        assert bool(z[f"model_raised{rk}"]) and "p2p" in str(z[f"msg{rk}"]), rk
+    assert 0.3 <= float(z["waited0"]) <= 1.9                                         # rank 0 gave up at the bound (0.4 s), not at the nap's end (2 s)
+    assert float(z["waited1"]) <= 0.35                                               # rank 1 (timed behind its nap) did not wait: aborted by rank 0
+
+
+@pytest.mark.gpu
+def test_p2p_connect_refuses_a_coarse_grained_buffer_across_devices():
+    """pinn_p2p_connect returns PINN_ERR_COLLECTIVE, before mapping anything, when a receive buffer is coarse-grained (the runtime refused
+    hipDeviceMallocFinegrained: here the debug hook forces it) and a peer lives on ANOTHER physical device (the PCI bus id travels in the
+    handle blob): such memory is coherent at kernel boundaries only -- a running kernel would never see the peer's writes."""
+    import ctypes as C
+    from pinn_elastodynamics_amd.capi import PinnLib
+    L = PinnLib().lib
+    HB = 128
+    L.pinn_p2p_create.argtypes = [C.c_int, C.c_int, C.c_int64, C.POINTER(C.c_void_p), C.c_void_p]
+    L.pinn_p2p_connect.argtypes = [C.c_void_p, C.c_void_p]
+    L.pinn_p2p_destroy.argtypes = [C.c_void_p]
+    L.pinn_p2p_debug_force_coarse.argtypes = [C.c_int]
+    for coarse, expect in ((1, -6), (0, None)):
+        L.pinn_p2p_debug_force_coarse(coarse)
+        try:
+            comm, handle = C.c_void_p(), (C.c_ubyte * HB)()
+            assert L.pinn_p2p_create(0, 2, 1024, C.byref(comm), C.cast(handle, C.c_void_p)) == 0
+            mine = bytes(handle)
+            assert mine[64] == (0 if coarse else 1)                                   # the memory kind travels with the handle
+            pci = mine[65:112].split(b"\0")[0]
+            assert len(pci) >= 7 and b":" in pci, pci                               # "0000:05:00.0"
+            other = bytearray(mine)
+            other[65:65 + 12] = b"ffff:ff:1f.7"                                      # the "peer" on another device ...
+            other[64] = 1                                                            # ... with a fine-grained buffer of its own
+            blob = (C.c_ubyte * (2 * HB)).from_buffer_copy(mine + bytes(other))
+            rc = L.pinn_p2p_connect(comm, C.cast(blob, C.c_void_p))
+            if expect is not None:
+                assert rc == expect, rc
+            else:
+                assert rc != -6, rc      # fine-grained on both sides: not refused by the rule (opening this made-up handle then fails in the runtime)
+            L.pinn_p2p_destroy(comm)
+        finally:
+            L.pinn_p2p_debug_force_coarse(0)
+
+
+@pytest.mark.gpu
+def test_p2p_across_two_devices(tmp_path):
+    """The same worker as test_p2p_one_shot_allreduce_two_ranks_on_one_gpu with ONE DEVICE PER RANK: peer writes over xGMI / PCIe into fine-grained
+    IPC-mapped memory, seen by a kernel that is already running.  Skipped on one-GPU boxes (every box the builder had): until this has run
+    somewhere, collective='p2p' across physical GPUs is unverified (include/pinn_hip.h says so)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    out = str(tmp_path / "p2p2.npz")
+    env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT="29539", HSA_ENABLE_IPC_MODE_LEGACY="0", PINN_TEST_NDEV="2")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29539", os.path.join(ROOT, "tests", "_dp_worker_p2p.py"), out], env=env, capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    z = np.load(out)
+    assert float(z["worst"]) == 0.0 and float(z["adam_err"]) <= 1e-7 and int(z["fine_grained"]) == 1
+    assert np.array_equal(z["p2p0"], z["p2p1"])
+    assert np.linalg.norm(z["p2p0"] - z["gloo0"]) <= 1e-6 * np.linalg.norm(z["gloo0"])

@@ -282,7 +282,16 @@ def test_c_abi_from_plain_cpp(dev, tmp_path):
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [l for l in r.stdout.splitlines() if l.startswith("step")]
     l0, l20 = float(lines[0].split()[3]), float(lines[1].split()[3])
-    assert np.isfinite(l0) and 0 < l20 < l0 and "abi 1 ok" in r.stdout
+    assert np.isfinite(l0) and 0 < l20 < l0 and "abi 2 ok" in r.stdout
+    # round 6: the demo's evaluations go through pinn_wave2d_loss_grad_checked (the finite-gradient ladder as a library call) and it
+    # provokes both rungs: an overflowing reverse pass (adjoint shift raised, gradient finite) and a weight beyond the fused format
+    # (two-kernel flag set, gradient finite)
+    lad = {l.split(":")[0]: l.split(":")[1].split() for l in r.stdout.splitlines() if l.startswith("ladder")}
+    assert lad["ladder after training"][1] == "0" and lad["ladder after training"][3] == "0", lad
+    ov = dict(zip(lad["ladder overflow"][::2], lad["ladder overflow"][1::2]))
+    assert int(ov["shift"]) >= 4 and ov["two_kernel"] == "0" and ov["finite"] == "1" and int(ov["attempts"]) == 1 + int(ov["shift"]) // 4, ov
+    rg = dict(zip(lad["ladder range"][::2], lad["ladder range"][1::2]))
+    assert rg["two_kernel"] == "1" and rg["finite"] == "1" and rg["attempts"] == "2" and float(rg["wmax"]) == 2100.0 and float(rg["limit"]) == 2047.0, rg
 
 
 @pytest.mark.parametrize("case,layers", [("infinite", [3] + 4 * [32] + [7]), ("semi_infinite", [3] + 3 * [48] + [7])])

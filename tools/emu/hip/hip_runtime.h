@@ -48,6 +48,7 @@ typedef void* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 enum { hipMemcpyDeviceToDevice = 3, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
@@ -260,3 +261,7 @@ inline void __builtin_amdgcn_sched_group_barrier(int, int, int) {}
 
 template <class T>
 inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T>
+inline T atomicOr(T* p, T v) { T o = *p; *p = o | v; return o; }
+template <class T>
+inline T atomicMax(T* p, T v) { T o = *p; *p = o > v ? o : v; return o; }
