@@ -176,6 +176,49 @@ def trained64():
     print("wave64 32k: loss_f_uv", ss[:4].sum() / N, "loss_f_s", ss[4:].sum() / N)
 
 
+def plate64():
+    """golden_plate64.npz / golden_plate64_32k.npz: the float64 oracle at the TRAINED plate 8x64 uv net of tools/make_trained_plate64.py (this
+    framework's own training run on the MI355X with the reference's trained distance / particular nets frozen; log in
+    profiles/r06_plate64_train_log.txt; moved off the optimiser's own optimum by a seeded 1e-4 relative perturbation -- NOT reference data: the
+    reference's plate net is 70 wide).  Same contents and the same points as golden_plate.npz / golden_plate_32k.npz; purpose: a cancellation-regime
+    test point for BASELINE configs[2]'s own kernel, the five-stream register-state layout.  Reads only tests/golden/ (no /root/reference)."""
+    rng = np.random.default_rng(2222)
+    nets = {}
+    for key, fn in (("uv", "weights_plate64_uv.npz"), ("dist", "weights_plate_dist.npz"), ("part", "weights_plate_part.npz")):
+        w = np.load(os.path.join(OUT, fn))
+        layers = [int(v) for v in w["layers"]]
+        L = len(layers) - 1
+        nets[key] = (po.pack_params([w[f"W{i}"] for i in range(L)], [w[f"b{i}"] for i in range(L)]), layers)
+    lb, ub, r = np.array([0.0, 0.0, 0.0]), np.array([0.5, 0.5, 10.0]), 0.1
+    N = 1024
+    X = lb + (ub - lb) * rng.random((4 * N, 3))
+    X = X[X[:, 0] ** 2 + X[:, 1] ** 2 > r * r][:N]
+    st = {k: pl.net_streams(nets[k][0], nets[k][1], X[:, 0], X[:, 1], X[:, 2]) for k in nets}
+    F = pl.composite(st["uv"], st["dist"], st["part"])
+    ss, g, f = pl.plate_loss_grad(nets["uv"][0], nets["uv"][1], X[:, 0], X[:, 1], X[:, 2], st["dist"], st["part"], term_weights=np.ones(5) / N)
+    th = np.linspace(0.0, np.pi / 2, 8)
+    tt = np.linspace(0.0, 10.0, 8)
+    H = np.stack([np.repeat(r * np.cos(th), 8), np.repeat(r * np.sin(th), 8), np.tile(tt, 8)], 1)
+    DH = pl.net_streams(nets["dist"][0], nets["dist"][1], H[:, 0], H[:, 1], H[:, 2])[0]
+    PH = pl.net_streams(nets["part"][0], nets["part"][1], H[:, 0], H[:, 1], H[:, 2])[0]
+    ssh, gh = pl.traction_loss_grad(nets["uv"][0], nets["uv"][1], H[:, 0], H[:, 1], H[:, 2], DH, PH, r, weight=1.0 / 64)
+    np.savez_compressed(os.path.join(OUT, "golden_plate64.npz"), X=X, H=H, N_streams=st["uv"], D_streams=st["dist"].astype(np.float32),
+                        P_streams=st["part"].astype(np.float32), F=F, f=f, sumsq=ss, grad=g.astype(np.float32), hole_sumsq=ssh,
+                        hole_grad=gh.astype(np.float32))
+    print("plate64: loss_f_uv", ss[:2].sum() / N, "loss_f_s", ss[2:].sum() / N, "loss_HOLE", ssh.sum() / 64)
+    X = gp.plate_points()
+    N = X.shape[0]
+    st = {k: pl.net_streams(nets[k][0], nets[k][1], X[:, 0], X[:, 1], X[:, 2]) for k in ("dist", "part")}
+    ss, g, f = pl.plate_loss_grad(nets["uv"][0], nets["uv"][1], X[:, 0], X[:, 1], X[:, 2], st["dist"], st["part"], term_weights=np.ones(5) / N)
+    H = gp.hole_points()
+    DH = pl.net_streams(nets["dist"][0], nets["dist"][1], H[:, 0], H[:, 1], H[:, 2])[0]
+    PH = pl.net_streams(nets["part"][0], nets["part"][1], H[:, 0], H[:, 1], H[:, 2])[0]
+    ssh, gh = pl.traction_loss_grad(nets["uv"][0], nets["uv"][1], H[:, 0], H[:, 1], H[:, 2], DH, PH, 0.1, weight=1.0 / H.shape[0])
+    np.savez_compressed(os.path.join(OUT, "golden_plate64_32k.npz"), n=np.array(N), sumsq=ss, grad=g, hole_n=np.array(H.shape[0]), hole_sumsq=ssh,
+                        hole_grad=gh, f_colnorm=np.linalg.norm(f, axis=0))
+    print("plate64 32k: loss_f_uv", ss[:2].sum() / N, "loss_f_s", ss[2:].sum() / N, "loss_HOLE", ssh.sum() / H.shape[0])
+
+
 def large():
     """golden_<case>_32k.npz: float64 oracle sums and gradient on oracle/golden_points.py's 32 768 seeded points at the reference's trained
     weights (the 1024-point sets above stay what they are: they also carry fields, Jacobians and the residual vectors)."""
@@ -221,3 +264,5 @@ if __name__ == "__main__":
         large()
     if len(sys.argv) < 2 or sys.argv[1] == "trained64":
         trained64()
+    if len(sys.argv) > 1 and sys.argv[1] == "plate64":
+        plate64()

@@ -37,8 +37,12 @@
 // weight-gradient waves read Z_L).
 #pragma once
 #include "pinn_device.hpp"
+#include <type_traits>
 #ifndef PINN_LO8_ENABLED
 #define PINN_LO8_ENABLED 1
+#endif
+#ifndef PINN_QUAD_ENABLED
+#define PINN_QUAD_ENABLED 1      // 0: the padded-width-128 layouts keep the round-3 chain (two waves per tile, half of the feature blocks each): for A / B timing
 #endif
 
 namespace pinn {
@@ -601,7 +605,11 @@ struct Fused {
             for (int i = 0; i < IBW; ++i)
 #pragma unroll
                 for (int b = 0; b < NNEXT; ++b)
+#ifdef PINN_X_NOSUMS
+                    next[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
                     next[i][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(job.accr, job.lane16, acc_record(L, i, O0 + NBK + b), 0));
+#endif
         }
         const uint32_t one2 = pack2<Op>(1.0f, 1.0f);
         const u32x4 ones = {one2, one2, one2, one2};
@@ -652,11 +660,13 @@ struct Fused {
         // the per-block loop above produced exactly that sequence.  So: all sums are final first, then all stores, then wait states, and the
         // scheduler may not move vector work in between.
         store_fence(acc);
+#ifndef PINN_X_NOSUMS
 #pragma unroll
         for (int i = 0; i < IBW; ++i)
 #pragma unroll
             for (int b = 0; b < NBK; ++b)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][b]), job.accr, job.lane16, acc_record(L, i, O0 + b), 0);
+#endif
         stores_issued();
     }
     // mid layer L of the ten-block layout: three passes over the out-blocks (pair, pair, single); lds_ = the first pass's sums (+ the bias
@@ -926,6 +936,9 @@ struct Fused {
     static __device__ __forceinline__ void dma_state(const DmaSrc& src, unsigned lane16, char* tile_lds, int l /*1..NL-1*/, int quad, int ii0 = 0,
                                                      int ii1 = N_DMA_ALL) {
         if constexpr (SLDS || WSLDS) return;
+#ifdef PINN_X_NODMA
+        return;
+#endif
         char* dst = tile_lds + TENSOR_Z_B + slot_of(l) * IMG_B;
         // LDSOP: two tiles, four waves: wave quad brings every second record of tile quad & 1 (records quad >> 1, +2, ...)
         const int i0 = LDSOP ? (quad >> 1) : 0;
@@ -946,6 +959,9 @@ struct Fused {
     // LDSOP forward: S_k (k = 1..NL-1) sits in the tile's Z area (k odd) or S slot 0 (k even), complete behind the layer's barrier; copy
     // this wave's records (the ones dma_state brings back) to the scratch image.  The LDS reads are drained by the next lds_barrier.
     static __device__ __forceinline__ void park_image(__amdgpu_buffer_rsrc_t scr, unsigned lane16, const char* tile_lds, int k, int quad) {
+#ifdef PINN_X_NODMA
+        return;
+#endif
         const char* src = tile_lds + ((k & 1) ? 0 : TENSOR_Z_B) + lane16;
         const int i0 = quad >> 1;
         u32x4 v[N_DMA_ALL];
@@ -972,6 +988,11 @@ struct Fused {
         stores_issued();
     }
     static __device__ __forceinline__ void load_sums(__amdgpu_buffer_rsrc_t accr, unsigned lane16, int L, Sums& p) {
+#ifdef PINN_X_NOSUMS
+        for (int i = 0; i < IBW; ++i) for (int o = 0; o < (STREAM_SUMS ? 2 : OBW); ++o) p.blk[i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
+        p.bias = f32x4{0.f, 0.f, 0.f, 0.f};
+        return;
+#endif
 #pragma unroll
         for (int i = 0; i < IBW; ++i)
 #pragma unroll
@@ -1075,7 +1096,25 @@ struct Fused {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             fused_stamp(a, tracer, 65 + 3 * (NL - L));
+#ifdef PINN_X_TOUCH
+            // experiment: bring the scratch image of S_{L-1} -- which this wave will LDS-DMA in the NEXT layer's hand-off window -- into L2 now
+            // (one dword per 128-byte line of this wave's records: 64 lanes x 3 loads cover its 20 records of 1 KB)
+            uint32_t touch[3] = {0u, 0u, 0u};
+            if constexpr (ONE_SLOT && L >= 2 && !kept_in_lds(L - 1)) {
+                const long gt = (long)fused_bid(a) * TILES + (quad & 1);
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gt * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES, 0x00020000);
+                const unsigned ln = lane16 >> 4;
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    const unsigned rec = (unsigned)(quad >> 1) + 2u * (8u * g + (ln >> 3));
+                    touch[g] = __builtin_amdgcn_raw_buffer_load_b32(rs, rec * 1024u + (ln & 7u) * 128u, (L - 2) * IMG_B, 0);
+                }
+            }
+#endif
             wgrad<L>(w, A, quad, ld, pend, DmaJob{&scr, lane16, tile_lds, quad, accr});
+#ifdef PINN_X_TOUCH
+            asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]));
+#endif
             if constexpr (EARLY_SUMS) {
                 if constexpr (in_memory(L)) store_sums(accr, lane16, L, pend);
                 if constexpr (in_memory(L - 1)) load_sums(accr, lane16, L - 1, ld);
@@ -1254,7 +1293,12 @@ struct Fused {
     // ---------------------------------------------------------------------------------------------
     // chain role
     // ---------------------------------------------------------------------------------------------
-    struct Ctx {                                   // wave-invariant addressing state of a chain wave
+    static constexpr bool QUAD = LDSOP && !WSLDS && WB == 8 && PINN_QUAD_ENABLED != 0;      // (see "QUAD chain" below)
+    // (a member the other layouts never read still moved their register allocation -- and put a vector write directly behind a 16-byte
+    // park store of the width-32 kernel, tests/test_isa_hazards.py: it lives in a base only the QUAD layouts have)
+    struct CtxQuad { char* lds0; };                // the workgroup's LDS (uniform): tile t's tensors at + t * WAVE_B (a QUAD chain wave works on both tiles)
+    struct CtxPlain {};
+    struct Ctx : std::conditional_t<QUAD, CtxQuad, CtxPlain> {       // wave-invariant addressing state of a chain wave
         __amdgpu_buffer_rsrc_t frags, scr, bias, w0p;  // bias / w0p: only where the constants are not in LDS
         unsigned lane16;                           // lane * 16: the only VGPR offset of the fragment traffic
         unsigned imgoff;                           // this lane's (rotated) 16-byte record inside a fragment record block of an S image
@@ -1277,6 +1321,7 @@ struct Fused {
             }
             lane16 = (unsigned)lane * 16u;
             tenZ = lds + slot * WAVE_B;
+            if constexpr (QUAD) this->lds0 = lds;
             cbias = lds + CONST_OFF + q_ * 16;
             cw0 = lds + CONST_OFF + CONST_BIAS_F * 4 + q_ * 64;
             imgoff = img_record(c_, q_);
@@ -1930,7 +1975,14 @@ struct Fused {
         for (int t = 0; t < NIT; ++t) {
             if (t % HB == 0) op_load(in, t / HB, Bk);
             fwd_kstep<0, 1>(Ar[(T0 + t) % RING], Bk, acc[t % HB]);
+#ifdef PINN_X_HALFW
+            if (t % 2 == 0)
+#endif
+#ifndef PINN_X_NOW
             fwd_request<PAR>(x, l, h, t + RING, Ar);
+#else
+            asm volatile("" : "+v"(Ar[(T0 + t) % RING][0][0]), "+v"(Ar[(T0 + t) % RING][0][1]));
+#endif
         }
     }
     // reverse: the same kind of ring over the items of layers NL-1 .. 1 (T0 = global index of this layer's item 0)
@@ -1949,7 +2001,14 @@ struct Fused {
         for (int t = 0; t < NIT; ++t) {
             if (t % HB == 0) op_load(in, t / HB, Bk);
             bwd_kstep<0, 1>(Ar[(T0 + t) % RINGB], Bk, acc[t % HB]);
+#ifdef PINN_X_HALFW
+            if (t % 2 == 0)
+#endif
+#ifndef PINN_X_NOW
             ring_request<L>(x, h, t + RINGB, Ar);
+#else
+            asm volatile("" : "+v"(Ar[(T0 + t) % RINGB][0][0]), "+v"(Ar[(T0 + t) % RINGB][0][1]), "+v"(Ar[(T0 + t) % RINGB][0][2]));
+#endif
         }
     }
     template <int J>
@@ -2145,6 +2204,278 @@ struct Fused {
             fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
             wide_down<L - 1>(a, x, xin, h, Zn, Ar);
         }
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    // QUAD chain (round 6; padded width 128: the reference's 8 x 100 net, SEMI:679, and the 3-D net of BASELINE configs[4])
+    // ---------------------------------------------------------------------------------------------
+    // What bounds the chain of these layouts is its weight-fragment traffic: with the points as the MFMA's N dimension a 1 KB fragment feeds
+    // 15 MFMAs (five streams x three parts) of ONE 16-point tile, and the two waves that own the same half of the feature blocks of the two
+    // tiles load the same 96 KB of a layer's fragments twice -- 4 MB through L2 per 32-point workgroup step, against a ring of four slots in
+    // flight per wave.  Ablations on the 3-D kernel (profiles/r06_lds_operand_ablations.txt): no fragment loads at all -20 % of the launch,
+    // every second one skipped -9 %.  QUAD: a chain wave owns a QUARTER of the feature blocks (blocks 2 qt, 2 qt + 1 = fragment record qt of
+    // an image) of BOTH tiles, so every fragment is loaded once per workgroup and feeds 30 MFMAs; the same ring then covers twice the matrix
+    // work per byte in flight.  Accumulators, operand fragments and results per wave stay what they were (2 tiles x 2 blocks instead of 1 x 4);
+    // LDS operand reads double (every wave reads both tiles' images: 80 of 1 KB per layer, 5 % of the LDS's time).  The head keeps its
+    // assignment (wave w: tile w & 1, both waves of a tile compute it), so do the barriers: the weight-gradient role does not change.
+    static_assert(!QUAD || (ONE_SLOT && TILES == 2), "QUAD: the one-slot layouts of padded width 128");
+    static constexpr int QB = 2;                        // feature blocks per chain wave
+    static constexpr int NITQ = KS * QB;                // items (k-step, block) of a layer; an item's fragment serves both tiles
+    static constexpr int RINGQ = 4;                     // fragment slots in flight: two k-steps' pairs
+    static_assert(!QUAD || NITQ % RINGQ == 0, "the ring's phase is the same in every layer");
+    static __device__ __forceinline__ int q_frag(int frag_l0, int qt, int t) { return frag_l0 + (2 * qt + (t & 1)) * KS + (t >> 1); }
+    static __device__ __forceinline__ void q_fwd_request(const Ctx& x, int l, int qt, int t /*item of layer l, may run past NITQ*/, u32x4 (&Ar)[RINGQ][1][FP]) {
+        if (t < NITQ) load_afrags<1, FP>(x, q_frag(FI::fwd_mid(l, 0, 0), qt, t), Ar[t % RINGQ]);
+        else if (l + 1 < NL) load_afrags<1, FP>(x, q_frag(FI::fwd_mid(l + 1, 0, 0), qt, t - NITQ), Ar[t % RINGQ]);
+        else if (t - NITQ < KS) load_afrags<1, FP>(x, FI::fwd_last(NL, t - NITQ), Ar[t % RINGQ]);      // the output layer's k-steps
+    }
+    template <int L>
+    static __device__ __forceinline__ void q_bwd_request(const Ctx& x, int qt, int t, u32x4 (&Ar)[RINGQ][1][RP]) {
+        if (t < NITQ) load_afrags<1, RP>(x, q_frag(FI::bwd_mid(NL, L, 0, 0), qt, t), Ar[t % RINGQ]);
+        else if (L >= 2) load_afrags<1, RP>(x, q_frag(FI::bwd_mid(NL, L >= 2 ? L - 1 : 1, 0, 0), qt, t - NITQ), Ar[t % RINGQ]);
+    }
+    // this lane's record of tile t's Z area / S slot of layer L
+    static __device__ __forceinline__ char* q_imgZ(const Ctx& x, int t) { return x.lds0 + t * WAVE_B + x.imgoff; }
+    static __device__ __forceinline__ char* q_imgS(const Ctx& x, int t, int L) { return x.lds0 + t * WAVE_B + TENSOR_Z_B + slot_of(L) * IMG_B + x.imgoff; }
+    // fragment record qt (this wave's two blocks) of every stream and part -> the image
+    static __device__ __forceinline__ void q_store(char* img, int qt, const u32x4 (&F)[NS][1][1][NP]) {
+        char* rec = img + qt * NP * 1024;
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) *reinterpret_cast<u32x4*>(rec + (s * KS * NP + p) * 1024) = F[s][0][0][p];
+    }
+    static __device__ __forceinline__ void q_gemm_fwd(const Ctx& x, int l, int qt, const char* in0, const char* in1, u32x4 (&Ar)[RINGQ][1][FP], f32x4 (&acc)[2][QB][NS]) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 Bk[NS][1][1][NP];
+                op_load(t ? in1 : in0, kk, Bk);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) fwd_kstep<0, 1>(Ar[(QB * kk + j) % RINGQ], Bk, acc[t][j]);
+            }
+#pragma unroll
+            for (int j = 0; j < QB; ++j) q_fwd_request(x, l, qt, QB * kk + j + RINGQ, Ar);
+        }
+    }
+    template <int L>
+    static __device__ __forceinline__ void q_gemm_bwd(const Ctx& x, int qt, const char* in0, const char* in1, u32x4 (&Ar)[RINGQ][1][RP], f32x4 (&acc)[2][QB][NS]) {
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 Bk[NS][1][1][NP];
+                op_load(t ? in1 : in0, kk, Bk);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) bwd_kstep<0, 1>(Ar[(QB * kk + j) % RINGQ], Bk, acc[t][j]);
+            }
+#pragma unroll
+            for (int j = 0; j < QB; ++j) q_bwd_request<L>(x, qt, QB * kk + j + RINGQ, Ar);
+        }
+    }
+    // first layer (VALU) of this wave's blocks for one tile: wide_first with the quarter's block numbers
+    template <int J>
+    static __device__ __forceinline__ void q_first(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int qt, u32x4 (&Bn)[NS][1][1][NP]) {
+        const int mb = 2 * qt + J;
+        float vals[NS][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float w[5];
+            if constexpr (DIN == 4) {
+                const f32x4 wa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x.w0p, (unsigned)x.q * 128u, (16 * mb + r) * 32, 0));
+                const f32x4 wb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x.w0p, (unsigned)x.q * 128u, (16 * mb + r) * 32 + 16, 0));
+                w[0] = wa[0]; w[1] = wa[1]; w[2] = wa[2]; w[3] = wa[3]; w[4] = wb[0];
+            } else {
+                f32x4 wa;
+                if constexpr (CONST_LDS) wa = *reinterpret_cast<const f32x4*>(x.cw0 + (16 * mb + r) * 16);
+                else wa = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x.w0p, (unsigned)x.q * 64u, (16 * mb + r) * 16, 0));
+                w[0] = wa[0]; w[1] = wa[1]; w[2] = wa[2]; w[3] = 0.0f; w[4] = wa[3];
+            }
+            float z0 = w[4];
+#pragma unroll
+            for (int k = 0; k < DIN; ++k) z0 += w[k] * xin[k];
+            float hh, sd;
+            tanh_act(z0, hh, sd);
+            vals[0][r] = hh;
+#pragma unroll
+            for (int s = 1; s <= NT; ++s) vals[s][r] = sd * (a.sx[s - 1] * w[s - 1]);
+            if constexpr (SECOND) vals[4][r] = -2.0f * hh * vals[3][r] * (a.sx[2] * w[2]);
+        }
+        emit_state<J, 1>(Bn, vals);
+        if constexpr (J + 1 < QB) q_first<J + 1>(a, x, xin, qt, Bn);
+    }
+    // one hidden weight layer l: S_l (images in0 / in1 of the two tiles) -> this wave's blocks of S_{l+1} of both tiles (images out0 / out1)
+    static __device__ __forceinline__ void q_fwd_layer(const Ctx& x, int l, int qt, const char* in0, const char* in1, char* out0, char* out1, u32x4 (&Af)[RINGQ][1][FP]) {
+        f32x4 acc[2][QB][NS];
+        f32x4 bias[QB];
+#pragma unroll
+        for (int j = 0; j < QB; ++j) {
+            bias[j] = load_bias(x, l, 2 * qt + j);
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                if constexpr (CONST_LDS) acc_init(bias[j], acc[t][j]);
+                else acc_zero(acc[t][j]);       // (constants from memory: requested here, added behind the layer's MFMAs -- see wide_fwd_layer)
+            }
+        }
+        q_gemm_fwd(x, l, qt, in0, in1, Af, acc);
+        if constexpr (!CONST_LDS) {
+#pragma unroll
+            for (int j = 0; j < QB; ++j)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[t][j][0] += bias[j];
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 out[NS][1][1][NP];
+            fwd_valu<0, 1>(acc[t][0], out);
+            fwd_valu<1, 1>(acc[t][1], out);
+            q_store(t ? out1 : out0, qt, out);
+        }
+    }
+    // forward of both tiles (this wave's quarter of the blocks); returns the output layer's products of the wave's HEAD tile (x) for fwd_head
+    static __device__ __forceinline__ void quad_forward(const FusedArgs& a, const Ctx& x, const float (&xt)[2][4], int qt, f32x4 (&acca)[NS]) {
+        char* opa0 = q_imgZ(x, 0);                            // Z areas
+        char* opa1 = q_imgZ(x, 1);
+        char* opb0 = opa0 + TENSOR_Z_B;                       // S slot 0 = slot_of(NL): S_NL ends where the reverse expects it
+        char* opb1 = opa1 + TENSOR_Z_B;
+        u32x4 Af[RINGQ][1][FP];
+#pragma unroll
+        for (int t = 0; t < RINGQ; ++t) q_fwd_request(x, 1, qt, t, Af);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 S1[NS][1][1][NP];
+            q_first<0>(a, x, xt[t], qt, S1);
+            q_store(t ? opa1 : opa0, qt, S1);
+        }
+        lds_barrier();
+        fused_stamp(a, x.tracer, 32);
+        for (int l = 1; l < NL; ++l) {                        // odd layers: Z area -> slot 0, even layers back
+            if (l & 1) q_fwd_layer(x, l, qt, opa0, opa1, opb0, opb1, Af);
+            else q_fwd_layer(x, l, qt, opb0, opb1, opa0, opa1, Af);
+            lds_barrier();
+            fused_stamp(a, x.tracer, 32 + l);
+        }
+        // output layer (16 padded outputs) of the head tile: one block, operand S_NL from slot 0; fragments requested during the last hidden layer
+        acc_init(load_bias(x, NL, 0), acca);
+        const char* opb = x.tenZ + TENSOR_Z_B + x.imgoff;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            u32x4 Bk[NS][1][1][NP];
+            op_load(opb, kk, Bk);
+            fwd_kstep<0, 1>(Af[kk % RINGQ], Bk, acca);
+        }
+    }
+    // reverse vector part of block J of this wave's quarter for one tile (state in full precision from the operand-layout image)
+    template <int J>
+    static __device__ __forceinline__ void q_bwd_epilogue(f32x4 (&acc)[QB][NS], const char* simg, int qt, u32x4 (&Zn)[NS][1][1][NP], int c, int q) {
+        const int mb = 2 * qt + J;
+        float st[NS][4];
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const char* rec = simg + ((s * KS + (mb >> 1)) * NP) * 1024 + 8 * (mb & 1);
+            const u32x2 hi = *reinterpret_cast<const u32x2*>(rec);
+            const u32x2 lo = *reinterpret_cast<const u32x2*>(rec + 1024);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if constexpr (MixF16<Op>::value)
+                    st[s][r] = (r & 1) ? MixF16<Op>::template sum2<1>(hi[r >> 1], lo[r >> 1]) : MixF16<Op>::template sum2<0>(hi[r >> 1], lo[r >> 1]);
+                else
+                    st[s][r] = cvt16<Op>((uint16_t)((r & 1) ? (hi[r >> 1] >> 16) : (hi[r >> 1] & 0xffffu))) +
+                               cvt16<Op>((uint16_t)((r & 1) ? (lo[r >> 1] >> 16) : (lo[r >> 1] & 0xffffu)));
+            }
+        }
+        float vals[NS][1][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float hh = st[0][r];
+            const float sds = (1.0f - hh * hh) * INV_WS;
+            float dot = 0.0f;
+#pragma unroll
+            for (int s = 1; s <= NT; ++s) {
+                dot += acc[J][s][r] * st[s][r];
+                vals[s][0][r] = sds * acc[J][s][r];
+            }
+            float zb = sds * acc[J][0][r] - (2.0f * INV_WS) * hh * dot;
+            if constexpr (SECOND) {
+                const float ht = st[3][r], htt = st[4][r];
+                const float httb = acc[J][4][r] * INV_WS;
+                vals[4][0][r] = sds * acc[J][4][r];
+                vals[3][0][r] -= 4.0f * hh * ht * httb;
+                zb += httb * (-2.0f * hh * htt - 2.0f * ht * ht);
+            }
+            vals[0][0][r] = zb;
+        }
+        CH::template emit<1, J>(Zn, vals, nullptr, WIDTH, c, q);
+        if constexpr (J + 1 < QB) q_bwd_epilogue<J + 1>(acc, simg, qt, Zn, c, q);
+    }
+    // entry: Zc[t] = this wave's blocks of Z_L of tile t in registers, first barrier of layer L not yet passed
+    template <int L>
+    static __device__ __forceinline__ void quad_down(const FusedArgs& a, const Ctx& x, const float (&xt)[2][4], int qt, int half, const u32x4 (&Zc)[2][NS][1][1][NP],
+                                                     u32x4 (&Ar)[RINGQ][1][RP]) {
+        lds_barrier();                                          // A(L): the weight-gradient waves are done with Z_{L+1}, S_{L+1}
+        fused_stamp(a, x.tracer, 3 + 3 * (NL - L));
+        q_store(q_imgZ(x, 0), qt, Zc[0]);
+        q_store(q_imgZ(x, 1), qt, Zc[1]);
+        if constexpr (L == 0) {
+            if (half == 0) put_input_state(a, x, xt[(x.tenZ - x.lds0) / WAVE_B]);      // the head tile's inputs (x addresses the head tile)
+        }
+        if constexpr (RECOMP_W && L == 1) {                     // S_1 again from the inputs, this wave's blocks of both tiles
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 S1[NS][1][1][NP];
+                q_first<0>(a, x, xt[t], qt, S1);
+                q_store(q_imgS(x, t, 1), qt, S1);
+            }
+        }
+        lds_barrier();                                          // B(L)
+        fused_stamp(a, x.tracer, 4 + 3 * (NL - L));
+        if constexpr (L >= 1) {
+            f32x4 acc[2][QB][NS];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < QB; ++j) acc_zero(acc[t][j]);
+            q_gemm_bwd<L>(x, qt, q_imgZ(x, 0), q_imgZ(x, 1), Ar, acc);       // operand: the Z_L images all four waves have just written
+            u32x4 Zn[2][NS][1][1][NP];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) q_bwd_epilogue<0>(acc[t], q_imgS(x, t, L), qt, Zn[t], x.c, x.q);
+            fused_stamp(a, x.tracer, 5 + 3 * (NL - L));
+            quad_down<L - 1>(a, x, xt, qt, half, Zn, Ar);
+        }
+    }
+    // reverse of both tiles; on entry the first barrier of the top layer has NOT been passed, S_NL (hi + lo) sits in S slot 0, ZL = the HEAD tile's Z_NL
+    static __device__ __forceinline__ void quad_reverse(const FusedArgs& a, const Ctx& x, const float (&xt)[2][4], int qt, int half, const u32x4 (&ZL)[NS][1][1][NP]) {
+        u32x4 Ar[RINGQ][1][RP];
+        u32x4 At[QB][1][RP];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < QB; ++j) load_afrags<1, RP>(x, FI::bwd_last(NL, 2 * qt + j), At[j]);
+#pragma unroll
+        for (int t = 0; t < RINGQ; ++t) q_bwd_request<NL - 1>(x, qt, t, Ar);
+        u32x4 Zn[2][NS][1][1][NP];
+        {
+            fused_stamp(a, x.tracer, 2);
+            lds_barrier();                                      // A(NL)
+            fused_stamp(a, x.tracer, 3);
+            if (half == 0) put_zimage<1>(x.imgZ(), ZL);         // (both waves of a tile hold the same Z_NL)
+            lds_barrier();                                      // B(NL)
+            fused_stamp(a, x.tracer, 4);
+            f32x4 acc[2][QB][NS];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u32x4 Bk[NS][1][1][NP];
+                op_load(q_imgZ(x, t), 0, Bk);                   // Z_NL of tile t: the k-step-0 records of its Z area
+#pragma unroll
+                for (int j = 0; j < QB; ++j) {
+                    acc_zero(acc[t][j]);
+                    bwd_kstep<0, 1>(At[j], Bk, acc[t][j]);
+                }
+                q_bwd_epilogue<0>(acc[t], q_imgS(x, t, NL), qt, Zn[t], x.c, x.q);
+            }
+            fused_stamp(a, x.tracer, 5);
+        }
+        quad_down<NL - 1>(a, x, xt, qt, half, Zn, Ar);
     }
 
     // ---------------------------------------------------------------------------------------------
@@ -2519,7 +2850,21 @@ struct Fused {
                 // gradient still reads (the narrow layouts' forward does not touch them).  Without it: a race that the x86 emulator cannot
                 // show and that happened not to bite with two tiles.
                 __syncthreads();
-                wide_forward(a, x, xin, half, acca);
+                float xt[2][4];                    // QUAD: the inputs of both tiles (this wave computes its quarter of the blocks for both)
+                if constexpr (QUAD) {
+                    float xo[4];
+                    bool vo;
+                    long po;
+                    load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + (wave ^ 1), c, xo, vo, po);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        xt[0][k] = wave ? xo[k] : xin[k];
+                        xt[1][k] = wave ? xin[k] : xo[k];
+                    }
+                    quad_forward(a, x, xt, wave4, acca);
+                } else {
+                    wide_forward(a, x, xin, half, acca);
+                }
                 float ls[LT];
 #pragma unroll
                 for (int i = 0; i < LT; ++i) ls[i] = 0.0f;
@@ -2532,7 +2877,8 @@ struct Fused {
 #pragma unroll
                         for (int i = 0; i < LT; ++i) lsum[k][i] += (k == set && half == 0) ? ls[i] : 0.0f;
                 }
-                wide_reverse(a, x, xin, half, ZL);
+                if constexpr (QUAD) quad_reverse(a, x, xt, wave4, half, ZL);
+                else wide_reverse(a, x, xin, half, ZL);
             } else {
                 u32x4 B[NS][1][KS][NP], ZL[NS][1][1][NP];
                 float ls[LT];

@@ -150,7 +150,7 @@ struct Host {
     template <int NSC>
     static constexpr bool step_has_ns() { return step_has() && (NSC == 4 || SPLIT == 3); }      // (the plate's five streams: split-precision families)
     template <int NS>
-    static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5 || NS == 1)) || (WIDTH <= 128 && (NS == 4 || NS == 1)) || (WIDTH == 160 && NS == 4))); }
+    static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5 || NS == 1)) || (WIDTH <= 128 && (NS == 4 || NS == 1)) || (WIDTH == 160 && (NS == 4 || NS == 1)))); }
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
     static constexpr long MIN_TILES = 64;
     static constexpr int MAX_REPACK_BLOCKS = 2048;
@@ -616,10 +616,11 @@ struct Host {
         if constexpr (fused_has<NS>()) {
             Plan p;
             plan_fixed<4>(net, 1, p);
-            constexpr int TILES = Fused<Op, SPLIT, WIDTH, 4, NS>::TILES;
+            constexpr int TILES = Fused<Op, SPLIT, WIDTH, WIDTH == 160 ? 6 : 4, NS>::TILES;
             // (sized for the default layout, which parks more than the fp16-state one)
-            const size_t per_wg = (size_t)TILES * (WIDTH == 160 ? Fused<Op, SPLIT, WIDTH, 6, NS>::SCRATCH_BYTES
-                                                                : (net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NS>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NS>::SCRATCH_BYTES));
+            size_t per_wg;
+            if constexpr (WIDTH == 160) per_wg = (size_t)TILES * Fused<Op, SPLIT, WIDTH, 6, NS>::SCRATCH_BYTES;      // (one depth: other depths of a one-stream layout would not fit the LDS)
+            else per_wg = (size_t)TILES * (net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NS>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NS>::SCRATCH_BYTES);
             if (ws_bytes < p.fixed_end + per_wg) return 0;
             return (long)((ws_bytes - p.fixed_end) / per_wg);
         } else {
@@ -665,7 +666,7 @@ struct Host {
             Plan p;
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
-            constexpr int TILES = Fused<Op, SPLIT, WIDTH, 4, NS>::TILES;
+            constexpr int TILES = Fused<Op, SPLIT, WIDTH, WIDTH == 160 ? 6 : 4, NS>::TILES;
             long grid = fused_images<NS>(c.net, c.ws_bytes);
             if (grid == 0) return 0;
             if (grid > FUSED_GRID) grid = FUSED_GRID;
@@ -704,6 +705,7 @@ struct Host {
             if (c.ws_bytes < p.fixed_end + per_wg) return 0;
             long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
             if (grid > FUSED_GRID) grid = FUSED_GRID;
+            if (g_fused_grid_cap > 0 && grid > g_fused_grid_cap) grid = g_fused_grid_cap;
             const long nsteps = (c.n + 16 * F::TILES - 1) / (16 * F::TILES);
             if (nsteps == 0) return 0;
             if (grid > nsteps) grid = nsteps;

@@ -332,10 +332,13 @@ def test_ragged_batches_wide_layout_emulated(emu, n):
 
 
 @pytest.mark.parametrize("layers,n,fused", [([3] + 4 * [32] + [7], 150, 1), ([3] + 8 * [64] + [7], 90, 1), ([3] + 8 * [64] + [7], 90, 0),
-                                            ([3] + 8 * [80] + [7], 100, 1), ([3] + 8 * [100] + [7], 75, 1)])
+                                            ([3] + 8 * [80] + [7], 100, 1), ([3] + 8 * [100] + [7], 75, 1), ([3] + 6 * [140] + [7], 75, 1)])
 def test_data_terms_fused_and_two_kernel_emulated(emu, layers, n, fused):
     """value-only side sets (loss_IC / loss_SRC / ...) through the fused kernel's 1-stream instantiation and the two-kernel path; the
-    reference's 8 x 80 / 8 x 100 nets through the one-stream LDS-operand layout with all layer states in LDS (round 3)"""
+    reference's 8 x 80 / 8 x 100 nets through the one-stream LDS-operand layout with all layer states in LDS (round 3); round 6: the
+    confined-domain net's 6 x 140 (CONF:891; its IC / FIX / SRC sets are ~90 k of ~240 k points per step, CONF:901-947) likewise --
+    padded width 160, seven 10 KB state slots per tile: the 160 KB exactly, constants from memory"""
+    emu.path_counts(reset=True)
     emu.set_fused(fused)
     rng = np.random.default_rng(8)
     Ws, bs = po.xavier_init(layers, rng)
@@ -354,6 +357,8 @@ def test_data_terms_fused_and_two_kernel_emulated(emu, layers, n, fused):
         emu.data_loss_grad(p32.ctypes.data, layers, x.ctypes.data, y.ctypes.data, t.ctypes.data, n, LB, UB, False, 0 if tg is None else tg.ctypes.data, ow,
                            loss.ctypes.data, grad.ctypes.data, False, "f16x3", ws.ctypes.data, wsb)
         assert rel(loss[:7], ss) < 2e-6 and rel(grad, g) < ((2e-4 if layers[1] <= 64 else 3e-6) if fused else 2e-6)
+    pc = emu.path_counts(reset=True)
+    assert pc["two-kernel" if not fused else ("fused-registers" if layers[1] <= 64 else "fused-lds")] == 2 and sum(pc.values()) == 2, pc
     emu.set_fused(1)
 
 

@@ -143,10 +143,18 @@ def test_plate_reference_weights_golden(dev, golden_dir):
     assert rel(gh.cpu().numpy(), g["hole_grad"]) < 5e-2
 
 
-def _plate_nets(golden_dir, dev, n):
+# The two TRAINED uv nets of the plate family: "plate" = the reference's own 8 x 70 net (PLATE:885-887; padded width 96: the five-stream
+# LDS-operand kernel), "plate64" = the BASELINE configs[2] net, 8 x 64, trained by this framework with the reference's distance / particular nets
+# frozen (tools/make_trained_plate64.py; round 6) -- the five-stream REGISTER-STATE kernel with the one-part weight gradient (ZDB), one-byte
+# parked low parts (LO8) and S1_HI_BY_WG, which until round 6 had only ever met fresh Xavier weights.
+TRAINED = {"plate": ("weights_plate_uv.npz", "golden_plate.npz", "golden_plate_32k.npz", "fused-lds"),
+           "plate64": ("weights_plate64_uv.npz", "golden_plate64.npz", "golden_plate64_32k.npz", "fused-registers")}
+
+
+def _plate_nets(golden_dir, dev, n, net="plate"):
     flat, lay, eng = {}, {}, {}
     for k in ("uv", "dist", "part"):
-        w = np.load(f"{golden_dir}/weights_plate_{k}.npz")
+        w = np.load(f"{golden_dir}/{TRAINED[net][0]}" if k == "uv" else f"{golden_dir}/weights_plate_{k}.npz")
         lay[k] = [int(v) for v in w["layers"]]
         L = len(lay[k]) - 1
         flat[k] = po.pack_params([w[f"W{i}"] for i in range(L)], [w[f"b{i}"] for i in range(L)])
@@ -163,15 +171,17 @@ def _layer_blocks_within(grad_dev, grad32, grad64, layers, factor, floor, tag):
             assert np.linalg.norm(d_ - r_) <= factor * np.linalg.norm(s_ - r_) + floor * np.linalg.norm(r_), (tag, l, np.linalg.norm(d_ - r_), np.linalg.norm(s_ - r_))
 
 
+@pytest.mark.parametrize("net", ["plate", "plate64"])
 @pytest.mark.parametrize("fused", [True, False])
-def test_plate_residual_and_layer_gradients_within_fp32_bounds(dev, golden_dir, fused):
+def test_plate_residual_and_layer_gradients_within_fp32_bounds(dev, golden_dir, fused, net):
     """The wave family's tight test (tests/test_gpu_parity.py::test_residual_vector_and_layer_gradients_within_fp32_bounds) for the plate:
     at the reference's TRAINED plate nets (PLATE:885-887; the uv net is 8 x 70 -> the five-stream LDS-operand layout of the fused kernel,
     or the two-kernel path with the fused kernels switched off) the residual vector f of PLATE:404-439 (golden_plate.npz stores it), the
     gradient blocks of the main head and of the hole-traction head are held to a small factor of the error a host fp32 evaluation of
-    the same formulas makes against the float64 oracle.  A 1-2 % error in one layer fails."""
-    g = np.load(f"{golden_dir}/golden_plate.npz")
-    flat, lay, eng = _plate_nets(golden_dir, dev, 1024)
+    the same formulas makes against the float64 oracle.  A 1-2 % error in one layer fails.
+    net = "plate64" (round 6): the same bars at the trained 8 x 64 net, through `Fused<OpF16,3,64,8,5>` -- asserted with the path counters."""
+    g = np.load(f"{golden_dir}/{TRAINED[net][1]}")
+    flat, lay, eng = _plate_nets(golden_dir, dev, 1024, net)
     X, H = g["X"], g["H"]
     n = X.shape[0]
     tw = np.ones(5) / n
@@ -192,7 +202,10 @@ def test_plate_residual_and_layer_gradients_within_fp32_bounds(dev, golden_dir, 
         for i in range(5):
             assert np.linalg.norm(f_dev[:, i] - f64[:, i]) <= 3.0 * np.linalg.norm(f32[:, i] - f64[:, i]) + 1e-7 * np.linalg.norm(f64[:, i]), i
         frozen = torch.stack([to_dev(Dst, dev), to_dev(Pst, dev)]).contiguous()
+        lib.path_counts(reset=True)
         ss, gr = eng["uv"].plate_loss_grad(theta, x, y, t, LB, UB, False, frozen, tw)
+        pc = lib.path_counts()
+        assert pc[TRAINED[net][3] if fused else "two-kernel"] == 1 and sum(pc.values()) == 1, (net, fused, pc)      # the kernel this test is about DID run
         assert rel(ss.cpu().numpy(), g["sumsq"]) < 2e-3
         _layer_blocks_within(gr.cpu().numpy(), grad32, grad64, lay["uv"], 6.0, 1e-6, "main")
         # hole traction head (PLATE:452-461)
@@ -209,13 +222,14 @@ def test_plate_residual_and_layer_gradients_within_fp32_bounds(dev, golden_dir, 
         lib.set_fused(True)
 
 
-def test_plate_trained_weight_gradient_over_many_workgroup_steps(dev, golden_dir):
+@pytest.mark.parametrize("net", ["plate", "plate64"])
+def test_plate_trained_weight_gradient_over_many_workgroup_steps(dev, golden_dir, net):
     """32 768 seeded points (oracle/golden_points.py, golden_plate_32k.npz) at the reference's trained plate nets, through a workspace
     sized for 1024 points (32 workgroups x 32 steps of the five-stream LDS-operand layout) and through the default one; the hole head on
     4096 points.  Sums within a few fp32 errors, gradient blocks per layer within 6 fp32 errors of the float64 oracle."""
     from oracle import golden_points as gp
-    g = np.load(f"{golden_dir}/golden_plate_32k.npz")
-    flat, lay, _ = _plate_nets(golden_dir, dev, 1024)
+    g = np.load(f"{golden_dir}/{TRAINED[net][2]}")
+    flat, lay, _ = _plate_nets(golden_dir, dev, 1024, net)
     X, H = gp.plate_points(int(g["n"])), gp.hole_points()
     n = X.shape[0]
     tw = np.ones(5) / n
@@ -226,9 +240,13 @@ def test_plate_trained_weight_gradient_over_many_workgroup_steps(dev, golden_dir
     theta = to_dev(flat["uv"], dev)
     frozen = torch.stack([to_dev(Dst, dev), to_dev(Pst, dev)]).contiguous()
     ss64 = g["sumsq"]
-    for max_points in (1024, n):
+    # (plate64: a 1024-point workspace holds fewer than the 64 scratch images a persistent launch of the register-state kernel asks for --
+    # the call would take the two-kernel path; 2048 points' worth: 64 workgroups x 8 steps)
+    for max_points in (2048 if net == "plate64" else 1024, n):
         eng = engine(lay["uv"], dev, max_points)
+        eng.lib.path_counts(reset=True)
         ss, gr = eng.plate_loss_grad(theta, x, y, t, LB, UB, False, frozen, tw)
+        assert eng.lib.path_counts()[TRAINED[net][3]] == 1, (net, eng.lib.path_counts())
         ssd = ss.cpu().numpy().astype(np.float64)
         for i in range(5):
             assert abs(ssd[i] - ss64[i]) <= 4.0 * abs(float(ss32[i]) - ss64[i]) + 2e-5 * ss64[i], (max_points, i, ssd[i], ss64[i])
@@ -252,14 +270,15 @@ def test_plate_trained_weight_gradient_over_many_workgroup_steps(dev, golden_dir
     _layer_blocks_within(gh.cpu().numpy(), gh32, g["hole_grad"], lay["uv"], 25.0, 2e-6, "traction")
 
 
-def test_plate_three_legs_oracle_fp32_device_f16x3(dev, golden_dir):
+@pytest.mark.parametrize("net", ["plate", "plate64"])
+def test_plate_three_legs_oracle_fp32_device_f16x3(dev, golden_dir, net):
     """Third leg for the plate (round 3: PINN_PREC_FP32 now carries the second time derivative and the plate heads): at the reference's
     TRAINED plate nets the fp32 device run agrees with the float64 oracle as well as fp32 can (five streams 2e-5, gradient to the
     cancellation-limited accuracy), and the f16x3 product mode stays within a small factor of the fp32 device run's own error, per
     weight layer, for the main head (PLATE:404-439) and the hole traction (PLATE:452-461)."""
     from pinn_elastodynamics_amd.hip_engine import HipEngine
-    g = np.load(f"{golden_dir}/golden_plate.npz")
-    flat, lay, eng = _plate_nets(golden_dir, dev, 1024)
+    g = np.load(f"{golden_dir}/{TRAINED[net][1]}")
+    flat, lay, eng = _plate_nets(golden_dir, dev, 1024, net)
     e32 = HipEngine(lay["uv"], precision="fp32", device=dev, max_points=1024)
     X, H = g["X"], g["H"]
     n = X.shape[0]
