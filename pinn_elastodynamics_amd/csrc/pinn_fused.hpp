@@ -339,6 +339,25 @@ struct Fused {
     static constexpr int NSUM = IBW * OBW + (LDSOP ? NBIASREC : 0);            // in-memory records per layer: the blocks (+ LDSOP: the bias blocks' lane records)
     static constexpr unsigned WG_ACC_BYTES = (unsigned)((NG > 0 ? NG : 1) * NSUM * 1024);
     static __device__ __forceinline__ constexpr bool in_memory(int L) { return L >= 1 && L <= NL - 1 && L > NREG; }
+    // Cache policy of the two per-workgroup memory classes (round 6).  A persistent workgroup owns TILES scratch images (parked states: written
+    // in the forward, read back once by LDS-DMA in the reverse) and four areas of running weight-gradient sums (read and written once per
+    // step and in-memory layer).  Nothing of either is ever shared between workgroups, and both cycle once per 32-point step: whether the
+    // traffic stops at the 256 MB Infinity Cache or goes on to HBM is a question of the launch's FOOTPRINT, 256 x (images + sums).
+    // Measured (profiles/r06_footprint_and_cache_policy.txt): the 3-D kernel at 318 MB runs its 174 us step in 119 us with 176 workgroups
+    // (224 MB) and in 139 us with the same traffic squeezed into half the addresses; marking ONE of the two classes non-temporal (`nt` on
+    // its loads and stores: allocated to be replaced first) keeps the other one resident: 3-D 21.4 -> 18.8 ms per 1 M points, 6 x 140
+    // (235 MB) 14.1 -> 12.8; both classes marked: 19.3; the layouts that fit (8 x 100: 214 MB, 8 x 80, plate 8 x 70, all narrow ones)
+    // LOSE 2-10 % with either class marked.  So: only the layouts whose full grid exceeds the cache, and of the two classes the one that
+    // moves fewer bytes per step.
+#ifndef PINN_NT_POLICY
+#define PINN_NT_POLICY 1           // A / B: 0 = no non-temporal hints anywhere, 2 = the sums of every LDS-operand layout, 3 = the images, 4 = both
+#endif
+    static constexpr size_t IMAGES_WG_BYTES = (size_t)TILES * SCRATCH_BYTES, SUMS_WG_BYTES = (size_t)4 * WG_ACC_BYTES;
+    static constexpr bool OVER_MALL = PINN_NT_POLICY == 1 && LDSOP && !WSLDS && (size_t)256 * (IMAGES_WG_BYTES + SUMS_WG_BYTES) > ((size_t)224 << 20);
+    static constexpr bool NT_FORCED = LDSOP && !WSLDS && PINN_NT_POLICY >= 2;
+    static constexpr bool NT_SUMS = (OVER_MALL && SUMS_WG_BYTES <= IMAGES_WG_BYTES) || (NT_FORCED && PINN_NT_POLICY != 3);      // (each class is read and written once per step: bytes per step ~ size)
+    static constexpr bool NT_IMAGES = (OVER_MALL && !NT_SUMS) || (NT_FORCED && PINN_NT_POLICY != 2);
+    static constexpr int ACC_AUX = NT_SUMS ? 2 : 0, SCR_AUX = NT_IMAGES ? 2 : 0;        // aux operand of the buffer builtins: bit 1 = nt
     struct Sums {                      // running sums of one in-memory layer: this wave's blocks (+ LDSOP: its bias blocks, one float per lane and block)
         f32x4 blk[IBW][STREAM_SUMS ? 2 : OBW];      // (STREAM_SUMS: the first pass's two out-blocks only, requested ahead)
         f32x4 bias;
@@ -605,11 +624,7 @@ struct Fused {
             for (int i = 0; i < IBW; ++i)
 #pragma unroll
                 for (int b = 0; b < NNEXT; ++b)
-#ifdef PINN_X_NOSUMS
-                    next[i][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#else
-                    next[i][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(job.accr, job.lane16, acc_record(L, i, O0 + NBK + b), 0));
-#endif
+                    next[i][b] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(job.accr, job.lane16, acc_record(L, i, O0 + NBK + b), ACC_AUX));
         }
         const uint32_t one2 = pack2<Op>(1.0f, 1.0f);
         const u32x4 ones = {one2, one2, one2, one2};
@@ -660,13 +675,11 @@ struct Fused {
         // the per-block loop above produced exactly that sequence.  So: all sums are final first, then all stores, then wait states, and the
         // scheduler may not move vector work in between.
         store_fence(acc);
-#ifndef PINN_X_NOSUMS
 #pragma unroll
         for (int i = 0; i < IBW; ++i)
 #pragma unroll
             for (int b = 0; b < NBK; ++b)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][b]), job.accr, job.lane16, acc_record(L, i, O0 + b), 0);
-#endif
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][b]), job.accr, job.lane16, acc_record(L, i, O0 + b), ACC_AUX);
         stores_issued();
     }
     // mid layer L of the ten-block layout: three passes over the out-blocks (pair, pair, single); lds_ = the first pass's sums (+ the bias
@@ -696,7 +709,7 @@ struct Fused {
                 ba[3] += b23[1];
                 f32x4 one[1][1] = {{ba}};
                 store_fence(one);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, one[0][0]), job.accr, job.lane16, bias_record(L), 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, one[0][0]), job.accr, job.lane16, bias_record(L), ACC_AUX);
                 stores_issued();
             }
             return;
@@ -710,12 +723,12 @@ struct Fused {
             ba[1] += b01[1];
             ba[2] += b23[0];
             ba[3] += b23[1];
-            f32x4 bb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(job.accr, job.lane16, bias_record(L) + 1024, 0));
+            f32x4 bb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(job.accr, job.lane16, bias_record(L) + 1024, ACC_AUX));
             bb[0] += b4[0];
             f32x4 both[1][2] = {{ba, bb}};
             store_fence(both);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, both[0][0]), job.accr, job.lane16, bias_record(L), 0);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, both[0][1]), job.accr, job.lane16, bias_record(L) + 1024, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, both[0][0]), job.accr, job.lane16, bias_record(L), ACC_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, both[0][1]), job.accr, job.lane16, bias_record(L) + 1024, ACC_AUX);
             stores_issued();
         }
     }
@@ -936,9 +949,6 @@ struct Fused {
     static __device__ __forceinline__ void dma_state(const DmaSrc& src, unsigned lane16, char* tile_lds, int l /*1..NL-1*/, int quad, int ii0 = 0,
                                                      int ii1 = N_DMA_ALL) {
         if constexpr (SLDS || WSLDS) return;
-#ifdef PINN_X_NODMA
-        return;
-#endif
         char* dst = tile_lds + TENSOR_Z_B + slot_of(l) * IMG_B;
         // LDSOP: two tiles, four waves: wave quad brings every second record of tile quad & 1 (records quad >> 1, +2, ...)
         const int i0 = LDSOP ? (quad >> 1) : 0;
@@ -948,8 +958,12 @@ struct Fused {
             const int i = LDSOP ? i0 + 2 * ii : ii;
 #if defined(__AMDGCN__)
             const unsigned lds_addr = (unsigned)(uintptr_t)((lds_void*)(dst + i * 1024));
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
-                         :: "v"(lane16), "s"(src.desc), "s"(lds_addr), "s"((unsigned)((l - 1) * IMG_B + i * 1024)) : "memory");
+            if constexpr (NT_IMAGES)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen nt lds"
+                             :: "v"(lane16), "s"(src.desc), "s"(lds_addr), "s"((unsigned)((l - 1) * IMG_B + i * 1024)) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+                             :: "v"(lane16), "s"(src.desc), "s"(lds_addr), "s"((unsigned)((l - 1) * IMG_B + i * 1024)) : "memory");
 #else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(src.rsrc, (lds_void*)(dst + i * 1024), 16, lane16, (l - 1) * IMG_B + i * 1024, 0, 0);
 #endif
@@ -959,16 +973,13 @@ struct Fused {
     // LDSOP forward: S_k (k = 1..NL-1) sits in the tile's Z area (k odd) or S slot 0 (k even), complete behind the layer's barrier; copy
     // this wave's records (the ones dma_state brings back) to the scratch image.  The LDS reads are drained by the next lds_barrier.
     static __device__ __forceinline__ void park_image(__amdgpu_buffer_rsrc_t scr, unsigned lane16, const char* tile_lds, int k, int quad) {
-#ifdef PINN_X_NODMA
-        return;
-#endif
         const char* src = tile_lds + ((k & 1) ? 0 : TENSOR_Z_B) + lane16;
         const int i0 = quad >> 1;
         u32x4 v[N_DMA_ALL];
 #pragma unroll
         for (int ii = 0; ii < N_DMA_ALL; ++ii) v[ii] = *reinterpret_cast<const u32x4*>(src + (i0 + 2 * ii) * 1024);
 #pragma unroll
-        for (int ii = 0; ii < N_DMA_ALL; ++ii) __builtin_amdgcn_raw_buffer_store_b128(v[ii], scr, lane16, (k - 1) * IMG_B + (i0 + 2 * ii) * 1024, 0);
+        for (int ii = 0; ii < N_DMA_ALL; ++ii) __builtin_amdgcn_raw_buffer_store_b128(v[ii], scr, lane16, (k - 1) * IMG_B + (i0 + 2 * ii) * 1024, SCR_AUX);
     }
 
     // accumulator blocks of an in-memory layer: record (L - NREG - 1, i, o) of this wave's 1 KB-record area
@@ -983,21 +994,16 @@ struct Fused {
 #pragma unroll
         for (int i = 0; i < IBW; ++i)
 #pragma unroll
-            for (int o = 0; o < OBW; ++o) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p.blk[i][o]), accr, lane16, acc_record(L, i, o), 0);
-        if constexpr (LDSOP) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p.bias), accr, lane16, bias_record(L), 0);
+            for (int o = 0; o < OBW; ++o) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p.blk[i][o]), accr, lane16, acc_record(L, i, o), ACC_AUX);
+        if constexpr (LDSOP) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, p.bias), accr, lane16, bias_record(L), ACC_AUX);
         stores_issued();
     }
     static __device__ __forceinline__ void load_sums(__amdgpu_buffer_rsrc_t accr, unsigned lane16, int L, Sums& p) {
-#ifdef PINN_X_NOSUMS
-        for (int i = 0; i < IBW; ++i) for (int o = 0; o < (STREAM_SUMS ? 2 : OBW); ++o) p.blk[i][o] = f32x4{0.f, 0.f, 0.f, 0.f};
-        p.bias = f32x4{0.f, 0.f, 0.f, 0.f};
-        return;
-#endif
 #pragma unroll
         for (int i = 0; i < IBW; ++i)
 #pragma unroll
-            for (int o = 0; o < (STREAM_SUMS ? 2 : OBW); ++o) p.blk[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), 0));
-        if constexpr (LDSOP) p.bias = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(L), 0));
+            for (int o = 0; o < (STREAM_SUMS ? 2 : OBW); ++o) p.blk[i][o] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(L, i, o), ACC_AUX));
+        if constexpr (LDSOP) p.bias = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(L), ACC_AUX));
     }
 
     // fences around a group of 16-byte buffer stores (see stream_pass): the values are complete before the first store, and no vector
@@ -1096,25 +1102,7 @@ struct Fused {
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             fused_stamp(a, tracer, 65 + 3 * (NL - L));
-#ifdef PINN_X_TOUCH
-            // experiment: bring the scratch image of S_{L-1} -- which this wave will LDS-DMA in the NEXT layer's hand-off window -- into L2 now
-            // (one dword per 128-byte line of this wave's records: 64 lanes x 3 loads cover its 20 records of 1 KB)
-            uint32_t touch[3] = {0u, 0u, 0u};
-            if constexpr (ONE_SLOT && L >= 2 && !kept_in_lds(L - 1)) {
-                const long gt = (long)fused_bid(a) * TILES + (quad & 1);
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(reinterpret_cast<char*>(a.scratch) + gt * (long)SCRATCH_BYTES), 0, (int)SCRATCH_BYTES, 0x00020000);
-                const unsigned ln = lane16 >> 4;
-#pragma unroll
-                for (int g = 0; g < 3; ++g) {
-                    const unsigned rec = (unsigned)(quad >> 1) + 2u * (8u * g + (ln >> 3));
-                    touch[g] = __builtin_amdgcn_raw_buffer_load_b32(rs, rec * 1024u + (ln & 7u) * 128u, (L - 2) * IMG_B, 0);
-                }
-            }
-#endif
             wgrad<L>(w, A, quad, ld, pend, DmaJob{&scr, lane16, tile_lds, quad, accr});
-#ifdef PINN_X_TOUCH
-            asm volatile("" :: "v"(touch[0]), "v"(touch[1]), "v"(touch[2]));
-#endif
             if constexpr (EARLY_SUMS) {
                 if constexpr (in_memory(L)) store_sums(accr, lane16, L, pend);
                 if constexpr (in_memory(L - 1)) load_sums(accr, lane16, L - 1, ld);
@@ -1162,7 +1150,7 @@ struct Fused {
             (void*)(reinterpret_cast<char*>(a.wg_acc) + ((long)fused_bid(a) * 4 + quad) * (long)WG_ACC_BYTES), 0, (int)WG_ACC_BYTES, 0x00020000);
         if constexpr (NG > 0) {
 #pragma unroll
-            for (int r = 0; r < NG * NSUM; ++r) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, accr, lane16, r * 1024, 0);
+            for (int r = 0; r < NG * NSUM; ++r) __builtin_amdgcn_raw_buffer_store_b128(u32x4{0u, 0u, 0u, 0u}, accr, lane16, r * 1024, ACC_AUX);
         }
         Sums pend, ld;
         Ctx xs1;                                          // S1_BY_WG: addressing of chain tile `quad` as far as the first layer needs it
@@ -1246,14 +1234,14 @@ struct Fused {
 #pragma unroll
                     for (int o = 0; o < OBW; ++o) {
                         f32x4 v;
-                        if (in_memory(l)) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(l, i, o), 0));
+                        if (in_memory(l)) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(l, i, o), ACC_AUX));
                         else v = A.mid[l <= NREG ? l - 1 : 0][NREG > 0 ? i : 0][NREG > 0 ? o : 0];
                         put_block(v, l, wide_block(wi, i), wide_block(wo, o), H, H);
                     }
                 f32x4 bv, bv2 = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (in_memory(l)) {
-                    bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l), 0));
-                    if constexpr (NBIASREC > 1) bv2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l) + 1024, 0));
+                    bv = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l), ACC_AUX));
+                    if constexpr (NBIASREC > 1) bv2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, bias_record(l) + 1024, ACC_AUX));
                 } else {
                     bv = f32x4{A.biasr[l <= NREG ? l - 1 : 0][0], A.biasr[l <= NREG ? l - 1 : 0][1], A.biasr[l <= NREG ? l - 1 : 0][2], A.biasr[l <= NREG ? l - 1 : 0][3]};
                 }
@@ -1280,7 +1268,7 @@ struct Fused {
 #pragma unroll
                 for (int o = 0; o < OBW; ++o) {
                     f32x4 v;
-                    if (in_memory(l)) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(l, i, o), 0));
+                    if (in_memory(l)) v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(accr, lane16, acc_record(l, i, o), ACC_AUX));
                     else v = A.mid[l <= NREG ? l - 1 : 0][i][o];
                     put_block(v, l, wi * IBW + i, wo * OBW + o, H, H);
                 }
@@ -1975,14 +1963,7 @@ struct Fused {
         for (int t = 0; t < NIT; ++t) {
             if (t % HB == 0) op_load(in, t / HB, Bk);
             fwd_kstep<0, 1>(Ar[(T0 + t) % RING], Bk, acc[t % HB]);
-#ifdef PINN_X_HALFW
-            if (t % 2 == 0)
-#endif
-#ifndef PINN_X_NOW
             fwd_request<PAR>(x, l, h, t + RING, Ar);
-#else
-            asm volatile("" : "+v"(Ar[(T0 + t) % RING][0][0]), "+v"(Ar[(T0 + t) % RING][0][1]));
-#endif
         }
     }
     // reverse: the same kind of ring over the items of layers NL-1 .. 1 (T0 = global index of this layer's item 0)
@@ -2001,14 +1982,7 @@ struct Fused {
         for (int t = 0; t < NIT; ++t) {
             if (t % HB == 0) op_load(in, t / HB, Bk);
             bwd_kstep<0, 1>(Ar[(T0 + t) % RINGB], Bk, acc[t % HB]);
-#ifdef PINN_X_HALFW
-            if (t % 2 == 0)
-#endif
-#ifndef PINN_X_NOW
             ring_request<L>(x, h, t + RINGB, Ar);
-#else
-            asm volatile("" : "+v"(Ar[(T0 + t) % RINGB][0][0]), "+v"(Ar[(T0 + t) % RINGB][0][1]), "+v"(Ar[(T0 + t) % RINGB][0][2]));
-#endif
         }
     }
     template <int J>
