@@ -151,7 +151,7 @@ def traffic_from_profiles(name):
     same launches, profiles/README.md) -- NOT measured in this run, hence its own key.  A summary collected on other kernel sources than
     the ones in this tree (kernel_source_sha) is refused: the key then says which file is stale instead of quoting its bytes."""
     sha = kernel_source_sha()
-    for rnd in ("r05", "r04"):
+    for rnd in ("r06", "r05", "r04"):
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", f"{rnd}_{name}_pmc_summary.json")))
             if pm.get("kernel_source_sha") != sha:

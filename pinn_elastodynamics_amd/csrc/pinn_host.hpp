@@ -145,10 +145,19 @@ struct Host {
     static constexpr int FUSED_MAX_WIDTH = 160;     // widest padded net the fused kernel takes (160: 4 streams, 6 layers = CONF:891; 128: 4 and 1 streams (+ the 3-D head); 96 also 5 streams)
     static constexpr size_t FUSED_ACC_W64 = 32 * 1024;
     static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? FUSED_ACC_W64 : (WIDTH <= 96 ? 72 * 1024 : 160 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
-    // fused_step_kernel (collocation set + side sets of a training step in one launch): the narrow layouts
-    static constexpr bool step_has() { return WIDTH <= 64; }
+    // fused_step_kernel (collocation set + side sets of a training step in one launch): the narrow layouts, and (round 6) every LDS-operand
+    // layout that has both of its parts -- the reference's own nets pay 0.36 ms (8 x 80) / 0.61 ms (8 x 100) of a 6.6 / 10.6 ms step for their
+    // side sets as a second launch (profiles/r06_wide_kernel_stats.csv)
+    static constexpr bool step_has() { return true; }
     template <int NSC>
-    static constexpr bool step_has_ns() { return step_has() && (NSC == 4 || SPLIT == 3); }      // (the plate's five streams: split-precision families)
+    static constexpr bool step_has_ns() {
+        if (WIDTH <= 64) return NSC == 4 || SPLIT == 3;      // (the plate's five streams: split-precision families)
+        // (padded width 160 keeps the separate calls: CONF's own step -- 185 k collocation + 90 k side points, tools/conf_step_time.py -- measured
+        // 3.34 / 3.32 ms as one launch against 3.30 / 3.29 as two: its side part is eleven rounds of its own, nothing to hide in a tail)
+        return WIDTH < 160 && fused_has<NSC>() && fused_has<1>();
+    }
+    // depth of the fused instantiations of this width (narrow: 4 or 8, by the net)
+    static constexpr int WIDE_NL = WIDTH == 160 ? 6 : 8;
     template <int NS>
     static constexpr bool fused_has() { return WIDTH <= 64 || (SPLIT == 3 && ((WIDTH <= 96 && (NS == 4 || NS == 5 || NS == 1)) || (WIDTH <= 128 && (NS == 4 || NS == 1)) || (WIDTH == 160 && (NS == 4 || NS == 1)))); }
     static constexpr int MAX_BLOCKS = 2048;   // chain kernel grid cap (4 waves per block)
@@ -568,9 +577,15 @@ struct Host {
             if (((uintptr_t)c.ws & 255) != 0 || c.n <= 0) return 0;
             Plan p;
             plan_fixed<4>(c.net, c.n, p);
-            constexpr int T4 = Fused<Op, SPLIT, WIDTH, 4, NSC>::TILES, T1 = Fused<Op, SPLIT, WIDTH, 4, 1>::TILES;
-            const size_t per4 = (size_t)T4 * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NSC>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NSC>::SCRATCH_BYTES);
-            const size_t per1 = (size_t)T1 * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, 1>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, 1>::SCRATCH_BYTES);
+            constexpr int T4 = Fused<Op, SPLIT, WIDTH, WIDE_NL, NSC>::TILES, T1 = Fused<Op, SPLIT, WIDTH, WIDE_NL, 1>::TILES;
+            size_t per4, per1;
+            if constexpr (WIDTH > 64) {
+                per4 = (size_t)T4 * Fused<Op, SPLIT, WIDTH, WIDE_NL, NSC>::SCRATCH_BYTES;
+                per1 = (size_t)T1 * Fused<Op, SPLIT, WIDTH, WIDE_NL, 1>::SCRATCH_BYTES;
+            } else {
+                per4 = (size_t)T4 * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, NSC>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, NSC>::SCRATCH_BYTES);
+                per1 = (size_t)T1 * (c.net.nl == 4 ? Fused<Op, SPLIT, WIDTH, 4, 1>::SCRATCH_BYTES : Fused<Op, SPLIT, WIDTH, 8, 1>::SCRATCH_BYTES);
+            }
             const long nsteps4 = (c.n + 16 * T4 - 1) / (16 * T4);
             long nsteps1 = 0;
             DataSet sets[4];
@@ -588,12 +603,18 @@ struct Host {
             p.wg_acc_b = bo;
             bo = align_up(bo + (size_t)grid1 * 4 * FUSED_ACC_BYTES, 256);
             if (c.ws_bytes < bo) return 0;      // (the two calls then size their grids to the workspace one by one)
+            if constexpr (WIDTH > 64) {
+                *out = step_launch<WIDE_NL, NSC, false>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1, nterms_a, nterms_b);
+                g_path_counts[PINN_PATH_FUSED_LDS] += 2;
+                return 1;
+            } else {
             if (NSC == 4 && c.fast_state && SPLIT == 3 && c.net.nl == 8)
                 *out = step_launch<8, NSC, NSC == 4>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1, nterms_a, nterms_b);
             else *out = c.net.nl == 4 ? step_launch<4, NSC, false>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1, nterms_a, nterms_b)
                                       : step_launch<8, NSC, false>(c, d, adam, p, (int)grid4, nsteps4, (int)grid1, nsteps1, off1, nterms_a, nterms_b);
             g_path_counts[PINN_PATH_FUSED_REGISTERS] += 2;      // (both families of the step)
             return 1;
+            }
         } else {
             return 0;
         }
