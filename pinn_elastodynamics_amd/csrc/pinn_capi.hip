@@ -82,7 +82,33 @@ static int g_ring_every = 1;
 #ifndef PINN_XCD_TAIL_DEFAULT
 #define PINN_XCD_TAIL_DEFAULT 16      // 1.6 % more steps for the even XCDs (A / B on one box, 96 interleaved launches each: 0 / 12 / 20 permille -> 4.492 / 4.437 / 4.432 ms per 2 M points; profiles/r05_xcd_bonus_ab.txt)
 #endif
-namespace pinn { long g_path_counts[5] = {0, 0, 0, 0, 0}; int g_xcd_tail_permille = PINN_XCD_TAIL_DEFAULT; int g_fused_grid_cap = 0; }
+namespace pinn {
+long g_path_counts[5] = {0, 0, 0, 0, 0};
+int g_xcd_tail_permille = PINN_XCD_TAIL_DEFAULT;
+int g_fused_grid_cap = 0;
+// The XCD-aware tail assumes what was measured on an MI355X in SPX mode: 256 compute units in 8 XCDs, workgroup b on XCD b % 8, the even
+// XCDs 2-3 % faster on this kernel.  Any other device (another part, a partitioned one: CPX / DPX show fewer compute units) keeps the plain
+// round-robin loop.  Asked once per device.
+bool xcd_tail_device_ok() {
+#if defined(PINN_SIMT_EMULATOR)
+    return true;       // (the x86 test build exercises the index arithmetic on small grids)
+#else
+    static int cached[64];      // 0 unknown, 1 yes, 2 no
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+    if (cached[dev] == 0) {
+        hipDeviceProp_t pr;
+        bool ok = hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount == 256;
+        if (ok) {
+            const char* a = pr.gcnArchName;
+            ok = a[0] == 'g' && a[1] == 'f' && a[2] == 'x' && a[3] == '9' && a[4] == '5' && a[5] == '0';
+        }
+        cached[dev] = ok ? 1 : 2;
+    }
+    return cached[dev] == 1;
+#endif
+}
+}
 
 extern "C" {
 

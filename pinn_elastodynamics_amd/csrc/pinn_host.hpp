@@ -89,6 +89,7 @@ struct Call {
 extern long g_path_counts[5];
 // extra steps of the even-XCD workgroups in 1/1000 (FusedArgs::n_plain; pinn_debug_set_xcd_bonus); 0 = off
 extern int g_xcd_tail_permille;
+bool xcd_tail_device_ok();      // (pinn_capi.hip) the tail's premises hold on the current device: gfx950, 256 compute units (SPX)
 // testing hook (pinn_debug_set_fused_grid_cap): at most this many workgroups in a fused launch (0: no cap beyond FUSED_GRID)
 extern int g_fused_grid_cap;
 
@@ -488,7 +489,7 @@ struct Host {
 #else
         const bool shape_ok = grid == FUSED_GRID && nsteps >= 64L * FUSED_GRID;
 #endif
-        if (NS >= 4 && DIN == 3 && block0 == 0 && shape_ok && g_xcd_tail_permille > 0) {
+        if (NS >= 4 && DIN == 3 && block0 == 0 && shape_ok && g_xcd_tail_permille > 0 && xcd_tail_device_ok()) {
             const long R = (long)((double)nsteps / ((grid / 2) * (2.0 + 0.001 * g_xcd_tail_permille)));
             a.n_plain = R * grid;
         }
