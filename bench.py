@@ -169,6 +169,53 @@ def traffic_from_profiles(name):
     return None
 
 
+def measure_traffic(argv, points_per_launch, timeout_s=240):
+    """HBM-side bytes per launch of the dominant kernel, MEASURED IN THIS RUN: two separate `rocprofv3 --pmc` passes (FETCH_SIZE, then WRITE_SIZE;
+    --kernel-trace only beside them, as /opt/skills/guides/MI355X_MICROARCH.md prescribes: counters in their own runs, run from /tmp) over a child
+    of this script (`--traffic-child`: the same workload, a few untimed steps), per-dispatch values of the full-grid fused launches, median.
+    gfx950 corrections of the guide: the counters are in KB, and streamed 16-byte reads are under-counted by 2 -> bytes = 1024 (2 FETCH + WRITE).
+    These are L2 <-> fabric bytes: Infinity-Cache hits are in them (the L2 cannot tell MALL from HBM).  Returns a dict; "bytes_per_launch" is None
+    with a "reason" when rocprofv3 is not there or a pass fails -- the bench line never depends on it."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"bytes_per_launch": None, "reason": "rocprofv3 not found"}
+    vals = {}
+    tmp = tempfile.mkdtemp(prefix="pinn_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [exe, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+                   "--traffic-child"] + [a for a in argv if a not in ("--traffic-child",)]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            rows = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "fused" in row["Kernel_Name"] and row["Counter_Name"] == ctr and int(row["Grid_Size"]) >= 256 * 512:
+                        rows.append(float(row["Counter_Value"]))
+            if r.returncode != 0 or not rows:
+                return {"bytes_per_launch": None, "reason": f"rocprofv3 --pmc {ctr} pass: rc {r.returncode}, {len(rows)} full-grid fused dispatches found",
+                        "tail": r.stdout.decode(errors="replace")[-400:]}
+            top = sorted(rows)[len(rows) // 2:]          # the full-size launches are the largest values: median of the top half (as tools/pmc_summarize.py)
+            vals[ctr] = (sorted(top)[len(top) // 2], len(rows))
+    except Exception as e:      # (a timeout, an unreadable file: the line goes out without the measurement)
+        return {"bytes_per_launch": None, "reason": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    b = 1024.0 * (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0])
+    return {"bytes_per_launch": b, "bytes_per_point": b / points_per_launch, "points_per_launch": points_per_launch,
+            "fetch_size_kb": vals["FETCH_SIZE"][0], "write_size_kb": vals["WRITE_SIZE"][0], "dispatches_seen": [vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]],
+            "seconds": time.perf_counter() - t0,
+            "note": "two rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE, --kernel-trace only) over a child of this script on this box, behind the timed region; "
+                    "bytes = 1024 x (2 x FETCH_SIZE + WRITE_SIZE) per the guide's gfx950 corrections; L2 <-> fabric bytes, Infinity-Cache hits included"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -194,6 +241,8 @@ def main():
     ap.add_argument("--no-step-call", action="store_true", help="wave config: make the step's library calls one by one (collocation kernel, side-set kernel, two "
                     "reductions, Adam: the round-4 sequence) instead of pinn_wave2d_step -- the same bits; for A / B timing on one box")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc passes that measure roofline.traffic (N = 1 only; ~30-40 s)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)      # the process those passes profile: the workload, a few untimed steps, no line
     ap.add_argument("--no-small-config", action="store_true")
     ap.add_argument("--extra-modes", default="bf16,f16x3_fp16state",
                     help="comma list of other modes to time briefly (wave, rank 0 / N=1): precision modes, or f16x3_fp16state = f16x3 with PINN_FLAG_STATE_FP16")
@@ -311,6 +360,13 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
+
+    if args.traffic_child:
+        step(2)
+        torch.cuda.synchronize()
+        step(6)
+        torch.cuda.synchronize()
+        return
 
     # clock ramp: the GPU idles at a few hundred MHz; run the step untimed for a moment before the counted warm-up so that the
     # K timed steps see settled clocks (a fixed number of steps, not a time limit: every rank must issue the same all-reduces)
@@ -487,8 +543,8 @@ def main():
                                "note": "achieved = algorithmic flops (one product per contraction) / MEDIAN HIP-event duration (launch_stat) of >= 32 bracketed launches of one "
                                        "more block of steps behind the timed ones (events in stream order, nothing synchronises in between); the f16x3 mode issues 3 MFMAs per "
                                        f"product in the forward / reverse chain and {wg_mfma} in the weight gradient, so a 100 %-busy matrix pipe is frac {1.0 / issued:.3f}. "
-                                       "Measured limiter: one wave's in-order issue of vector instructions + MFMAs and its vector-memory instructions (DESIGN.md section 4, profiles/r04_opcode_issue_costs.md). traffic: NOT MEASURED IN THIS "
-                                       "RUN (PMC counters need rocprofv3); traffic_from_profiles quotes the committed PMC passes of the same kernel sources"}
+                                       "Measured limiter: one wave's in-order issue of vector instructions + MFMAs and its vector-memory instructions (DESIGN.md section 4, profiles/r04_opcode_issue_costs.md). traffic: bytes per launch from two "
+                                       "rocprofv3 --pmc passes over a child of this script behind the timed region (traffic_detail; null with a reason if they fail); traffic_from_profiles quotes the committed PMC passes of the same kernel sources"}
             out["kernel_ms_per_step"] = acc
         elif cfg == "plate" and eng.lib.supported_width(layers[1]) <= 96 and len(layers) - 2 in (4, 8):
             # ---- the five-stream instantiation of the fused kernel: HIP events around the kernel on the launch stream (process-wide
@@ -505,7 +561,7 @@ def main():
                                        "gradient) / HIP-event launch time of the collocation launch; the hole-traction set (9960 points) is a second, one-stream "
                                        "launch of the fused kernel.  The launches are timed in one more block of `steps` steps behind the timed ones "
                                        "(timed_block_ms_per_step is that block's own wall time per step: avg_launch_ms is a part of IT; the collocation launch "
-                                       "is 98 % of a plate step, so a percent of drift between the blocks shows).  traffic not measured in this run"}
+                                       "is 98 % of a plate step, so a percent of drift between the blocks shows).  traffic: see traffic_detail"}
             out["kernel_ms_per_step"] = acc
         elif cfg == "nc3d" and args.precision == "f16x3" and layers[1:-1] == [128] * 10:
             # ---- the 3-D instantiation of the fused kernel (Fused<..., NL = 10, NS = 5, DIN = 4>): HIP events around the collocation launch
@@ -535,7 +591,7 @@ def main():
                                "launches_timed": int(collo_ms.size), "timed_block_ms_per_step": ring_block_ms_per_step, "launch_stat": ls, "issued_mfma_tflops": tflops * issued,
                                "note": "achieved = algorithmic flops (15 x 2 sum|W| per point: five streams forward, five reverse, five in the weight "
                                        "gradient) / HIP-event launch time of the collocation launch; measured limiter of the LDS-operand layouts: the bytes "
-                                       "of parked states and in-memory weight-gradient sums through L2 (DESIGN_HISTORY.md section 6).  traffic not measured in this run"}
+                                       "of parked states and in-memory weight-gradient sums through L2 (DESIGN_HISTORY.md section 6).  traffic: see traffic_detail"}
             out["kernel_ms_per_step"] = acc
         else:
             # two-kernel path: the step is a sequence of chain + weight-gradient launches over workspace passes; report the whole step
@@ -545,6 +601,13 @@ def main():
                                "issued_mfma_tflops": tflops * issued, "algorithmic_flop_per_point": flop_pt,
                                "note": "whole-step algorithmic flops / wall time per step (HIP work of a step is back-to-back on one stream); this path "
                                        "spills the per-layer state and adjoint panels to HBM and is bound by that traffic, not by the matrix pipe"}
+        if world == 1 and not args.no_traffic and "roofline" in out and "traffic" in out["roofline"] and out["roofline"].get("launches_per_step") in (None, 1):
+            # roofline.traffic, measured on this box in this run (two rocprofv3 --pmc passes over a child process: see measure_traffic); the
+            # committed passes of the round stay beside it (traffic_from_profiles)
+            tr = measure_traffic(sys.argv[1:], pts_per_rank)
+            out["roofline"]["traffic"] = tr.get("bytes_per_launch")
+            out["roofline"]["traffic_measured_in_this_run"] = tr.get("bytes_per_launch") is not None
+            out["roofline"]["traffic_detail"] = tr
         if world == 1:
             if cfg == "wave":
                 from pinn_elastodynamics_amd.elastic_wave import DeepHPM

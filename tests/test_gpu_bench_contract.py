@@ -25,7 +25,7 @@ def run_bench(args, env=None, launcher=None):
                                        ("plate", ["--points-per-gpu", "120000"]),
                                        ("nc3d", ["--points-per-gpu", "65536"])])
 def test_bench_line(cfg, extra):
-    d = run_bench(["--config", cfg, "--steps", "4", "--warmup", "1", "--ramp-steps", "2", "--no-cpu-baseline"] + extra)
+    d = run_bench(["--config", cfg, "--steps", "4", "--warmup", "1", "--ramp-steps", "2", "--no-cpu-baseline"] + ([] if cfg == "nc3d" else ["--no-traffic"]) + extra)
     assert REQUIRED <= set(d), sorted(REQUIRED - set(d))
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["unit"] == "collocation-points/s" and d["value"] > 0 and d["ms_per_step"] > 0 and d["dtype"] == "f16x3" and d["data"] == "synthetic"
@@ -54,6 +54,11 @@ def test_bench_line(cfg, extra):
         assert r["ring_every"] == 8 and d["allreduce_ms"] is None and d["rank_share"] is None
     if cfg == "nc3d":
         assert "fused_wave_kernel" in r["kernel"] and r["launches_per_step"] == 1 and "fused" in d["config"]["workload"]
+        # round 6: roofline.traffic is measured in the run (two rocprofv3 --pmc passes over a child process): the 3-D kernel moves ~80 KB per point
+        assert r["traffic_measured_in_this_run"] is True and r["traffic"] == r["traffic_detail"]["bytes_per_launch"], r.get("traffic_detail")
+        assert 40e3 < r["traffic_detail"]["bytes_per_point"] < 120e3, r["traffic_detail"]
+    else:
+        assert r["traffic"] is None and r["traffic_measured_in_this_run"] is False          # (--no-traffic)
     # at least one second of timed work whatever --steps is: the K-step block is repeated, the median block is reported
     tb = d["timed_blocks"]
     assert tb["steps_per_block"] == 4 and tb["count"] >= 1 and (tb["count"] * tb["block_ms_median"] >= 900.0 or tb["count"] == 64)
@@ -77,6 +82,9 @@ def test_bench_line_of_the_drivers_exact_command_is_self_consistent():
     assert abs(r["frac"] - d["whole_path"]["frac_of_mfma_peak"]) <= 0.003, (r["frac"], d["whole_path"])
     assert d["mcycles_per_step"] is not None and abs(d["mcycles_per_step"] - d["ms_per_step"] * d["shader_clock_ghz"]) < 1e-9
     assert "cpu_baseline" in d and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    # round 6: traffic measured on this box in this run, per launch like `achieved`: the headline kernel parks ~7.4 KB per point through L2 <-> fabric
+    assert r["traffic_measured_in_this_run"] is True and r["traffic"] is not None, r.get("traffic_detail")
+    assert 5e3 < r["traffic"] / 2_000_000 < 11e3, r["traffic_detail"]
 
 
 def test_bench_two_ranks_strong_scaling_gloo():
