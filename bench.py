@@ -353,7 +353,7 @@ def main():
                     f"{pts_per_rank} collocation pts per GPU + IC/TOP 20000 each + SRC 20000, Adam step incl. gradient all-reduce (BASELINE configs[4]: "
                     f"32 M pts on 8 GPUs); 'fp32' is served by f16x3 (fp32-class: sums and gradient within 2e-5 of the float64 oracle; exact-fp32 device mode exists "
                     f"for checks); collocation set through the fused LDS-operand kernel (padded width 128, five first-order streams, four inputs), side sets "
-                    f"through the two-kernel path")
+                    f"through its one-stream instantiation (round 6)")
     flop_pt = flop_per_point(layers, streams)
 
     def barrier():

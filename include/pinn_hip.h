@@ -323,7 +323,9 @@ int pinn_nc3d_loss_grad(const float* params_flat, const int* layers, int n_layer
                         int precision_mode, void* workspace, size_t ws_bytes, void* stream);
 
 /* Value-only terms of the 4-input net (initial state, sources, the traction-free surface s33 = s13 = s23 = 0 of the half space):
- * pinn_data_loss_grad with four coordinates; targets SoA [n_out][n] or NULL, out_weights[n_out], loss_terms_out[n_out]. */
+ * pinn_data_loss_grad with four coordinates; targets SoA [n_out][n] or NULL, out_weights[n_out], loss_terms_out[n_out].
+ * Round 6: the BASELINE configs[4] net (10 x 128, 12 outputs) takes the fused kernel's one-stream instantiation here as well
+ * (pinn_path_for(.., PINN_HEAD_NC3D_DATA) = PINN_PATH_FUSED_LDS), every other layer list the two-kernel path. */
 int pinn_nc3d_data_loss_grad(const float* params_flat, const int* layers, int n_layers,
                              const float* x, const float* y, const float* z, const float* t, int64_t n,
                              const double lb[4], const double ub[4], int normalize,

@@ -72,9 +72,10 @@ struct FusedArgs {
     const float* set_x[4];
     const float* set_y[4];
     const float* set_t[4];
+    const float* set_z[4];     // 4-input instantiations only (the 3-D side sets, round 6)
     const float* set_targets[4];
     long set_n[4];
-    float set_tw[4][8];
+    float set_tw[4][16];       // (3-input nets: 8 used; the 3-D data head: up to 16 outputs)
     int set_head[4];           // 0: data head (targets, output weights); 1: hole traction of the plate's composite fields (PLATE:452-461)
     const float* set_aux[4];   // traction sets: [12][n] = D0[5], P0[5], nx, ny of the set's points
     u32x4* scratch;            // [gridDim.x * TILES][SCRATCH_BYTES]: per-tile images of the parked states
@@ -150,12 +151,12 @@ struct Fused {
     // SGPRs) took the three extra scalar values of the loop as +10 % launch time (25.2 against 22.3-23.3 ms per 1 M points, with the tail on or off)
     static constexpr bool XCD_TAIL = DIN_ == 3;
     static_assert(NS == 4 || NS == 1 || NS == 5, "wave residual head (4 streams), value-only data head (1 stream) or plate / 3-D head (5 streams)");
-    static_assert(DIN == 3 || (DIN == 4 && NS == 5), "4 inputs: the five-stream 3-D head only");
+    static_assert(DIN == 3 || (DIN == 4 && (NS == 5 || NS == 1)), "4 inputs: the five-stream 3-D head only");
     // NS = 5, 3 inputs: streams (value, x, y, t, tt) -- the fifth carries the second time derivative (PLATE:417-419) -- and the plate head:
     // composite F = P + D*N with the frozen nets' streams, plane-stress residuals (PLATE:358-439)
     static constexpr bool SECOND = NS == 5 && DIN == 3;
     static constexpr int NT = NS >= 4 ? (SECOND ? 3 : NS - 1) : 0;                 // first-order tangent streams 1..NT (stream s differentiates by input s - 1)
-    static constexpr int HEAD = DIN == 4 ? HEAD_NC3D : (NS == 4 ? HEAD_WAVE : (NS == 1 ? HEAD_DATA : HEAD_PLATE));
+    static constexpr int HEAD = (DIN == 4 && NS == 5) ? HEAD_NC3D : (NS == 4 ? HEAD_WAVE : (NS == 1 ? HEAD_DATA : HEAD_PLATE));
     static constexpr int NOG = DIN == 4 ? 16 : 8;              // outputs a lane gathers for the head
     static constexpr int LT = DIN == 4 ? LOSS_SLOTS_3D : 8;    // loss partial slots per tile and set
     // weight fragments in the fused format of repack_kernel: [T(V), T(V - T(V)), T(T(V)/LO_SCALE)] with V = FUSED_WEIGHT_SCALE * w
@@ -173,7 +174,9 @@ struct Fused {
     static_assert(!LDSOP || NP == 2, "the LDS-operand layout is built for the split-precision cases");
     // One stream at these widths (the value-only side sets loss_IC / loss_SRC / loss_NB / loss_FIX of the reference's 8 x 80 / 8 x 100 nets,
     // round 3): images of 6 / 8 KB, so ALL layer states S_0..S_NL of both tiles stay in LDS (NL + 1 slots) -- nothing is parked, no LDS-DMA.
-    static constexpr bool WSLDS = LDSOP && NS_ == 1;
+    // (the 3-D net's one-stream instantiation -- 10 layers: eleven 8 KB states per tile do not fit twice -- takes the PARKED one-slot layout of
+    // the five-stream kernel instead: 16 KB of LDS per tile, states through the scratch images; round 6)
+    static constexpr bool WSLDS = LDSOP && NS_ == 1 && DIN_ == 3;
     // Five streams at padded width 96 (the reference's plate net, 8 x 70: PLATE:885-887): images of 30 KB, and two tiles have room for
     // ONE state slot each beside the Z area (2 x 60 KB).  The LDS-DMA of S_L can then only start when the readers of S_{L+1} are done
     // -- in the hand-off window of layer L itself -- and that window waits for it.
@@ -212,7 +215,8 @@ struct Fused {
     static constexpr int CONST_BIAS_F = (NL - 1) * WIDTH + 16, CONST_F = CONST_BIAS_F + WIDTH * 4, CONST_B = CONST_F * 4;
     // (Five streams at width 64 fill the 160 KB with tensors alone: that instantiation reads the constants from memory.)
     static constexpr int BASE_SLOTS = WSLDS ? NL + 1 : (ONE_SLOT ? 1 : 2);
-    static constexpr bool CONST_LDS = TILES * (TENSOR_Z_B + BASE_SLOTS * IMG_B) + CONST_B <= 160 * 1024;
+    // (Four inputs: the first layer's rows are 32 bytes and read from memory wherever they are used -- q_first, wide_first --: no LDS copy.)
+    static constexpr bool CONST_LDS = DIN_ == 3 && TILES * (TENSOR_Z_B + BASE_SLOTS * IMG_B) + CONST_B <= 160 * 1024;
     static constexpr int CONST_USED = CONST_LDS ? CONST_B : 0;
     static constexpr bool SLDS = !LDSOP && 4 * (TENSOR_Z_B + (NL + 1) * IMG_B) + CONST_USED <= 160 * 1024;      // all 1-stream cases; 4 streams: 4x32 only
     // ZDB (round 4; the narrow four-stream layouts with parked states, i.e. the collocation kernel of the 8 x 64 / 4 x 64 nets): the WEIGHT
@@ -1169,7 +1173,7 @@ struct Fused {
             if constexpr (S1_WG_ANY) {                    // the tile's inputs: requested here, used a forward and six reverse layers later
                 bool valid;
                 long pidx;
-                load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + quad, c, sj.xin, valid, pidx);
+                load_inputs(a, a.x, a.y, a.t, a.z, a.n, step * TILES + quad, c, sj.xin, valid, pidx);
             }
             if constexpr (KEEP2) lds_barrier();           // the forward's barrier in front of its first state-slot write (see KEEP2)
             if constexpr (LDSOP) {
@@ -2686,7 +2690,7 @@ struct Fused {
             adj[0][4] = (gx * ny + gy * nx) * D0[4];
         } else {
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
+            for (int o = 0; o < NOG; ++o) {
                 float d = 0.0f;
                 const float* tg = a.set_targets[set];
                 if (o < a.net.nout) d = Y[0][o] - (tg ? tg[(long)o * a.set_n[set] + pidx] : 0.0f);
@@ -2744,7 +2748,7 @@ struct Fused {
         Down<NL - 1>::run(a, x, xin, Zn);
     }
 
-    static __device__ __forceinline__ void load_inputs(const FusedArgs& a, const float* px, const float* py, const float* pt, long n, long tile, int c,
+    static __device__ __forceinline__ void load_inputs(const FusedArgs& a, const float* px, const float* py, const float* pt, const float* pz, long n, long tile, int c,
                                                        float (&xin)[4], bool& valid, long& pidx) {
         const long p = tile * 16 + c;
         valid = p < n;
@@ -2752,7 +2756,7 @@ struct Fused {
         xin[0] = px[pidx] * a.sx[0] + a.ox[0];
         xin[1] = py[pidx] * a.sx[1] + a.ox[1];
         if constexpr (DIN == 4) {
-            xin[2] = a.z[pidx] * a.sx[2] + a.ox[2];
+            xin[2] = pz[pidx] * a.sx[2] + a.ox[2];
             xin[3] = pt[pidx] * a.sx[3] + a.ox[3];
         } else {
             xin[2] = pt[pidx] * a.sx[2] + a.ox[2];
@@ -2807,9 +2811,9 @@ struct Fused {
 #pragma unroll
                 for (int k = 1; k < FUSED_MAX_SETS; ++k)
                     if (k < a.nsets && step >= a.set_step0[k]) set = k;
-                load_inputs(a, a.set_x[set], a.set_y[set], a.set_t[set], a.set_n[set], (step - a.set_step0[set]) * TILES + wave, c, xin, valid, pidx);
+                load_inputs(a, a.set_x[set], a.set_y[set], a.set_t[set], a.set_z[set], a.set_n[set], (step - a.set_step0[set]) * TILES + wave, c, xin, valid, pidx);
             } else {
-                load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + wave, c, xin, valid, pidx);
+                load_inputs(a, a.x, a.y, a.t, a.z, a.n, step * TILES + wave, c, xin, valid, pidx);
             }
             x.tracer = fused_bid(a) == 0 && wave4 == 0 && lane == 0 && step == 2 * (long)a.grid;      // a steady-state step
             if constexpr (LDSOP) {                 // lane addresses derived from these are then formed where they are used, not hoisted and spilled
@@ -2829,7 +2833,8 @@ struct Fused {
                     float xo[4];
                     bool vo;
                     long po;
-                    load_inputs(a, a.x, a.y, a.t, a.n, step * TILES + (wave ^ 1), c, xo, vo, po);
+                    if constexpr (NS == 1) load_inputs(a, a.set_x[set], a.set_y[set], a.set_t[set], a.set_z[set], a.set_n[set], (step - a.set_step0[set]) * TILES + (wave ^ 1), c, xo, vo, po);
+                    else load_inputs(a, a.x, a.y, a.t, a.z, a.n, step * TILES + (wave ^ 1), c, xo, vo, po);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         xt[0][k] = wave ? xo[k] : xin[k];

@@ -15,7 +15,8 @@ namespace pinn {
 struct DataSet {                // one value-only point set of pinn_data_loss_grad_multi
     const float *x, *y, *t, *targets;
     long n;
-    float tw[8];
+    float tw[16];              // (3-input nets: 8 used; the 3-D data head: up to 16 outputs)
+    const float* z = nullptr;  // 4-input nets (the 3-D side sets)
     float* loss_out;
     int head = 0;              // 0: sum_o w_o (Y_o - target_o)^2;  1: hole traction of the plate's composite fields (HEAD_TRACTION), `aux` = [12][n]
     const float* aux = nullptr;
@@ -398,7 +399,8 @@ struct Host {
         sets[0].t = c.t;
         sets[0].targets = c.targets;
         sets[0].n = c.n;
-        for (int i = 0; i < 8; ++i) sets[0].tw[i] = c.tw[i];
+        sets[0].z = c.z;
+        for (int i = 0; i < 16; ++i) sets[0].tw[i] = c.tw[i];
         sets[0].loss_out = c.loss_out;
         sets[0].head = c.one_stream_head;
         sets[0].aux = c.aux;
@@ -443,8 +445,9 @@ struct Host {
         if constexpr (NS == 1) {
             DataSet sets[4];
             nsets = data_sets(c, sets);
+            constexpr int NTW = DIN == 4 ? 16 : 8;      // output weights of a set
             for (int k = 0; k < nsets; ++k)
-                for (int i = 0; i < 8; ++i) { const float v = sets[k].tw[i] < 0 ? -sets[k].tw[i] : sets[k].tw[i]; if (v > twmax) twmax = v; }
+                for (int i = 0; i < NTW; ++i) { const float v = sets[k].tw[i] < 0 ? -sets[k].tw[i] : sets[k].tw[i]; if (v > twmax) twmax = v; }
             twmax *= (float)(1u << c.adj_shift);
             if constexpr (F::WG_HI) twmax *= 1.0f / F::ZDB_SEED_SCALE;
             long s0 = 0;
@@ -454,11 +457,12 @@ struct Host {
                 a.set_x[k] = on ? sets[k].x : nullptr;
                 a.set_y[k] = on ? sets[k].y : nullptr;
                 a.set_t[k] = on ? sets[k].t : nullptr;
+                a.set_z[k] = on ? sets[k].z : nullptr;
                 a.set_targets[k] = on ? sets[k].targets : nullptr;
                 a.set_n[k] = on ? sets[k].n : 0;
                 a.set_head[k] = on ? sets[k].head : 0;
                 a.set_aux[k] = on ? sets[k].aux : nullptr;
-                for (int i = 0; i < 8; ++i) a.set_tw[k][i] = on && twmax > 0.0f ? sets[k].tw[i] / twmax : 0.0f;
+                for (int i = 0; i < 16; ++i) a.set_tw[k][i] = on && i < NTW && twmax > 0.0f ? sets[k].tw[i] / twmax : 0.0f;
                 if (on) { s0 += (sets[k].n + 16 * F::TILES - 1) / (16 * F::TILES); lo.p[k] = sets[k].loss_out; }
             }
             a.set_step0[4] = s0;
@@ -532,7 +536,7 @@ struct Host {
                                    grid, c.net.nparams, twmax, c.grad_out, c.accumulate, (const float*)a.loss_part, (long)grid * F::TILES, 0, 0, SLOTS, lo,
                                    (const int*)(b + p.wflags), SPLIT == 3 ? repack_blocks(c.net) : 0);
                 hipLaunchKernelGGL((reduce_loss_kernel<0>), dim3(1), dim3(256), 0, c.stream, (const float*)a.loss_part, (long)grid * F::TILES, nterms,
-                                   c.loss_out, 0, LOSS_SLOTS_3D, (const int*)(b + p.wflags), SPLIT == 3 ? repack_blocks(c.net) : 0);
+                                   c.loss_out, 0, LOSS_SLOTS_3D * SLOTS, (const int*)(b + p.wflags), SPLIT == 3 ? repack_blocks(c.net) : 0);      // (NS = 1: set 0's slots of [tile][FUSED_MAX_SETS][16])
                 return (int)hipGetLastError();
             }
             hipLaunchKernelGGL((reduce_grad_loss_kernel<0>), dim3((c.net.nparams + 63) / 64 + nsets), dim3(256), 0, c.stream, (const float*)a.partial,
@@ -649,9 +653,10 @@ struct Host {
             return 0;
         }
     }
+    template <int NS = 5>
     static long fused_images_3d(const NetDesc& net, size_t ws_bytes) {
         if constexpr (fused_has_3d()) {
-            typedef Fused<Op, SPLIT, WIDTH, 10, 5, false, 4> F;
+            typedef Fused<Op, SPLIT, WIDTH, 10, NS, false, 4> F;
             Plan p;
             plan_fixed<4>(net, 1, p);
             const size_t per_wg = (size_t)F::TILES * F::SCRATCH_BYTES;
@@ -675,6 +680,8 @@ struct Host {
                 if (SPLIT != 3) return PINN_ERR_PRECISION;
                 return fused_has_3d() && net.nl == 10 && net.din == 4 && net.nout == 12 && enough(fused_images_3d(net, ws_bytes)) ? PINN_PATH_FUSED_LDS : PINN_PATH_TWO_KERNEL;
             case PINN_HEAD_NC3D_DATA:
+                if (SPLIT != 3) return PINN_ERR_PRECISION;
+                return fused_has_3d() && net.nl == 10 && net.din == 4 && net.nout == 12 && enough(fused_images_3d<1>(net, ws_bytes)) ? PINN_PATH_FUSED_LDS : PINN_PATH_TWO_KERNEL;
             case PINN_HEAD_STREAMS: return SPLIT == 3 ? PINN_PATH_TWO_KERNEL : PINN_ERR_PRECISION;
             default: return PINN_ERR_LAYERS;
         }
@@ -716,13 +723,16 @@ struct Host {
     }
 
     // the 3-D head through the fused LDS-operand kernel: 10 hidden layers of padded width 128 (BASELINE configs[4])
+    // (NS = 5: the collocation head; NS = 1, round 6: a value-only side set -- source, initial or top-surface points -- through the one-stream
+    // instantiation with the same parked one-slot layout, so that no set of a 3-D training step is left on the two-kernel path)
+    template <int NS = 5>
     static int try_fused_3d(const Call& c, int* out) {
         if constexpr (fused_has_3d()) {
             if (c.net.nl != 10 || c.net.din != 4 || c.net.nout != 12) return 0;
             Plan p;
             if (((uintptr_t)c.ws & 255) != 0) return 0;
             plan_fixed<4>(c.net, c.n, p);
-            typedef Fused<Op, SPLIT, WIDTH, 10, 5, false, 4> F;
+            typedef Fused<Op, SPLIT, WIDTH, 10, NS, false, 4> F;
             const size_t per_wg = (size_t)F::TILES * F::SCRATCH_BYTES;
             if (c.ws_bytes < p.fixed_end + per_wg) return 0;
             long grid = (long)((c.ws_bytes - p.fixed_end) / per_wg);
@@ -732,7 +742,7 @@ struct Host {
             if (nsteps == 0) return 0;
             if (grid > nsteps) grid = nsteps;
             if (grid < FUSED_MIN_GRID && grid < nsteps) return 0;      // (see FUSED_MIN_GRID)
-            *out = fused_launch<10, 5, false, 4>(c, p, (int)grid, 12, nsteps);
+            *out = fused_launch<10, NS, false, 4>(c, p, (int)grid, 12, nsteps);
             ++g_path_counts[PINN_PATH_FUSED_LDS];
             return 1;
         } else {
@@ -826,7 +836,11 @@ struct Host {
         return PINN_ERR_PRECISION;
     }
     static int nc3d_data_loss_grad(const Call& c) {
-        if constexpr (SPLIT == 3) return loss_grad<1, HEAD_DATA3D>(c, c.net.nout);
+        if constexpr (SPLIT == 3) {
+            int rc = 0;
+            if (c.use_fused && try_fused_3d<1>(c, &rc)) return rc;
+            return loss_grad<1, HEAD_DATA3D>(c, c.net.nout);
+        }
         return PINN_ERR_PRECISION;
     }
     static int nc3d_fields(const Call& c) {

@@ -95,9 +95,10 @@ def test_path_for_names_the_path_of_every_layer_list(lib):
     assert lib.path_for(w(6, 140), "f16x3", "wave") == "fused-lds"               # CONF:891
     assert lib.path_for(w(6, 140), "f16x3", "data") == "fused-lds"               # CONF:901-947's IC / FIX / SRC sets (round 6)
     assert lib.path_for(w(10, 128, 12, 4), "f16x3", "nc3d") == "fused-lds"       # configs[4]
+    assert lib.path_for(w(10, 128, 12, 4), "f16x3", "nc3d_data") == "fused-lds"  # its value-only side sets (round 6: the one-stream instantiation of the parked layout)
     # depths / widths the fused kernel is not compiled for: they run, on the two-kernel path
     for layers, head in ((w(5, 64), "wave"), (w(6, 64), "data"), (w(4, 80), "wave"), (w(8, 140), "wave"), (w(8, 140), "data"), (w(8, 100, 5), "plate"),
-                         (w(8, 128, 12, 4), "nc3d"), (w(10, 128, 12, 4), "nc3d_data"), (w(8, 64, 5), "streams"), (w(8, 80), "wave")):
+                         (w(8, 128, 12, 4), "nc3d"), (w(8, 128, 12, 4), "nc3d_data"), (w(8, 64, 5), "streams"), (w(8, 80), "wave")):
         mode = "bf16" if layers == w(8, 80) else "f16x3"       # (the LDS-operand layouts exist for the split modes only)
         assert lib.path_for(layers, mode, head) == "two-kernel", (layers, head)
     assert lib.path_for(w(8, 64), "fp32", "wave") == "fp32"

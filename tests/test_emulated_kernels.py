@@ -620,6 +620,31 @@ def test_fused_nc3d_emulated(emu):
             assert rel(loss[:12], ss) < 2e-6 and rel(grad, g) < 5e-6, (fused, n, rel(loss[:12], ss), rel(grad, g))
         emu.set_fused(True)
         assert rel(res[True][1], res[False][1].astype(np.float64)) < 5e-6
+        # round 6: the value-only side sets of the 3-D step (source, initial state, traction-free surface) through the ONE-stream instantiation of
+        # the same parked layout (Fused<.., 128, 10, 1, false, 4>): no set of a 3-D training step is left on the two-kernel path
+        tgt = rng.standard_normal((n, 12))
+        ow = np.array([1, 1, 1, 0.5, 0.5, 0.5, 0, 0, 2, 0, 2, 2.0]) / n
+        ss_d, g_d, _ = n3.nc3d_data_loss_grad(flat, layers, *X.T, lb, ub, True, tgt, ow)
+        tg = np.ascontiguousarray(tgt.T.astype(np.float32))
+        resd = {}
+        for fused in (True, False):
+            emu.set_fused(fused)
+            emu.path_counts(reset=True)
+            loss = np.full(16, np.nan, np.float32)
+            grad = np.full(p32.size, np.nan, np.float32)
+            emu.nc3d_data_loss_grad(p32.ctypes.data, layers, *ptr, n, lb, ub, True, tg.ctypes.data, ow, loss.ctypes.data, grad.ctypes.data, False,
+                                    "f16x3", ws.ctypes.data, wsb)
+            pc = emu.path_counts(reset=True)
+            assert pc["fused-lds" if fused else "two-kernel"] == 1 and sum(pc.values()) == 1, (fused, pc)
+            resd[fused] = grad.copy()
+            assert rel(loss[:12], ss_d) < 2e-6 and rel(grad, g_d) < 5e-6, (fused, n, rel(loss[:12], ss_d), rel(grad, g_d))
+        emu.set_fused(True)
+        assert not np.array_equal(resd[True], resd[False])
+        # ... and accumulated behind the collocation call, as a training step does
+        grad = res[True][1].copy()
+        emu.nc3d_data_loss_grad(p32.ctypes.data, layers, *ptr, n, lb, ub, True, 0, ow, loss.ctypes.data, grad.ctypes.data, True, "f16x3", ws.ctypes.data, wsb)
+        ss_0, g_0, _ = n3.nc3d_data_loss_grad(flat, layers, *X.T, lb, ub, True, None, ow)
+        assert rel(loss[:12], ss_0) < 2e-6 and rel(grad, g + g_0) < 5e-6
 
 
 def test_fused_width160_emulated(emu):

@@ -59,8 +59,22 @@ def test_nc3d_loss_grad_and_fields_vs_oracle(dev, layers, n, prec, tol):
     tgt = rng.standard_normal((n, 12))
     ow = np.array([1, 1, 1, 0.5, 0.5, 0.5, 0, 0, 2, 0, 2, 2.0]) / n
     ssd, gd, _ = n3.nc3d_data_loss_grad(flat, layers, *X.T, LB, UB, True, tgt, ow)
+    eng.lib.path_counts(reset=True)
     lossd, gradd = eng.nc3d_data_loss_grad(theta, *cols, LB, UB, True, to_dev(tgt.T, dev), ow)
     assert rel(lossd.cpu().numpy(), ssd) < tol and rel(gradd.cpu().numpy(), gd) < tol
+    # round 6: the value-only sets of the BASELINE configs[4] net take the fused one-stream kernel too (Fused<.., 128, 10, 1, false, 4>); other
+    # depths stay on the two-kernel path -- and pinn_path_for says which
+    pc = eng.lib.path_counts(reset=True)
+    expect = "fused-lds" if layers == LAYERS else "two-kernel"
+    assert eng.path("nc3d_data") == expect and pc[expect] == 1 and sum(pc.values()) == 1, (layers, pc)
+    if layers == LAYERS:
+        eng.lib.set_fused(False)
+        try:
+            l2, g2 = eng.nc3d_data_loss_grad(theta, *cols, LB, UB, True, to_dev(tgt.T, dev), ow)
+        finally:
+            eng.lib.set_fused(True)
+        assert eng.lib.path_counts(reset=True)["two-kernel"] == 1
+        assert rel(g2.cpu().numpy(), gd) < tol and rel(gradd.cpu().numpy(), g2.cpu().numpy().astype(np.float64)) < tol
 
 
 def test_nc3d_plane_wave_known_answer_through_the_kernels(dev):
