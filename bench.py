@@ -187,6 +187,11 @@ def measure_traffic(argv, points_per_launch, timeout_s=240):
     vals = {}
     tmp = tempfile.mkdtemp(prefix="pinn_traffic_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
+    if "MASTER_PORT" in env:        # (--always-reduce: the child makes a process group of its own, and this process still holds its port)
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            env["MASTER_PORT"] = str(sk.getsockname()[1])
     t0 = time.perf_counter()
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
