@@ -2,6 +2,7 @@
 tools/studies/wgrad_operand_study.py: forward f16x3, reverse chain with 2^11-scaled adjoint low parts, exact states in the activation reverse)
 with  Wbar_l = S_l^T Z_l  computed as
   full  : S (hi + lo) x Z (hi + lo)      3 MFMAs per product (what the LDS-operand layouts do today)
+  s_lo8 : S (hi + lo8) x Z (hi + lo)      3 MFMAs, the state's low part as the one-byte e5m2 the narrow kernels park (would cut the parked images by a quarter)
   s_hi  : S hi        x Z (hi + lo)      2 MFMAs; the state image the weight gradient reads needs no low part
   z_hi  : S (hi + lo) x Z hi             2 MFMAs; the adjoint image needs no low part
   hi    : S hi        x Z hi             1 MFMA (round 4: fails at inf10s)
@@ -25,13 +26,15 @@ def mm_bwd(Z, Wt):
 def wg(S, Z, mode):
     S = np.asarray(S, f32); Z = np.asarray(Z, f32)
     Sh = r16(S); Sl = r16(S - Sh); Zh = r16(Z); Zl = r16((Z - Zh) * f32(2048))
+    if mode == 's_lo8':          # the parked image's low part as ONE byte (the top byte of the fp16: e5m2, three significant bits) -- the narrow kernels' LO8 format
+        Sl = (Sl.astype(np.float16).view(np.uint16) & np.uint16(0xff00)).view(np.float16).astype(f32)
     out = Sh.T @ Zh
-    if mode in ('full', 's_hi'): out = out + (Sh.T @ Zl) / f32(2048)
-    if mode in ('full', 'z_hi'): out = out + Sl.T @ Zh
+    if mode in ('full', 's_hi', 's_lo8'): out = out + (Sh.T @ Zl) / f32(2048)
+    if mode in ('full', 'z_hi', 's_lo8'): out = out + Sl.T @ Zh
     return out
 def bsum(Z, mode):
     Z = np.asarray(Z, f32); Zh = r16(Z); Zl = r16((Z - Zh) * f32(2048))
-    return Zh.sum(0) + (Zl.sum(0) / f32(2048) if mode in ('full', 's_hi') else 0)
+    return Zh.sum(0) + (Zl.sum(0) / f32(2048) if mode in ('full', 's_hi', 's_lo8') else 0)
 
 def run(X, Ws, bs, lb, ub, normalize, tw, mode, seed_scale):
     X = np.asarray(X, f32); N = X.shape[0]
@@ -83,7 +86,7 @@ for case in sys.argv[1:] or ['inf10s', 'inf20s', 'semi16s', 'conf14s']:
     _, g32, _ = po.wave2d_loss_grad(flat.astype(f32), layers, X[:, 0], X[:, 1], X[:, 2], lb, ub, norm, term_weights=tw, dtype=f32)
     e32 = layer_errs(g32, g64, layers); eb32 = layer_errs(g32, g64, layers, True)
     print(f'{case} layers {layers[1]}x{L - 1} n={m}: host fp32 rel err per W layer ' + ' '.join(f'{e:.1e}' for e in e32))
-    for mode in ('full', 's_hi', 'z_hi', 'hi'):
+    for mode in ('full', 's_lo8', 's_hi', 'z_hi', 'hi'):
         for ssc in (1.0, float(m)):
             gv = run(X, Ws, bs, lb, ub, norm, tw, mode, ssc)
             e = layer_errs(gv, g64, layers); eb = layer_errs(gv, g64, layers, True)
