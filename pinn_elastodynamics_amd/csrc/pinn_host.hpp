@@ -149,7 +149,7 @@ struct Host {
     static constexpr size_t FUSED_ACC_BYTES = WIDTH <= 64 ? FUSED_ACC_W64 : (WIDTH <= 96 ? 72 * 1024 : 160 * 1024);     // per weight-gradient wave: in-memory accumulator blocks
     // fused_step_kernel (collocation set + side sets of a training step in one launch): the narrow layouts, and (round 6) every LDS-operand
     // layout that has both of its parts -- the reference's own nets pay 0.36 ms (8 x 80) / 0.61 ms (8 x 100) of a 6.6 / 10.6 ms step for their
-    // side sets as a second launch (profiles/r06_wide_kernel_stats_two_launches.csv)
+    // side sets as a second launch (profiles/r06_wide_kernel_stats.csv)
     static constexpr bool step_has() { return true; }
     template <int NSC>
     static constexpr bool step_has_ns() {
