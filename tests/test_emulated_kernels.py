@@ -622,6 +622,8 @@ def test_fused_nc3d_emulated(emu):
         assert rel(res[True][1], res[False][1].astype(np.float64)) < 5e-6
         # round 6: the value-only side sets of the 3-D step (source, initial state, traction-free surface) through the ONE-stream instantiation of
         # the same parked layout (Fused<.., 128, 10, 1, false, 4>): no set of a 3-D training step is left on the two-kernel path
+        if n != 45:
+            continue        # (one size is enough here: the GPU test runs it at 1500 points)
         tgt = rng.standard_normal((n, 12))
         ow = np.array([1, 1, 1, 0.5, 0.5, 0.5, 0, 0, 2, 0, 2, 2.0]) / n
         ss_d, g_d, _ = n3.nc3d_data_loss_grad(flat, layers, *X.T, lb, ub, True, tgt, ow)
@@ -779,7 +781,6 @@ def _step_case(emu, layers, n, n_side, prec, seed, with_adam):
     ([3] + 8 * [64] + [7], 130, (40,), "bf16", False),              # one MFMA per product, no optimizer step (the data-parallel form)
     ([3] + 8 * [80] + [7], 100, (40, 33), "f16x3", True),           # round 6: the LDS-operand layouts take the one-launch step too -- INF:645's net (padded width 96, two state slots)
     ([3] + 8 * [100] + [7], 70, (35,), "f16x3", False),             # SEMI:679's net (padded width 128: one slot, QUAD chain, streamed sums)
-    ([3] + 6 * [140] + [7], 70, (35, 20), "f16x3", True),           # CONF:891's net (padded width 160): the step call makes the separate calls inside (measured: no gain as one launch)
 ])
 def test_step_call_is_the_separate_calls_bit_for_bit_emulated(emu, layers, n, n_side, prec, with_adam):
     """pinn_wave2d_step (round 5): collocation set + side sets in ONE persistent launch (fused_step_kernel: the side sets' workgroups behind the
