@@ -41,6 +41,9 @@
 #ifndef PINN_LO8_ENABLED
 #define PINN_LO8_ENABLED 1
 #endif
+#ifndef PINN_FWD8_ENABLED
+#define PINN_FWD8_ENABLED 1      // 0: the padded-width-96 layouts keep the forward on the four chain waves alone (A / B timing)
+#endif
 #ifndef PINN_QUAD_ENABLED
 #define PINN_QUAD_ENABLED 1      // 0: the padded-width-128 layouts keep the round-3 chain (two waves per tile, half of the feature blocks each): for A / B timing
 #endif
@@ -1158,6 +1161,8 @@ struct Fused {
         }
         Sums pend, ld;
         Ctx xs1;                                          // S1_BY_WG: addressing of chain tile `quad` as far as the first layer needs it
+        Ctx xf;                                   // FWD8: this wave's addressing state for its block of the forward (tile ftile)
+        if constexpr (FWD8) xf.init(a, lds, ftile, lane, c, q);
         S1Job sj;
         sj.x = &xs1;
         if constexpr (S1_WG_ANY) {
@@ -1176,7 +1181,16 @@ struct Fused {
                 load_inputs(a, a.x, a.y, a.t, a.z, a.n, step * TILES + quad, c, sj.xin, valid, pidx);
             }
             if constexpr (KEEP2) lds_barrier();           // the forward's barrier in front of its first state-slot write (see KEEP2)
-            if constexpr (LDSOP) {
+            if constexpr (FWD8) {
+                float xf_in[4];
+                bool valid;
+                long pidx;
+                load_inputs(a, a.x, a.y, a.t, a.z, a.n, step * TILES + ftile, c, xf_in, valid, pidx);
+                xf.imgoff = in_loop(xf.imgoff);
+                xf.lane16 = in_loop(xf.lane16);
+                __syncthreads();                          // step barrier
+                f8_wg_forward(a, xf, xf_in, quad >> 1, scr_st, lane16, tile_lds, quad);
+            } else if constexpr (LDSOP) {
                 __syncthreads();                          // step barrier (see the chain role): this wave's reads of the previous step are done
                 // the forward's exchange barriers between the two halves of a tile; behind barrier l the image of S_{l+1} is complete and
                 // this wave parks its share of it (the records it will bring back by LDS-DMA: same wave, same addresses, program order)
@@ -2020,8 +2034,9 @@ struct Fused {
         half_store(outimg, h, out);
         if (kept_in_lds(l + 1)) half_store(x.imgS(l + 1), h, out);       // S_{NL-1} also into its reverse slot (KEEP_W)
     }
+    // first layer (VALU) of local block J of half h
     template <int J>
-    static __device__ __forceinline__ void wide_first(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, u32x4 (&Bn)[NS][1][HR][NP]) {
+    static __device__ __forceinline__ void first_block(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, u32x4 (&Bn)[NS][1][HR][NP]) {
         const int mb = half_block(h, J);
         float vals[NS][4];
 #pragma unroll
@@ -2050,8 +2065,151 @@ struct Fused {
             if constexpr (SECOND) vals[4][r] = -2.0f * hh * vals[3][r] * (a.sx[2] * w[2]);      // z_tt = 0 at the first layer
         }
         emit_state<J, HR>(Bn, vals);
+    }
+    template <int J>
+    static __device__ __forceinline__ void wide_first(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, u32x4 (&Bn)[NS][1][HR][NP]) {
+        first_block<J>(a, x, xin, h, Bn);
         if constexpr (J + 1 < HB) wide_first<J + 1>(a, x, xin, h, Bn);
     }
+    // ---------------------------------------------------------------------------------------------
+    // FWD8 (round 6; padded width 96: the reference's 8 x 80 net, INF:645, and the plate's 8 x 70, PLATE:885)
+    // ---------------------------------------------------------------------------------------------
+    // These two layouts are not bound by bytes (ablations, profiles/r06_footprint_and_cache_policy.txt section 6: images -13 %, sums -4 %, fragments
+    // -5 %); 37 % of their step is the forward (profiles/r06_phase_trace_wide.txt: 36.7 k of 99.5 k cycles), in which the four chain waves run at 38 %
+    // of their matrix pipe while the four weight-gradient waves only park images.  The state lives in LDS images anyway, so the forward's feature
+    // blocks are dealt to all EIGHT waves: a chain wave keeps the PAIR of its half (blocks 0, 1 | 4, 5: one fragment record), the weight-gradient
+    // wave (tile = quad & 1, half = quad >> 1) computes the half's SINGLE block (2 | 3: half of record 1).  The reverse is unchanged (three blocks
+    // per chain half).  Barriers: one per layer for all eight waves, as before; the weight-gradient wave parks S_l BEHIND its block of layer l.
+    // Measured (profiles/r06_fwd8_ab.txt): 8 x 80 -1.9 ... -2.7 %, plate 8 x 70 -1.9 ... -4.8 % of the launch on two boxes -- a third of what the
+    // block count promised: the forward's 4.4 k cycles per layer did NOT move with two blocks instead of three (nor with a second layer of fragment
+    // distance, nor much without the parks: 3.7 k), i.e. a forward layer of these layouts is bound by its barrier-to-barrier latency chain (operand
+    // reads, dependent MFMA chains, the tanh epilogue, the exchange barrier), not by the chain wave's issue; what the step gains (100 k -> 94 k
+    // cycles) comes from the weight-gradient role starting its reverse with warm fragments and a shorter top of the reverse.
+    static constexpr bool FWD8 = LDSOP && !WSLDS && WB == 6 && PINN_FWD8_ENABLED != 0;
+    template <int J0, int NJ>            // a wave's forward block set: local blocks J0 .. J0 + NJ - 1 of half h
+    struct F8 {
+        static constexpr int NITJ = KS * NJ;                 // items (k-step, block) of a layer
+#ifndef PINN_F8_DEPTH
+#define PINN_F8_DEPTH 1
+#endif
+        // fragment slots in flight: PINN_F8_DEPTH whole layers of this wave's items.  (Two layers of distance -- the dealt forward leaves the
+        // registers for it -- measured 0.5-4 % SLOWER than one: profiles/r06_fwd8_ab.txt; the forward layer is not waiting for its fragments.)
+        static constexpr int DEPTH = PINN_F8_DEPTH;
+        static constexpr int RINGJ = DEPTH * NITJ;
+        static_assert(DEPTH == 1 || DEPTH == 2, "ring phase: item 0 of layer l in slot 0 (l odd) or NITJ (l even, DEPTH 2)");
+        static __device__ __forceinline__ int frag(int frag_l0, int h, int t) { return frag_l0 + half_block(h, J0 + t % NJ) * KS + t / NJ; }
+        // PAR = l & 1; t = item of layer l, may run DEPTH layers past it
+        template <int PAR>
+        static __device__ __forceinline__ void request(const Ctx& x, int l, int h, int t, u32x4 (&Ar)[RINGJ][1][FP]) {
+            constexpr int T0 = (PAR || DEPTH == 1) ? 0 : NITJ;
+            const int ll = l + t / NITJ, tt = t % NITJ;
+            u32x4 (&slot)[1][FP] = Ar[(T0 + t) % RINGJ];
+            if (ll < NL) load_afrags<1, FP>(x, frag(FI::fwd_mid(ll, 0, 0), h, tt), slot);
+            else if (J0 == 0 && ll == NL && tt < KS) load_afrags<1, FP>(x, FI::fwd_last(NL, tt), slot);      // the output layer's k-steps (chain waves)
+        }
+        template <int PAR>
+        static __device__ __forceinline__ void gemm(const Ctx& x, int l, int h, const char* in, u32x4 (&Ar)[RINGJ][1][FP], f32x4 (&acc)[NJ][NS]) {
+            constexpr int T0 = (PAR || DEPTH == 1) ? 0 : NITJ;
+            u32x4 Bk[NS][1][1][NP];
+#pragma unroll
+            for (int t = 0; t < NITJ; ++t) {
+                if (t % NJ == 0) op_load(in, t / NJ, Bk);
+                fwd_kstep<0, 1>(Ar[(T0 + t) % RINGJ], Bk, acc[t % NJ]);
+                request<PAR>(x, l, h, t + RINGJ, Ar);
+            }
+        }
+        // the set's part of the local fragments -> the image: the pair's record 2h, the single block's 8 bytes of record 1
+        static __device__ __forceinline__ void store(char* img, int h, const u32x4 (&Fl)[NS][1][HR][NP]) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s)
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    if constexpr (J0 == 0) *reinterpret_cast<u32x4*>(img + ((s * KS + 2 * h) * NP + p) * 1024) = Fl[s][0][0][p];
+                    if constexpr (J0 + NJ > 2) *reinterpret_cast<u32x2*>(img + ((s * KS + 1) * NP + p) * 1024 + 8 * h) = u32x2{Fl[s][0][1][p][0], Fl[s][0][1][p][1]};
+                }
+        }
+        static __device__ __forceinline__ void first(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, u32x4 (&Bn)[NS][1][HR][NP]) {
+            first_block<J0>(a, x, xin, h, Bn);
+            if constexpr (NJ == 2) first_block<J0 + 1>(a, x, xin, h, Bn);
+        }
+        // one hidden weight layer l: S_l (image `in`) -> this set's blocks of S_{l+1} (image `outimg`)
+        template <int PAR>
+        static __device__ __forceinline__ void layer(const Ctx& x, int l, int h, const char* in, char* outimg, u32x4 (&Af)[RINGJ][1][FP]) {
+            f32x4 acc[NJ][NS];
+            if constexpr (CONST_LDS) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc_init(load_bias(x, l, half_block(h, J0 + j)), acc[j]);
+                gemm<PAR>(x, l, h, in, Af, acc);
+            } else {
+                f32x4 bias[NJ];          // (constants from memory: requested here, added behind the layer's MFMAs -- see wide_fwd_layer)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    bias[j] = load_bias(x, l, half_block(h, J0 + j));
+                    acc_zero(acc[j]);
+                }
+                gemm<PAR>(x, l, h, in, Af, acc);
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j][0] += bias[j];
+            }
+            u32x4 out[NS][1][HR][NP];
+            fwd_valu<J0, HR>(acc[0], out);
+            if constexpr (NJ == 2) fwd_valu<J0 + 1, HR>(acc[1], out);
+            store(outimg, h, out);
+            if (kept_in_lds(l + 1)) store(x.imgS(l + 1), h, out);       // S_{NL-1} also into its reverse slot (KEEP_W)
+        }
+    };
+    typedef F8<0, 2> F8P;      // chain wave: the pair
+    typedef F8<2, 1> F8S;      // weight-gradient wave: the single block
+    // chain wave's forward under FWD8: wide_forward with the pair only
+    static __device__ __forceinline__ void f8_chain_forward(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, f32x4 (&acca)[NS]) {
+        char* opa = x.tenZ + x.imgoff;
+        char* opb = x.tenZ + TENSOR_Z_B + x.imgoff;
+        u32x4 Af[F8P::RINGJ][1][FP];
+#pragma unroll
+        for (int t = 0; t < F8P::RINGJ; ++t) F8P::template request<1>(x, 1, h, t, Af);
+        {
+            u32x4 S1[NS][1][HR][NP];
+            F8P::first(a, x, xin, h, S1);
+            F8P::store(opa, h, S1);
+        }
+        lds_barrier();
+        fused_stamp(a, x.tracer, 32);
+        for (int l = 1; l < NL; ++l) {
+            if (l & 1) F8P::template layer<1>(x, l, h, opa, opb, Af);
+            else F8P::template layer<0>(x, l, h, opb, opa, Af);
+            lds_barrier();
+            fused_stamp(a, x.tracer, 32 + l);
+        }
+        acc_init(load_bias(x, NL, 0), acca);
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            u32x4 Bk[NS][1][1][NP];
+            op_load(opb, kk, Bk);
+            fwd_kstep<0, 1>(Af[((NL - 1) * F8P::NITJ + kk) % F8P::RINGJ], Bk, acca);      // (requested during the last hidden layers)
+        }
+    }
+    // weight-gradient wave's forward under FWD8: its half's single block of every layer, and the park of the finished images as before
+    static __device__ __forceinline__ void f8_wg_forward(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, __amdgpu_buffer_rsrc_t scr_st, unsigned lane16,
+                                                         const char* tile_lds, int quad) {
+        char* opa = x.tenZ + x.imgoff;
+        char* opb = x.tenZ + TENSOR_Z_B + x.imgoff;
+        u32x4 Af[F8S::RINGJ][1][FP];
+#pragma unroll
+        for (int t = 0; t < F8S::RINGJ; ++t) F8S::template request<1>(x, 1, h, t, Af);
+        {
+            u32x4 S1[NS][1][HR][NP];
+            F8S::first(a, x, xin, h, S1);
+            F8S::store(opa, h, S1);
+        }
+        lds_barrier();                                       // S_1 complete
+        for (int l = 1; l < NL; ++l) {
+            if (l & 1) F8S::template layer<1>(x, l, h, opa, opb, Af);
+            else F8S::template layer<0>(x, l, h, opb, opa, Af);
+            if (!kept_in_lds(l)) park_image(scr_st, lane16, tile_lds, l, quad);      // S_l: complete since the previous barrier, read by this layer, overwritten behind the next one
+            lds_barrier();                                   // S_{l+1} complete
+        }
+    }
+
     // forward of one tile (this wave's half): returns the output layer's products (acca, both halves compute them) for fwd_head; S_NL
     // ends in the second buffer.  One LDS barrier behind every layer: the halves exchange their blocks through the image.
     static __device__ __forceinline__ void wide_forward(const FusedArgs& a, const Ctx& x, const float (&xin)[4], int h, f32x4 (&acca)[NS]) {
@@ -2841,6 +2999,8 @@ struct Fused {
                         xt[1][k] = wave ? xin[k] : xo[k];
                     }
                     quad_forward(a, x, xt, wave4, acca);
+                } else if constexpr (FWD8) {
+                    f8_chain_forward(a, x, xin, half, acca);
                 } else {
                     wide_forward(a, x, xin, half, acca);
                 }
