@@ -397,6 +397,12 @@ int pinn_debug_set_xcd_bonus(int permille);
 /* Testing hook (process-wide): at most `cap` workgroups in a fused per-family launch (0: the default, one per compute unit) -- several steps per
  * workgroup on small test inputs.  Returns the previous setting. */
 int pinn_debug_set_fused_grid_cap(int cap);
+/* Query (round 6): the per-workgroup memory of the fused collocation kernel a layer list takes (f16x3; head = PINN_HEAD_WAVE / _PLATE / _NC3D) and the
+ * cache policy compiled into it.  A persistent workgroup owns `*images_bytes` of parked state images and `*sums_bytes` of running weight-gradient
+ * sums; a full grid is 256 of them.  Where that exceeds the 256 MB Infinity Cache the kernel marks ONE of the two classes non-temporal so that the other
+ * stays resident (profiles/r06_footprint_and_cache_policy.txt).  Returns 0 (no hint), 1 (the sums), 2 (the images), or
+ * PINN_ERR_LAYERS for a layer list without fused kernel.  Host-only, no device call. */
+int pinn_debug_cache_policy(const int* layers, int n_layers, int head, size_t* images_bytes, size_t* sums_bytes);
 /* Profiling hook (process-wide): device buffer of 128 uint64 that the fused kernel fills with shader-clock
  * stamps of its phases (workgroup 0 only); NULL turns it off. */
 void pinn_debug_set_stamp_buffer(void* device_u64x128);

@@ -205,6 +205,17 @@ class PinnLib:
             raise PinnLibError(f"pinn_path_for failed: {self.lib.pinn_error_string(rc).decode()} (code {rc})")
         return PATHS[rc]
 
+    def cache_policy(self, layers, head: str = "wave") -> dict:
+        """pinn_debug_cache_policy: per-workgroup bytes of the fused collocation kernel's two memory classes and which of them (if any) the
+        instantiation marks non-temporal -- {'policy': 'none' | 'sums' | 'images', 'images_bytes', 'sums_bytes', 'grid_bytes' (256 workgroups)}"""
+        im, su = C.c_size_t(0), C.c_size_t(0)
+        self.lib.pinn_debug_cache_policy.argtypes = [C.POINTER(C.c_int), C.c_int, C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        self.lib.pinn_debug_cache_policy.restype = C.c_int
+        rc = int(self.lib.pinn_debug_cache_policy(self._ints(layers), len(layers), HEADS[head], C.byref(im), C.byref(su)))
+        if rc < 0:
+            raise PinnLibError(f"pinn_debug_cache_policy failed: {self.lib.pinn_error_string(rc).decode()} (code {rc})")
+        return {"policy": ("none", "sums", "images")[rc], "images_bytes": int(im.value), "sums_bytes": int(su.value), "grid_bytes": 256 * (int(im.value) + int(su.value))}
+
     def path_counts(self, reset: bool = False) -> dict:
         """calls per path since the last reset (pinn_debug_path_counts)"""
         buf = (C.c_int64 * 5)()

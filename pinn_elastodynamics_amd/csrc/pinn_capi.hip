@@ -110,6 +110,13 @@ bool xcd_tail_device_ok() {
 }
 }
 
+template <class F>
+static int cache_policy_of(size_t* images, size_t* sums) {
+    if (images) *images = F::IMAGES_WG_BYTES;
+    if (sums) *sums = F::SUMS_WG_BYTES;
+    return F::NT_SUMS ? 1 : (F::NT_IMAGES ? 2 : 0);
+}
+
 extern "C" {
 
 int pinn_abi_version(void) { return 2; }      // 2 (round 6): PINN_IPC_HANDLE_BYTES 64 -> 128, pinn_p2p_set_timeout_ms / _peek_status, pinn_wave2d_step_checked
@@ -167,6 +174,35 @@ int pinn_debug_set_xcd_bonus(int permille) {
     const int old = g_xcd_tail_permille;
     g_xcd_tail_permille = permille < 0 ? 0 : (permille > 200 ? 200 : permille);
     return old;
+}
+
+int pinn_debug_cache_policy(const int* layers, int n_layers, int head, size_t* images_bytes, size_t* sums_bytes) {
+    const int din = head == PINN_HEAD_NC3D ? 4 : 3;
+    NetDesc net;
+    int width = 0;
+    const int rc = decode_net(layers, n_layers, net, width, din);
+    if (rc) return rc;
+    // (the instantiations the f16x3 families ship: pinn_host.hpp, Host::fused_depth / fused_has_3d)
+    if (head == PINN_HEAD_NC3D) {
+        if (width == 128 && net.nl == 10 && net.nout == 12) return cache_policy_of<Fused<OpF16, 3, 128, 10, 5, false, 4>>(images_bytes, sums_bytes);
+        return PINN_ERR_LAYERS;
+    }
+    if (head == PINN_HEAD_PLATE) {
+        if (width == 32 && net.nl == 4) return cache_policy_of<Fused<OpF16, 3, 32, 4, 5>>(images_bytes, sums_bytes);
+        if (width == 64 && net.nl == 4) return cache_policy_of<Fused<OpF16, 3, 64, 4, 5>>(images_bytes, sums_bytes);
+        if (width == 64 && net.nl == 8) return cache_policy_of<Fused<OpF16, 3, 64, 8, 5>>(images_bytes, sums_bytes);
+        if (width == 96 && net.nl == 8) return cache_policy_of<Fused<OpF16, 3, 96, 8, 5>>(images_bytes, sums_bytes);
+        return PINN_ERR_LAYERS;
+    }
+    if (head != PINN_HEAD_WAVE) return PINN_ERR_LAYERS;
+    if (width == 32 && net.nl == 4) return cache_policy_of<Fused<OpF16, 3, 32, 4, 4>>(images_bytes, sums_bytes);
+    if (width == 32 && net.nl == 8) return cache_policy_of<Fused<OpF16, 3, 32, 8, 4>>(images_bytes, sums_bytes);
+    if (width == 64 && net.nl == 4) return cache_policy_of<Fused<OpF16, 3, 64, 4, 4>>(images_bytes, sums_bytes);
+    if (width == 64 && net.nl == 8) return cache_policy_of<Fused<OpF16, 3, 64, 8, 4>>(images_bytes, sums_bytes);
+    if (width == 96 && net.nl == 8) return cache_policy_of<Fused<OpF16, 3, 96, 8, 4>>(images_bytes, sums_bytes);
+    if (width == 128 && net.nl == 8) return cache_policy_of<Fused<OpF16, 3, 128, 8, 4>>(images_bytes, sums_bytes);
+    if (width == 160 && net.nl == 6) return cache_policy_of<Fused<OpF16, 3, 160, 6, 4>>(images_bytes, sums_bytes);
+    return PINN_ERR_LAYERS;
 }
 
 int pinn_debug_set_fused_grid_cap(int cap) { const int old = g_fused_grid_cap; g_fused_grid_cap = cap < 0 ? 0 : cap; return old; }

@@ -111,3 +111,28 @@ def test_path_for_names_the_path_of_every_layer_list(lib):
     with pytest.raises(PinnLibError):
         lib.path_for(w(8, 64), "bf16", "plate")
     assert lib.path_counts(reset=True).keys() == {"fused-registers", "fused-lds", "two-kernel", "fp32"}
+
+
+def test_cache_policy_of_the_fused_layouts(lib):
+    """pinn_debug_cache_policy (round 6): the layouts whose persistent grid -- 256 x (parked images + running sums) -- exceeds the 256 MB Infinity
+    Cache mark ONE of their two memory classes non-temporal: the 3-D net its sums, the 6 x 140 net its images; every layout
+    that fits marks nothing (measured: they lose 2-10 % with either class marked).  A change of a layout's scratch or sums sizes that flips a policy
+    shows here, not in a benchmark."""
+    from pinn_elastodynamics_amd.capi import PinnLibError
+    w = lambda depth, width, nout=7, din=3: [din] + depth * [width] + [nout]
+    MB = 1 << 20
+    got = {name: lib.cache_policy(layers, head) for name, layers, head in (
+        ("8x64", w(8, 64), "wave"), ("plate8x64", w(8, 64, 5), "plate"), ("8x80", w(8, 80), "wave"), ("plate8x70", w(8, 70, 5), "plate"),
+        ("8x100", w(8, 100), "wave"), ("6x140", w(6, 140), "wave"), ("3d", w(10, 128, 12, 4), "nc3d"))}
+    assert {k: v["policy"] for k, v in got.items()} == {"8x64": "none", "plate8x64": "none", "8x80": "none", "plate8x70": "none", "8x100": "none",
+                                                        "6x140": "images", "3d": "sums"}, got
+    for k, v in got.items():
+        over = v["grid_bytes"] > 224 * MB
+        assert over == (v["policy"] != "none"), (k, v)
+        if v["policy"] == "sums":
+            assert v["sums_bytes"] <= v["images_bytes"]          # the class that moves fewer bytes per step is the one marked
+        if v["policy"] == "images":
+            assert v["images_bytes"] < v["sums_bytes"]
+    assert 300 * MB < got["3d"]["grid_bytes"] < 340 * MB and 200 * MB < got["8x100"]["grid_bytes"] < 224 * MB
+    with pytest.raises(PinnLibError):
+        lib.cache_policy(w(5, 64), "wave")
